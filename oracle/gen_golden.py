@@ -1,0 +1,372 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (imported from /root/reference).
+
+Run only in the build container (the reference does not exist on the GPU box):
+
+    python oracle/gen_golden.py
+
+The reference is imported unmodified.  Its one missing third-party import
+(`torch_robotics...utils.SE3_distance`, reference costs/fields.py:4, used only by
+EESE3DistanceField which is out of scope) is satisfied by an empty stub module so that
+`LinkDistanceField` / `LinkSelfDistanceField` can be imported.  Noise is captured by wrapping
+`torch.distributions.multivariate_normal._standard_normal`, so the committed eps tensors are
+exactly what the reference consumed, in call order.
+
+Fixtures hold data only: inputs, captured noise and the reference's outputs.
+"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+import matplotlib  # noqa: E402
+matplotlib.use("Agg")
+for _name in ("torch_robotics", "torch_robotics.torch_kinematics_tree",
+              "torch_robotics.torch_kinematics_tree.geometrics",
+              "torch_robotics.torch_kinematics_tree.geometrics.utils"):
+    sys.modules[_name] = types.ModuleType(_name)
+sys.modules["torch_robotics.torch_kinematics_tree.geometrics.utils"].SE3_distance = None
+
+import torch.distributions.multivariate_normal as _mvn  # noqa: E402
+from stoch_gpmp.planner import StochGPMP  # noqa: E402
+from stoch_gpmp.costs.cost_functions import (CostCollision, CostComposite, CostGP,  # noqa: E402
+                                             CostGoalPrior)
+from stoch_gpmp.costs.factors.mp_priors_multi import MultiMPPrior  # noqa: E402
+from stoch_gpmp.costs.factors.gp_factor import GPFactor  # noqa: E402
+from stoch_gpmp.costs.factors.unary_factor import UnaryFactor  # noqa: E402
+from stoch_gpmp.costs.fields import LinkDistanceField, LinkSelfDistanceField  # noqa: E402
+from stoch_gpmp.envs.map_generator import generate_obstacle_map  # noqa: E402
+from stoch_gpmp.envs.obst_map import ObstacleMap  # noqa: E402
+
+from oracle.fk import fk_all_links  # noqa: E402
+
+F64 = {"device": torch.device("cpu"), "dtype": torch.float64}
+F32 = {"device": torch.device("cpu"), "dtype": torch.float32}
+
+
+class NoiseTap:
+    """Records every standard-normal draw torch's MultivariateNormal makes."""
+
+    def __enter__(self):
+        self.draws = []
+        self._orig = _mvn._standard_normal
+
+        def tapped(shape, dtype, device):
+            e = self._orig(shape, dtype=dtype, device=device)
+            self.draws.append(e.clone())
+            return e
+        _mvn._standard_normal = tapped
+        return self
+
+    def __exit__(self, *a):
+        _mvn._standard_normal = self._orig
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()      # copy: the planner updates its means in place
+
+
+def planar_scene(tensor_args):
+    random.seed(0)
+    np.random.seed(0)
+    return generate_obstacle_map(map_dim=[20, 20], obst_list=[], cell_size=0.1, random_gen=True,
+                                 num_obst=15, rand_limits=[[-7.5, 7.5], [-7.5, 7.5]],
+                                 rand_rect_shape=[2, 2], tensor_args=tensor_args)[0]
+
+
+PLANAR = dict(n_dof=2, dt=0.02, start=[-9., -9., 0., 0.],
+              cost_sigma_start=1e-3, cost_sigma_gp=0.1, sigma_coll=1e-5, sigma_goal_prior=1e-3,
+              sigma_start_init=1e-3, sigma_goal_init=1e-3, sigma_gp_init=20.,
+              sigma_start_sample=1e-3, sigma_goal_sample=1e-3, sigma_gp_sample=3.,
+              step_size=0.5, temperature=1.)
+
+
+def build_planar(obst_map, T, goals, nppg, S, seed, ta, initial_particle_means=None,
+                 temperature=None, **overrides):
+    c = dict(PLANAR, **overrides)
+    start = torch.tensor(c["start"], **ta)
+    goals_t = torch.tensor(goals, **ta)
+    cost = CostComposite(c["n_dof"], T, [
+        CostGP(c["n_dof"], T, start, c["dt"],
+               dict(sigma_start=c["cost_sigma_start"], sigma_gp=c["cost_sigma_gp"]), ta),
+        CostGoalPrior(c["n_dof"], T, multi_goal_states=goals_t, num_particles_per_goal=nppg,
+                      num_samples=S, sigma_goal_prior=c["sigma_goal_prior"], tensor_args=ta),
+        CostCollision(c["n_dof"], T, field=obst_map, sigma_coll=c["sigma_coll"]),
+    ])
+    planner = StochGPMP(
+        num_particles_per_goal=nppg, num_samples=S, traj_len=T, dt=c["dt"], n_dof=c["n_dof"],
+        opt_iters=1, temperature=c["temperature"] if temperature is None else temperature,
+        start_state=start, multi_goal_states=goals_t, cost=cost,
+        step_size=c["step_size"], sigma_start_init=c["sigma_start_init"],
+        sigma_goal_init=c["sigma_goal_init"], sigma_gp_init=c["sigma_gp_init"],
+        sigma_start_sample=c["sigma_start_sample"], sigma_goal_sample=c["sigma_goal_sample"],
+        sigma_gp_sample=c["sigma_gp_sample"], seed=seed, tensor_args=ta,
+        initial_particle_means=initial_particle_means)
+    return planner, cost
+
+
+# ------------------------------------------------------------------------------ G1
+def gen_prior():
+    """Sigma_inv / means / scale_tril of MultiMPPrior for small and example-size problems."""
+    out = {}
+    for tag, n, T, dt, ss, sg, sgoal, goals, start in [
+        ("planar_T8", 2, 8, 0.02, 1e-3, 3., 1e-3, [[9., 6., 0., 0.], [9., -3., 0., 0.]],
+         [-9., -9., 0., 0.]),
+        ("planar_T64_init", 2, 64, 0.02, 1e-3, 20., 1e-3, [[9., 6., 0., 0.], [9., -3., 0., 0.]],
+         [-9., -9., 0., 0.]),
+        ("nogoal_T6", 3, 6, 0.1, 0.05, 0.7, None, None, [0.1, -0.2, 0.3, 0., 0., 0.]),
+        ("panda_T16", 7, 16, 0.05, 1e-3, 0.1, 0.07,
+         [[0.5, 0.2, 0.3, -1.5, 0.1, 2.0, 0.3] + [0.] * 7],
+         [0.012, -0.57, 0., -2.81, 0., 3.037, 0.741] + [0.] * 7),
+    ]:
+        d = 2 * n
+        start_t = torch.tensor(start, **F64)
+        goals_t = None if goals is None else torch.tensor(goals, **F64)
+        K_s = UnaryFactor(d, ss, start_t, F64).K
+        K_g = None if goals is None else UnaryFactor(d, sgoal, goals_t[0], F64).K
+        Q = GPFactor(n, sg, dt, T - 1, F64).Q_inv[0]
+        prior = MultiMPPrior(T - 1, dt, d, n, K_s, Q, start_t, K_g_inv=K_g, goal_states=goals_t,
+                             tensor_args=F64)
+        out[tag + "/params"] = np.array([n, T, dt, ss, sg, -1. if sgoal is None else sgoal])
+        out[tag + "/start"] = npy(start_t)
+        if goals is not None:
+            out[tag + "/goals"] = npy(goals_t)
+        out[tag + "/means"] = npy(prior.means)
+        M = T * d
+        if M <= 256:
+            out[tag + "/Sigma_inv"] = npy(prior.Sigma_inv)
+            out[tag + "/scale_tril"] = npy(prior.dist._unbroadcasted_scale_tril[0])
+        else:   # keep the fixture small: first/last block rows + a strided sample of rows
+            S_inv, L = prior.Sigma_inv, prior.dist._unbroadcasted_scale_tril[0]
+            out[tag + "/Sigma_inv_top"] = npy(S_inv[:2 * d, :3 * d])
+            out[tag + "/Sigma_inv_mid"] = npy(S_inv[5 * d:6 * d, 4 * d:7 * d])
+            out[tag + "/Sigma_inv_bot"] = npy(S_inv[-2 * d:, -3 * d:])
+            out[tag + "/Sigma_inv_offband_absmax"] = np.array(
+                float((S_inv - torch.tril(torch.triu(S_inv, -2 * d + 1), 2 * d - 1)).abs().max()))
+            rows = list(range(0, M, 37)) + [M - 1]
+            out[tag + "/scale_tril_rows_idx"] = np.array(rows)
+            out[tag + "/scale_tril_rows"] = npy(L[rows])
+    np.savez_compressed(os.path.join(OUT, "g1_prior.npz"), **out)
+
+
+# ------------------------------------------------------------------------------ G2
+def gen_planar_e2e():
+    """Config 1 of BASELINE.json: planar, 2 goals x 2 particles, S=16, T=64, fp64, seed 0."""
+    obst = planar_scene(F64)
+    grid = obst.map
+    assert grid.max() <= 255 and np.all(grid == np.round(grid))
+    T, goals, nppg, S, seed = 64, [[9., 6., 0., 0.], [9., -3., 0., 0.]], 2, 16, 0
+    n_iters, keep_eps = 10, 3
+    out = {"grid": grid.astype(np.uint8), "cell_size": np.array(obst.cell_size),
+           "c_offset": npy(obst.c_offset), "goals": np.array(goals),
+           "dims": np.array([T, nppg, S, seed, n_iters])}
+    with NoiseTap() as tap:
+        planner, _ = build_planar(obst, T, goals, nppg, S, seed, F64)
+        out["means_reset"] = npy(planner.particle_means)
+        out["Sigma_inv_sample_diag_blocks"] = npy(planner.Sigma_inv[:8, :12])
+        for it in range(1, n_iters + 1):
+            sp, cp, st, cs, costs, grad = planner.optimize()
+            if it <= keep_eps:
+                out[f"costs_{it}"] = npy(costs)
+                out[f"grad_{it}"] = npy(grad)
+                out[f"weights_{it}"] = npy(planner._weights.reshape(planner.num_particles, S))
+            if it in (1, 2, 3, 10):
+                out[f"means_{it}"] = npy(planner.particle_means)
+            if it == 1:
+                out["samples_1_p0_s0"] = npy(planner.state_samples[0, 0])
+                out["samples_1_p3_s15"] = npy(planner.state_samples[3, 15])
+                out["ret_state_particles_1"] = npy(sp)      # pre-update mean positions
+        draws = tap.draws
+    assert len(draws) == 2 + n_iters
+    out["eps_init"] = npy(draws[0])                  # [nppg, G, M]
+    out["eps_discard_checksum"] = np.array(float(draws[1].sum()))
+    for it in range(1, keep_eps + 1):
+        out[f"eps_{it}"] = npy(draws[1 + it])        # [S, P, M]
+    # checksums so a seed replay of the later draws can be validated without storing them
+    out["eps_checksums"] = np.array([float(dr.sum()) for dr in draws])
+    np.savez_compressed(os.path.join(OUT, "g2_planar_e2e.npz"), **out)
+
+    # a multi-goal 'const_vel' start in a small workspace with soft (not one-hot) weights
+    T2, nppg2, S2 = 16, 2, 8
+    goals2 = [[2.9, 2.6, 0., 0.], [2.9, -1.3, 0., 0.], [-1.3, 2.9, 0., 0.]]
+    soft = dict(start=[-2.9, -2.9, 0., 0.], dt=0.5, cost_sigma_start=0.5, cost_sigma_gp=8.,
+                sigma_coll=0.4, sigma_goal_prior=2., sigma_start_sample=2., sigma_goal_sample=2.,
+                sigma_gp_sample=6.)
+    out2 = {"dims": np.array([T2, nppg2, S2, 1, 3]), "goals": np.array(goals2),
+            "temperature": np.array(20.), "start": np.array(soft["start"]),
+            "sigmas": np.array([soft["dt"], soft["cost_sigma_start"], soft["cost_sigma_gp"],
+                                soft["sigma_coll"], soft["sigma_goal_prior"],
+                                soft["sigma_start_sample"], soft["sigma_goal_sample"],
+                                soft["sigma_gp_sample"]])}
+    with NoiseTap() as tap:
+        planner, _ = build_planar(obst, T2, goals2, nppg2, S2, 1, F64,
+                                  initial_particle_means='const_vel', temperature=20., **soft)
+        out2["means_reset"] = npy(planner.particle_means)
+        for it in range(1, 4):
+            _, _, _, _, costs, grad = planner.optimize()
+            out2[f"costs_{it}"] = npy(costs)
+            out2[f"grad_{it}"] = npy(grad)
+            out2[f"weights_{it}"] = npy(planner._weights.reshape(planner.num_particles, S2))
+            out2[f"means_{it}"] = npy(planner.particle_means)
+        draws = tap.draws
+    assert len(draws) == 1 + 3
+    for it in range(1, 4):
+        out2[f"eps_{it}"] = npy(draws[it])
+    np.savez_compressed(os.path.join(OUT, "g2b_planar_constvel_soft.npz"), **out2)
+
+
+# ------------------------------------------------------------------------------ G3
+def gen_cost_terms():
+    """Per-term costs on random small trajectories, incl. out-of-grid and negative coordinates."""
+    g = torch.Generator().manual_seed(123)
+    out = {}
+    for tag, ta in (("f64", F64), ("f32", F32)):
+        n, T, dt = 2, 5, 0.02
+        G, nppg, S = 2, 1, 3
+        B = G * nppg * S
+        obst = planar_scene(ta)
+        trajs = (torch.rand(B, T, 2 * n, generator=g, dtype=torch.float64) * 24. - 12.).to(**ta)
+        trajs[0, 1, :2] = torch.tensor([-10.0, 9.99], **ta)      # edges / outside
+        trajs[1, 2, :2] = torch.tensor([15.0, -15.0], **ta)
+        trajs[2, 3, :2] = torch.tensor([-0.05, 0.05], **ta)      # floor on negatives
+        trajs[3, 4, :2] = torch.tensor([0.0, 0.0], **ta)
+        start = torch.tensor([-9., -9., 0., 0.], **ta)
+        goals = torch.tensor([[9., 6., 0., 0.], [9., -3., 0., 0.]], **ta)
+        cgp = CostGP(n, T, start, dt, dict(sigma_start=1e-3, sigma_gp=0.1), ta)
+        cgl = CostGoalPrior(n, T, multi_goal_states=goals, num_particles_per_goal=nppg,
+                            num_samples=S, sigma_goal_prior=1e-3, tensor_args=ta)
+        cco = CostCollision(n, T, field=obst, sigma_coll=1e-5)
+        out[tag + "/trajs"] = npy(trajs)
+        out[tag + "/cost_gp"] = npy(cgp.eval(trajs))
+        out[tag + "/cost_goal_prior"] = npy(cgl.eval(trajs))
+        out[tag + "/cost_collision"] = npy(cco.eval(trajs))
+        out[tag + "/grid_vals"] = npy(obst.compute_cost(trajs[:, :, :2].reshape(-1, 2)))
+        out[tag + "/composite"] = npy(CostComposite(n, T, [cgp, cgl, cco]).eval(
+            trajs.reshape(G * nppg, S, T, 2 * n)))
+    np.savez_compressed(os.path.join(OUT, "g3_cost_terms.npz"), **out)
+
+
+# ------------------------------------------------------------------------------ G4
+def gen_panda_fields():
+    """Link fields on random frames, and the reference's CostComposite driven by the oracle FK."""
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    B, T, L = 3, 4, 11
+    frames = torch.zeros(B, T, L, 4, 4, dtype=torch.float64)
+    frames[..., :3, 3] = torch.rand(B, T, L, 3, generator=g, dtype=torch.float64) * 0.8 - 0.2
+    frames[..., 3, 3] = 1.
+    frames[0, 0, 3, :3, 3] = frames[0, 0, 2, :3, 3]           # coincident links
+    spheres = torch.tensor([[[0.3, 0.1, 0.4, 0.15], [0.1, -0.1, 0.2, 0.1], [0.5, 0.4, 0.1, 0.2]]],
+                           dtype=torch.float64)
+    out["frames"] = npy(frames)
+    out["spheres"] = npy(spheres)
+    for tag, ta in (("f64", F64), ("f32", F32)):
+        fr, sp = frames.to(**ta), spheres.to(**ta)
+        for name, kw in [("rbf", dict(field_type='rbf')), ("sdf", dict(field_type='sdf')),
+                         ("sdf_clamp", dict(field_type='sdf', clamp_sdf=True)),
+                         ("occ", dict(field_type='occupancy')),
+                         ("rbf_interp2", dict(field_type='rbf', num_interpolate=2)),
+                         ("sdf_interp3", dict(field_type='sdf', num_interpolate=3,
+                                              link_interpolate_range=[2, 6]))]:
+            f = LinkDistanceField(tensor_args=ta, **kw)
+            out[f"{tag}/{name}"] = npy(f.compute_cost(fr, obstacle_spheres=sp))
+            out[f"{tag}/{name}_2dsph"] = npy(f.compute_cost(fr, obstacle_spheres=sp[0]))
+        out[f"{tag}/self"] = npy(LinkSelfDistanceField(margin=0.03, tensor_args=ta).compute_cost(fr))
+        out[f"{tag}/self_m2_interp2"] = npy(LinkSelfDistanceField(
+            margin=0.2, num_interpolate=2, tensor_args=ta).compute_cost(fr))
+
+    # composite Panda cost through the REFERENCE CostComposite with the oracle FK injected
+    n, T, dt, nppg, S = 7, 8, 0.05, 2, 4
+    start_q = [0.012, -0.57, 0., -2.81, 0., 3.037, 0.741]
+    goal_q = [0.5, 0.2, 0.3, -1.5, 0.1, 2.0, 0.3]
+    rng = np.random.default_rng(0)
+    sph = np.zeros((1, 5, 4))
+    sph[0, :, :3] = rng.uniform([0.2, -0.5, 0.2], [1.0, 0.5, 1.0], size=(5, 3))
+    sph[0, :, 3] = rng.uniform(0.1, 0.2, size=5)
+    out["panda/spheres"] = sph
+    out["panda/start_q"] = np.array(start_q)
+    out["panda/goal_q"] = np.array(goal_q)
+    for tag, ta in (("f64", F64), ("f32", F32)):
+        start = torch.tensor(start_q + [0.] * 7, **ta)
+        goals = torch.tensor([goal_q + [0.] * 7], **ta)
+        # smooth-ish random trajectories between start and goal
+        lam = torch.linspace(0, 1, T, dtype=torch.float64).view(1, 1, T, 1)
+        base = (1 - lam) * torch.tensor(start_q, dtype=torch.float64) + lam * torch.tensor(goal_q, dtype=torch.float64)
+        pos = base + 0.15 * torch.randn(nppg, S, T, n, generator=g, dtype=torch.float64)
+        vel = 0.3 * torch.randn(nppg, S, T, n, generator=g, dtype=torch.float64)
+        trajs = torch.cat([pos, vel], dim=-1).to(**ta)
+        sph_t = torch.from_numpy(sph).to(**ta)
+        terms = dict(
+            gp=CostGP(n, T, start, dt, dict(sigma_start=1e-4, sigma_gp=7e-4), ta),
+            goal_prior=CostGoalPrior(n, T, multi_goal_states=goals, num_particles_per_goal=nppg,
+                                     num_samples=S, sigma_goal_prior=20., tensor_args=ta),
+            self=CostCollision(n, T, field=LinkSelfDistanceField(margin=0.03, tensor_args=ta),
+                               sigma_coll=0.01),
+            coll_rbf=CostCollision(n, T, field=LinkDistanceField(tensor_args=ta), sigma_coll=0.01),
+            coll_sdf=CostCollision(n, T, field=LinkDistanceField(field_type='sdf', tensor_args=ta),
+                                   sigma_coll=0.01),
+            coll_occ=CostCollision(n, T, field=LinkDistanceField(field_type='occupancy',
+                                                                 tensor_args=ta), sigma_coll=0.01),
+        )
+        out[f"panda/{tag}/trajs"] = npy(trajs)
+        q = trajs.reshape(-1, 2 * n)[:, :n]
+        out[f"panda/{tag}/fk_oracle"] = npy(fk_all_links(q))
+        for name, term in terms.items():
+            cc = CostComposite(n, T, [term], FK=fk_all_links, tensor_args=ta)
+            out[f"panda/{tag}/{name}"] = npy(cc.eval(trajs, obstacle_spheres=sph_t))
+        cc = CostComposite(n, T, [terms["gp"], terms["goal_prior"], terms["self"],
+                                  terms["coll_rbf"]], FK=fk_all_links, tensor_args=ta)
+        out[f"panda/{tag}/composite"] = npy(cc.eval(trajs, obstacle_spheres=sph_t))
+    np.savez_compressed(os.path.join(OUT, "g4_panda_fields.npz"), **out)
+
+
+# ------------------------------------------------------------------------------ G5
+def gen_update_and_is():
+    """_update_distribution and the importance-sampling term on hand-made inputs."""
+    obst = planar_scene(F64)
+    T, goals, nppg, S = 8, [[9., 6., 0., 0.], [9., -3., 0., 0.]], 2, 5
+    g = torch.Generator().manual_seed(99)
+    out = {"dims": np.array([T, nppg, S])}
+    planner, cost = build_planar(obst, T, goals, nppg, S, 5, F64, temperature=3.0)
+    P, d = planner.num_particles, 4
+    samples = planner.particle_means.unsqueeze(1) + 0.3 * torch.randn(P, S, T, d, generator=g,
+                                                                      dtype=torch.float64)
+    planner.state_samples = samples
+    out["means_in"] = npy(planner.particle_means)
+    out["samples"] = npy(samples)
+    out["costs_with_is"] = npy(planner._get_costs())
+    out["costs_no_is"] = npy(cost.eval(samples).reshape(P, S))
+    for tag, costs in (("spread", torch.tensor([[1., 5., 2., 9., 4.]] * P, dtype=torch.float64)
+                        + torch.arange(P, dtype=torch.float64).view(P, 1)),
+                       ("neartie", torch.tensor([[7.0, 7.0 + 1e-9, 7.5, 30., 7.0]] * P,
+                                                dtype=torch.float64)),
+                       ("huge", torch.tensor([[1e11, 3e9, 3e9 + 2., 8e10, 5e9]] * P,
+                                             dtype=torch.float64))):
+        planner.particle_means = torch.from_numpy(out["means_in"]).clone()
+        planner._sample_dist.set_mean(planner.particle_means.view(P, -1))
+        grad = planner._update_distribution(costs.clone(), samples)
+        out[f"{tag}/costs"] = npy(costs)
+        out[f"{tag}/weights"] = npy(planner._weights.reshape(P, S))
+        out[f"{tag}/grad"] = npy(grad)
+        out[f"{tag}/means_out"] = npy(planner.particle_means)
+    np.savez_compressed(os.path.join(OUT, "g5_update_is.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    gen_prior()
+    gen_planar_e2e()
+    gen_cost_terms()
+    gen_panda_fields()
+    gen_update_and_is()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
