@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the StochGPMP inner loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A step is ONE planner iteration = one body of the loop at reference planner.py:289-299 (draw S
+samples per particle, evaluate the composite cost, softmax-reweight, update the particle means) on
+synthetic data.  Workload at N = 1: BASELINE.json configs[2] -- Panda 7-DoF (14-D state), 1024
+particles x 128 samples x 64 waypoints, 5 synthetic sphere obstacles (rbf field) + self-collision,
+fp32 compute with the prior factored in fp64.  At N > 1 every rank holds 1024 particles of a
+(1024 N)-particle problem (configs[3] at N = 8: weak scaling, particles sharded, no data-path
+collective; a 4-double statistics all-reduce over RCCL per iteration).
+
+Prints one JSON line (rank 0).  `roofline` prices the dominant kernel (the cost sweep) against the
+HBM peak using its algorithmic bytes N*w + P*S*8 and its average duration measured
+with HIP events on the launch stream; `cpu_baseline` times the reference-equivalent PyTorch-CPU
+oracle on a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="panda", choices=["panda", "planar"])
+    ap.add_argument("--particles", type=int, default=None, help="particles per GPU")
+    ap.add_argument("--samples", type=int, default=None)
+    ap.add_argument("--traj-len", type=int, default=None)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--field", default="rbf", choices=["rbf", "sdf", "occupancy"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-particles", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    return ap.parse_args()
+
+
+def build_planner(args, torch, rank, world, dev):
+    from stoch_gpmp_amd import workloads as W
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    ta = {"device": dev, "dtype": dtype}
+    if args.workload == "panda":
+        P_local = args.particles or 1024
+        S, T = args.samples or 128, args.traj_len or 64
+        pl = W.hip_panda_planner(W.PANDA, T, P_local * world, S, ta, field_type=args.field, seed=0,
+                                 rank=rank, world_size=world)
+        obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres()).to(**ta)}
+        name = (f"Panda 7-DoF, {P_local * world} particles ({P_local}/GPU) x {S} samples x {T} waypoints, "
+                f"GP + goal-prior + self-collision + 5 sphere obstacles ({args.field}), synthetic")
+    else:
+        from stoch_gpmp_amd.envs.obst_map import synthetic_obstacle_map
+        P_local = args.particles or 256
+        S, T = args.samples or 64, args.traj_len or 128
+        goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
+        om = synthetic_obstacle_map(seed=0, tensor_args=ta)
+        assert (P_local * world) % len(goals) == 0
+        pl = W.hip_planar_planner(W.PLANAR, T, goals, P_local * world // len(goals), S, om, ta, seed=0,
+                                  rank=rank, world_size=world)
+        obs = {}
+        name = (f"2-D point mass, {P_local * world} particles ({P_local}/GPU) x {S} samples x {T} waypoints, "
+                "GP + goal-prior + 200x200 occupancy grid, synthetic")
+    return pl, obs, name, P_local, S, T, dtype
+
+
+def cpu_baseline(args, torch):
+    """Reference-equivalent PyTorch-CPU path (oracle/ref_equiv.py: replicated [P,M,M] precision,
+    MultivariateNormal rebuilt per iteration, dense sampling, dense IS matmul) on a bounded sample:
+    `cpu_particles` particles of the workload at its full S and T."""
+    from tests import scenarios as SC
+    from stoch_gpmp_amd import workloads as W
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    Pc = args.cpu_particles
+    if args.workload == "panda":
+        S, T = args.samples or 128, args.traj_len or 64
+        P_full = args.particles or 1024
+        # the reference's fp32 MultivariateNormal validation rejects these stiff priors
+        # (reference README.md:35), so the CPU path is timed in fp64 as the reference must be run
+        ora = SC.oracle_panda_planner(W.PANDA, T, Pc, S, dtype=torch.float64, field_type=args.field, seed=0)
+        obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres())}
+    else:
+        from stoch_gpmp_amd.envs.obst_map import synthetic_obstacle_map
+        S, T = args.samples or 64, args.traj_len or 128
+        P_full = args.particles or 256
+        om = synthetic_obstacle_map(seed=0, tensor_args={"device": torch.device("cpu"), "dtype": torch.float64})
+        goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
+        Pc = max(Pc // 4, 1) * 4
+        ora = SC.oracle_planar_planner(W.PLANAR, T, goals, Pc // 4, S, om.map, om.cell_size,
+                                       [om.origin_xi, om.origin_yi], seed=0)
+        obs = {}
+    ora.step(**obs)                                     # warm-up
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_iters):
+        ora.step(**obs)
+    dt = (time.perf_counter() - t0) / args.cpu_iters
+    its = 1.0 / dt
+    return {
+        "value": its * Pc / P_full, "unit": "iterations/s", "cores": cores, "kind": "port",
+        "sample": (f"{Pc} of {P_full} particles at full S={S}, T={T}, fp64 (the reference's fp32 prior "
+                   f"construction fails its own validation), {args.cpu_iters} iterations after 1 warm-up; "
+                   f"measured {its:.3f} it/s at P={Pc}; value = per-particle linear extrapolation to "
+                   f"P={P_full} (the dense reference algorithm needs ~0.4 GB per particle)"),
+        "measured_it_per_s_at_sample": its, "sample_particles": Pc,
+        "torch_threads": torch.get_num_threads(),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run "
+                             f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pl, obs, name, P_local, S, T, dtype = build_planner(args, torch, rank, world, dev)
+    w = 4 if dtype == torch.float32 else 8
+    d = pl.d_state_opt
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pl.optimize(opt_iters=1, **obs)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pl.optimize(opt_iters=1, **obs)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    mean_cost, mean_min_cost = pl.global_stats()
+
+    # per-kernel device time with HIP events on the launch stream (separate pass: the events sit
+    # between the kernels, so this pass is not the one that is timed above)
+    prof_steps = min(args.steps, 50)
+    pl._engine.profile_enable(True)
+    for _ in range(prof_steps):
+        pl.optimize(opt_iters=1, **obs)
+    torch.cuda.synchronize()
+    kms, launches = pl._engine.profile_read()
+    pl._engine.profile_enable(False)
+    assert launches == prof_steps
+
+    if rank == 0:
+        N_elems = P_local * S * T * d
+        sweep_bytes = N_elems * w + P_local * S * 8
+        sweep_ms = kms["cost_sweep"] / launches
+        achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+        iter_bytes = 3 * N_elems * w + 2 * P_local * T * d * w + 2 * P_local * S * 8
+        out = {
+            "metric": "planner iterations/sec (and ms/iter) at fixed particles x samples x T",
+            "value": args.steps / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
+            "config": {"workload": name, "particles_per_gpu": P_local, "particles_total": P_local * world,
+                       "samples": S, "traj_len": T, "state_dim": d,
+                       "parallelism": f"particle-sharded x{world}" if world > 1 else "single GPU",
+                       "noise": "philox (in-kernel)", "prior_factor_dtype": "f64"},
+            "roofline": {"bound": "hbm", "kernel": "cost_sweep_kernel (K3)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": sweep_bytes,
+                         "avg_launch_ms": sweep_ms},
+            "kernel_ms_per_step": {k: v / launches for k, v in kms.items()},
+            "iteration_roofline": {"algorithmic_bytes": iter_bytes,
+                                   "achieved_GBs": iter_bytes / (elapsed / args.steps) / 1e9,
+                                   "frac_of_hbm_peak": iter_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+            "last_iteration": {"mean_cost_sum": mean_cost, "mean_min_cost": mean_min_cost},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, torch)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,199 @@
+/*
+ * sgpmp.h -- C ABI of libsgpmp.so: the MI355X (gfx950) StochGPMP inner loop.
+ *
+ * The reference (anindex/stoch_gpmp) is pure Python and has no FFI of its own; its boundary for this
+ * path is the Python API of `stoch_gpmp.planner.StochGPMP` and `stoch_gpmp.costs.*`.  Every entry
+ * point below therefore cites the reference Python function whose work it performs; the Python
+ * classes in `stoch_gpmp_amd/` keep the reference's names/signatures and forward here via ctypes
+ * (the binding a reference maintainer would add is shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - All tensor memory is owned by the caller (torch tensors used as containers); the library
+ *     borrows raw DEVICE pointers for the duration of the stream operation it enqueues.  The
+ *     library owns only small factor / descriptor / scratch buffers inside the context.
+ *   - `dtype`: SGPMP_F32 or SGPMP_F64 is the element type of every `void*` tensor argument of a
+ *     context.  Prior factors are always computed in fp64.
+ *   - Layouts are dense row-major: means [P,T,d], samples [P,S,T,d], costs/weights [P,S],
+ *     d = 2*n_dof = (positions, velocities)  (reference planner.py:52, 215, 227).
+ *   - Every call returns 0 on success or a negative SGPMP_E* code; `sgpmp_last_error()` returns a
+ *     thread-local message.  All launches are asynchronous on the caller's `stream`
+ *     (a hipStream_t passed as void*; NULL = default stream) except where noted.
+ *   - A context is bound to the device current at creation and is not thread-safe.
+ */
+#ifndef SGPMP_H
+#define SGPMP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGPMP_ABI_VERSION 1
+
+enum { SGPMP_F32 = 0, SGPMP_F64 = 1 };
+enum { SGPMP_PRIOR_INIT = 0, SGPMP_PRIOR_SAMPLE = 1 };
+
+enum {
+    SGPMP_OK = 0,
+    SGPMP_EINVAL = -1,     /* bad argument / unsupported size  (Python: AssertionError/ValueError) */
+    SGPMP_ENOTPD = -2,     /* prior precision not positive definite (Python: ValueError, as torch's
+                              MultivariateNormal raises in the reference, README.md:35)            */
+    SGPMP_EHIP = -3,       /* HIP runtime error                                                     */
+    SGPMP_ESTATE = -4      /* call order violated (e.g. step before set_prior)                      */
+};
+
+/* Cost-term kinds: one per reference Cost class on the StochGPMP path. */
+enum {
+    SGPMP_COST_GP = 1,          /* CostGP.eval / CostGPTrajectory.eval   cost_functions.py:128-146,202-215 */
+    SGPMP_COST_GOAL_PRIOR = 2,  /* CostGoalPrior.eval                    cost_functions.py:376-388         */
+    SGPMP_COST_GRID = 3,        /* CostCollision + ObstacleMap           cost_functions.py:247-261, obst_map.py:164-185 */
+    SGPMP_COST_SPHERES = 4,     /* CostCollision + LinkDistanceField     fields.py:63-86                   */
+    SGPMP_COST_SELF = 5         /* CostCollision + LinkSelfDistanceField fields.py:114-124                 */
+};
+enum { SGPMP_FIELD_RBF = 0, SGPMP_FIELD_SDF = 1, SGPMP_FIELD_OCCUPANCY = 2 };
+#define SGPMP_FLAG_GP_START 1      /* GP term includes the start-state unary factor (CostGP)  */
+#define SGPMP_FLAG_SDF_CLAMP 16    /* LinkDistanceField(clamp_sdf=True)                       */
+
+#define SGPMP_MAX_TERMS 8
+#define SGPMP_MAX_JOINTS 16
+#define SGPMP_MAX_DOF 8            /* state blocks are handled as one 16x16 MFMA tile        */
+#define SGPMP_MAX_INTERP 8
+
+typedef struct sgpmp_dims {
+    int32_t n_dof;                 /* n;  d = 2n                                                  */
+    int32_t traj_len;              /* T                                                           */
+    int32_t num_particles;         /* particles held by THIS context (local shard)                */
+    int32_t particle_offset;       /* global index of local particle 0 (multi-GPU sharding)       */
+    int32_t num_particles_global;  /* G * nppg                                                    */
+    int32_t num_samples;           /* S                                                           */
+    int32_t num_goals;             /* G (1 when not goal-directed)                                */
+    int32_t num_particles_per_goal;/* nppg; goal of global particle p is p / nppg                 */
+    int32_t dtype;                 /* SGPMP_F32 | SGPMP_F64                                       */
+    int32_t reserved;
+} sgpmp_dims;
+
+typedef struct sgpmp_cost_desc {
+    int32_t kind;                  /* SGPMP_COST_*                                                */
+    int32_t flags;                 /* GP: SGPMP_FLAG_GP_START; SPHERES: SGPMP_FIELD_* | SGPMP_FLAG_SDF_CLAMP */
+    double sigma;                  /* GP: sigma_gp; GOAL_PRIOR: sigma_goal_prior; collision: sigma_coll */
+    double sigma2;                 /* GP: sigma_start; SELF: margin                               */
+    double dt;                     /* GP: time step                                               */
+    const void* data;              /* GP: HOST double[d] start state; GOAL_PRIOR: HOST double[G*d]
+                                      goal states; GRID: DEVICE grid [dim0,dim1] in ctx dtype      */
+    int32_t dim0, dim1;            /* GOAL_PRIOR: G, nppg*S of the cost (cost_functions.py:379);
+                                      GRID: map.shape[0], map.shape[1]                            */
+    double p0, p1, p2;             /* GRID: cell_size, c_offset[0], c_offset[1] (obst_map.py:129-140) */
+    int32_t num_interpolate;       /* fields.py:32,94                                             */
+    int32_t interp_lo, interp_hi;  /* link_interpolate_range                                      */
+    int32_t reserved;
+    double alpha[SGPMP_MAX_INTERP];/* interpolation weights torch.linspace(0,1,K+2)[1:K+1] (fields.py:69) */
+} sgpmp_cost_desc;
+
+/* One joint of a serial URDF chain: H_child = H_parent * Trans(xyz) * RPY(rpy) * Rz(q).
+ * The FK callable of the reference (cost_functions.py:39,51-52) is third-party; see DESIGN.md. */
+typedef struct sgpmp_joint {
+    double rpy[3];
+    double xyz[3];
+    int32_t revolute;              /* 1: consumes the next joint coordinate; 0: fixed             */
+    int32_t reserved;
+} sgpmp_joint;
+
+typedef struct sgpmp_ctx sgpmp_ctx;
+
+int sgpmp_abi_version(void);
+const char* sgpmp_last_error(void);
+
+/* ---- context ---------------------------------------------------------------------------------- */
+/* StochGPMP.__init__ / reset bookkeeping (planner.py:20-82,181-227). Synchronous. */
+int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out);
+void sgpmp_destroy(sgpmp_ctx* ctx);
+
+/* K1. GP-prior precision blocks + reverse block-Cholesky, fp64, one launch.
+ * Replaces GPFactor.calc_phi/calc_Q_inv (gp_factor.py:36-52), UnaryFactor.K (unary_factor.py:19),
+ * MultiMPPrior.get_const_vel_covariance (mp_priors_multi.py:170-202) and the precision->scale_tril
+ * conversion torch performs on every MultiMPPrior.update_dist (mp_priors_multi.py:100-110).
+ * sigma_goal < 0: not goal-directed.  qc_inv: HOST double[n*n] or NULL (= I/sigma_gp^2).
+ * Synchronous (reads back the positive-definiteness flag): returns SGPMP_ENOTPD on failure. */
+int sgpmp_set_prior(sgpmp_ctx* ctx, int which, double dt, double sigma_start, double sigma_gp,
+                    double sigma_goal, const double* qc_inv, void* stream);
+
+/* Test/inspection hook: copy K1's outputs to HOST buffers (any may be NULL). Synchronous.
+ *   blocks  double[4*d*d]  D_0, D_interior, D_last, E = Sigma_inv[(i+1)-block, i-block]
+ *   G, H    double[T*d*d]  scan coefficients:  y_t = G_t eps_t + H_t y_{t-1}  (= scale_tril @ eps) */
+int sgpmp_get_prior(sgpmp_ctx* ctx, int which, double* blocks, double* G, double* H);
+
+/* CostComposite(cost_list, FK) compiled to a device cost program (cost_functions.py:34-58). */
+int sgpmp_set_costs(sgpmp_ctx* ctx, const sgpmp_cost_desc* descs, int n_desc);
+int sgpmp_set_fk(sgpmp_ctx* ctx, const sgpmp_joint* chain, int n_joints);
+
+/* ---- kernels ---------------------------------------------------------------------------------- */
+/* K2. MultiMPPrior.sample (mp_priors_multi.py:204-207): out[m,s,:] = means[m,:] + scale_tril @ eps.
+ * `n_modes` mean trajectories [n_modes,T,d], `n_samples` draws each -> out [n_modes,n_samples,T,d].
+ * eps == NULL: counter-based Philox noise keyed by (seed, draw, mode_offset+m, s, element).
+ * eps != NULL (parity mode): eps is laid out like torch's randn(n_samples, eps_modes, T*d)
+ * (multivariate_normal.py:250-253) and mode m reads column eps_mode_offset + m. */
+int sgpmp_sample(sgpmp_ctx* ctx, int which, uint64_t seed, uint64_t draw, const void* means,
+                 int n_modes, int mode_offset, int n_samples, const void* eps, int eps_modes,
+                 int eps_mode_offset, void* out, void* stream);
+
+/* K3. CostComposite.eval (cost_functions.py:47-58): trajs [B,T,d] -> costs [B].
+ * Row b of the batch is global row batch_offset + b (for CostGoalPrior's goal lookup).
+ * spheres: DEVICE [n_spheres,4] (cx,cy,cz,r) in ctx dtype = observation['obstacle_spheres'].
+ * is_weights: NULL, or DEVICE [B/rows_per_particle, T+1, d] importance-sampling weights (K5) whose
+ * inner product with (x_0, e_0..e_{T-2}, x_{T-1}) is added (planner.py:233-236).
+ * costs (ctx dtype) and costs64 (double) may each be NULL. */
+int sgpmp_cost_eval(sgpmp_ctx* ctx, const void* trajs, int64_t batch, int64_t batch_offset,
+                    const void* spheres, int n_spheres, const void* is_weights,
+                    int rows_per_particle, void* costs, double* costs64, void* stream);
+
+/* K5. Importance-sampling weights  a = temperature * blkdiag(K_s, Q^-1.., K_g) A mu  per particle
+ * (the factored form of Sigma_inv @ mu, planner.py:226,235-236). out: DEVICE [P,T+1,d] ctx dtype. */
+int sgpmp_is_weights(sgpmp_ctx* ctx, const void* means, int n_particles, double temperature,
+                     void* out, void* stream);
+
+/* K4. StochGPMP._update_distribution (planner.py:263-275): softmax(-costs/temperature) over S,
+ * grad = sum_s w (x - mu), means += step_size * grad.  costs_dtype: SGPMP_F64 or the ctx dtype.
+ * weights [P,S] and grad [P,T,d] in ctx dtype (may be NULL). means_prev [P,T,d] (may be NULL)
+ * receives the PRE-update means, which is what optimize() returns (planner.py:252-253).
+ * stats: DEVICE double[4] accumulated (sum of costs, sum over particles of min cost, particle
+ * count, reserved) or NULL. */
+int sgpmp_update(sgpmp_ctx* ctx, const void* costs, int costs_dtype, const void* samples,
+                 void* means, double temperature, double step_size, void* weights, void* grad,
+                 void* means_prev, double* stats, void* stream);
+
+/* One body of the loop at planner.py:289-299 for the context's particle shard:
+ * K5 -> K2 -> K3 -> K4 on `stream`.  samples [P,S,T,d] is written (state_samples of the iteration);
+ * costs [P,S] ctx dtype may be NULL. means updated in place. stats (DEVICE double[4] or NULL) is
+ * zeroed at the start of the step and holds this step's sums afterwards. */
+int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, int eps_modes,
+               int eps_mode_offset, void* means, void* samples, void* costs, void* weights,
+               void* grad, void* means_prev, const void* spheres, int n_spheres, double temperature,
+               double step_size, double* stats, void* stream);
+
+/* ---- standalone field / FK ops (the planner <-> cost seam) ----------------------- */
+/* FK callable: q [B,n] -> link frames [B,L,4,4], L = 1 + n_joints (cost_functions.py:51-52). */
+int sgpmp_fk(sgpmp_ctx* ctx, const void* q, int64_t batch, void* frames, void* stream);
+/* ObstacleMap.compute_cost (obst_map.py:164-185): X [B,2] -> values [B]; uses cost term `term`. */
+int sgpmp_grid_lookup(sgpmp_ctx* ctx, int term, const void* xy, int64_t batch, void* out,
+                      void* stream);
+/* LinkDistanceField / LinkSelfDistanceField.compute_cost on explicit frames [B,L,4,4] -> [B]
+ * using cost term `term` (its field type, margin, interpolation). */
+int sgpmp_field_eval(sgpmp_ctx* ctx, int term, const void* frames, int64_t batch, int n_links,
+                     const void* spheres, int n_spheres, void* out, void* stream);
+
+/* Kernel timing helper for bench.py: elapsed ms between two events recorded on `stream`
+ * (HIP events on the stream the kernels run on). */
+int sgpmp_event_create(void** ev);
+int sgpmp_event_record(void* ev, void* stream);
+int sgpmp_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on stop */
+int sgpmp_event_destroy(void* ev);
+/* Per-kernel accumulated device time (ms) measured with events inside sgpmp_step when enabled:
+ * out double[4] = K5, K2, K3, K4; `launches` = steps accumulated.  Enabling inserts events only. */
+int sgpmp_profile_enable(sgpmp_ctx* ctx, int on);
+int sgpmp_profile_read(sgpmp_ctx* ctx, double* ms4, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGPMP_H */

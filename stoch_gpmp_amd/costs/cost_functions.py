@@ -1,0 +1,213 @@
+"""Cost classes with the names, constructor signatures and `eval` semantics of reference
+`stoch_gpmp/costs/cost_functions.py`, compiled to the device cost program that the HIP cost sweep
+(csrc/cost_sweep.hip, K3) executes in ONE pass over the trajectory batch.
+
+A cost object here is a descriptor: `CostComposite` turns its `cost_list` into
+`sgpmp_cost_desc[]` (include/sgpmp.h).  `eval(trajs, **observation)` runs K3 and returns [B] costs,
+like the reference (cost_functions.py:47-58).  `get_linear_system` belongs to the GPMP planner,
+which is out of scope, and raises.
+"""
+from abc import ABC, abstractmethod
+
+import torch
+
+from .. import _lib as L
+from ..engine import Engine
+from .factors.field_factor import FieldFactor
+from .factors.gp_factor import GPFactor
+from .factors.unary_factor import UnaryFactor
+
+
+def _host_list(t):
+    return [float(v) for v in torch.as_tensor(t).detach().cpu().double().flatten()]
+
+
+class Cost(ABC):
+    def __init__(self, n_dof, traj_len):
+        self.n_dof = n_dof
+        self.dim = 2 * n_dof
+        self.traj_len = traj_len
+        self._solo = None
+
+    def set_cost_factors(self):
+        pass
+
+    def __call__(self, trajs, **observation):
+        return self.eval(trajs, **observation)
+
+    @abstractmethod
+    def descriptors(self):
+        """-> list of cost-term dicts for Engine.set_costs."""
+
+    def eval(self, trajs, x_trajs=None, **observation):
+        """Stand-alone evaluation of this single cost: [B,T,d] -> [B] (runs K3 with one term).
+        `x_trajs` is ignored: link frames are recomputed inside the sweep from the FK chain."""
+        if self._solo is None:
+            self._solo = CostComposite(self.n_dof, self.traj_len, [self], FK=getattr(self, "_fk", None),
+                                       tensor_args=getattr(self, "tensor_args", None))
+        return self._solo.eval(trajs, **observation)
+
+    def get_linear_system(self, trajs, **observation):
+        raise NotImplementedError("get_linear_system serves the Gauss-Newton GPMP planner, which is "
+                                  "outside the StochGPMP hot path built here (SURVEY.md 8f)")
+
+
+class CostComposite(Cost):
+    """reference cost_functions.py:32-58."""
+
+    def __init__(self, n_dof, traj_len, cost_list, FK=None, tensor_args=None):
+        super().__init__(n_dof, traj_len)
+        self.cost_list = cost_list
+        self.FK = FK
+        self.tensor_args = tensor_args
+        self._engines = {}
+        self.chain = self._resolve_chain(FK)
+
+    @staticmethod
+    def _resolve_chain(FK):
+        if FK is None:
+            return None
+        owner = getattr(FK, "__self__", FK)          # bound method of a URDFChain, or the chain itself
+        chain = getattr(owner, "chain", None)
+        if chain is None:
+            raise TypeError(
+                "FK must be a stoch_gpmp_amd URDF chain (e.g. robots.panda.DifferentiableFrankaPanda("
+                ").compute_forward_kinematics_all_links): an arbitrary Python callable cannot run "
+                "inside the HIP cost sweep")
+        return chain
+
+    def descriptors(self):
+        out = []
+        for cost in self.cost_list:
+            if not hasattr(cost, "descriptors"):
+                raise TypeError(f"{type(cost).__name__} is not a stoch_gpmp_amd cost; wrap foreign costs "
+                                "at the planner level (StochGPMP accepts any object with .eval)")
+            out.extend(cost.descriptors())
+        return out
+
+    def compile_into(self, engine):
+        """Load this composite (and its FK chain) into an Engine's cost program."""
+        if self.chain is not None:
+            engine.set_fk(self.chain)
+        engine.set_costs(self.descriptors())
+
+    def needs_spheres(self):
+        return any(dsc["kind"] == L.COST_SPHERES for dsc in self.descriptors())
+
+    def _engine(self, dtype, device):
+        key = (dtype, str(device))
+        if key not in self._engines:
+            eng = Engine(self.n_dof, self.traj_len, 0, 1, tensor_args={"device": device, "dtype": dtype})
+            self.compile_into(eng)
+            self._engines[key] = eng
+        return self._engines[key]
+
+    def eval(self, trajs, **observation):
+        trajs = trajs.reshape(-1, self.traj_len, self.dim)
+        if not trajs.is_contiguous():
+            trajs = trajs.contiguous()
+        spheres = observation.get('obstacle_spheres', None)
+        if spheres is None and self.needs_spheres():
+            # the reference fails here too: LinkDistanceField returns int 0 and FieldFactor calls
+            # .reshape on it (fields.py:64-65, field_factor.py:32)
+            raise AttributeError("obstacle_spheres observation is required by LinkDistanceField costs")
+        if spheres is not None:
+            spheres = spheres.to(device=trajs.device, dtype=trajs.dtype).reshape(-1, 4).contiguous()
+        return self._engine(trajs.dtype, trajs.device).cost_eval(trajs, spheres=spheres)
+
+
+class CostGP(Cost):
+    """reference cost_functions.py:88-146: start-state unary factor + GP transition factors."""
+
+    def __init__(self, n_dof, traj_len, start_state, dt, sigma_params, tensor_args, **kwargs):
+        super().__init__(n_dof, traj_len)
+        self.start_state = start_state
+        self.dt = dt
+        self.sigma_start = sigma_params['sigma_start']
+        self.sigma_gp = sigma_params['sigma_gp']
+        self.tensor_args = tensor_args
+        self.set_cost_factors()
+
+    def set_cost_factors(self):
+        self.start_prior = UnaryFactor(self.dim, self.sigma_start, self.start_state, self.tensor_args)
+        self.gp_prior = GPFactor(self.n_dof, self.sigma_gp, self.dt, self.traj_len - 1, self.tensor_args)
+
+    def descriptors(self):
+        return [dict(kind=L.COST_GP, flags=L.FLAG_GP_START, sigma=self.sigma_gp, sigma2=self.sigma_start,
+                     dt=self.dt, host_data=_host_list(self.start_state))]
+
+
+class CostGPTrajectory(Cost):
+    """reference cost_functions.py:171-218: GP transition factors only."""
+
+    def __init__(self, n_dof, traj_len, start_state, dt, sigma_params, tensor_args, **kwargs):
+        super().__init__(n_dof, traj_len)
+        self.start_state = start_state
+        self.dt = dt
+        self.sigma_gp = sigma_params['sigma_gp']
+        self.tensor_args = tensor_args
+        self.set_cost_factors()
+
+    def set_cost_factors(self):
+        self.gp_prior = GPFactor(self.n_dof, self.sigma_gp, self.dt, self.traj_len - 1, self.tensor_args)
+
+    def descriptors(self):
+        return [dict(kind=L.COST_GP, flags=0, sigma=self.sigma_gp, dt=self.dt)]
+
+
+class CostCollision(Cost):
+    """reference cost_functions.py:221-261: K * sum_{t=1}^{T-1} field(state_t)."""
+
+    def __init__(self, n_dof, traj_len, field=None, sigma_coll=None, tensor_args=None):
+        super().__init__(n_dof, traj_len)
+        self.field = field
+        self.sigma_coll = sigma_coll
+        self.tensor_args = tensor_args
+        self.set_cost_factors()
+
+    def set_cost_factors(self):
+        self.obst_factor = FieldFactor(self.n_dof, self.sigma_coll, [1, self.traj_len])
+
+    def descriptors(self):
+        if self.field is None:
+            return []                                   # cost_functions.py:248-249: contributes 0
+        if not hasattr(self.field, "descriptor"):
+            raise TypeError(f"field {type(self.field).__name__} is not a stoch_gpmp_amd field")
+        return [self.field.descriptor(self.sigma_coll)]
+
+
+class CostGoalPrior(Cost):
+    """reference cost_functions.py:340-388: per-goal unary factor on the last waypoint;
+    row b of the batch belongs to goal b // (num_particles_per_goal * num_samples)."""
+
+    def __init__(self, n_dof, traj_len, multi_goal_states=None, num_particles_per_goal=None,
+                 num_samples=None, sigma_goal_prior=None, tensor_args=None):
+        super().__init__(n_dof, traj_len)
+        self.multi_goal_states = multi_goal_states
+        self.num_goals = multi_goal_states.shape[0]
+        self.num_particles_per_goal = num_particles_per_goal
+        self.num_particles = num_particles_per_goal * self.num_goals
+        self.num_samples = num_samples
+        self.sigma_goal_prior = sigma_goal_prior
+        self.tensor_args = tensor_args
+        self.set_cost_factors()
+
+    def set_cost_factors(self):
+        self.multi_goal_prior = [UnaryFactor(self.dim, self.sigma_goal_prior, self.multi_goal_states[i],
+                                             self.tensor_args) for i in range(self.num_goals)]
+
+    def descriptors(self):
+        return [dict(kind=L.COST_GOAL_PRIOR, sigma=self.sigma_goal_prior, dim0=self.num_goals,
+                     dim1=self.num_particles_per_goal * self.num_samples,
+                     host_data=_host_list(self.multi_goal_states))]
+
+
+class CostGoal(Cost):
+    """reference cost_functions.py:282-337 (end-effector SE(3) goal).  Depends on the un-vendored
+    torch_robotics SE3_distance; ranked "next" in SURVEY.md 8(f), not built in this round."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("CostGoal / EESE3DistanceField are not built yet (SURVEY.md 8f)")
+
+    def descriptors(self):  # pragma: no cover
+        raise NotImplementedError

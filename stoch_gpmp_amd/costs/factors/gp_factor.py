@@ -1,0 +1,41 @@
+"""GPFactor -- same interface as reference costs/factors/gp_factor.py (host-side mirror).
+
+The kernels rebuild Phi and Q^-1 from (dim, sigma | Q_c_inv, d_t) themselves (K1 in
+csrc/prior_factor.hip, the GP term of csrc/cost_sweep.hip); `phi`, `Q_c_inv`, `Q_inv` are exposed as
+small tensors for API parity only."""
+import torch
+
+
+class GPFactor:
+    def __init__(self, dim, sigma, d_t, num_factors, tensor_args=None, Q_c_inv=None):
+        self.dim = dim
+        self.sigma = sigma
+        self.d_t = d_t
+        self.tensor_args = tensor_args
+        self.state_dim = self.dim * 2
+        self.num_factors = num_factors
+        self.user_Q_c_inv = Q_c_inv
+
+    @property
+    def phi(self):                                      # gp_factor.py:36-42
+        phi = torch.eye(self.state_dim, **self.tensor_args)
+        phi[:self.dim, self.dim:] = torch.eye(self.dim, **self.tensor_args) * self.d_t
+        return phi
+
+    @property
+    def Q_c_inv(self):                                  # gp_factor.py:25-27
+        q = self.user_Q_c_inv
+        if q is None:
+            q = torch.eye(self.dim, **self.tensor_args) / self.sigma ** 2
+        return torch.zeros(self.num_factors, self.dim, self.dim, **self.tensor_args) + q
+
+    @property
+    def Q_inv(self):                                    # gp_factor.py:44-52
+        qc = self.Q_c_inv
+        m1, m2, m3 = 12. * (self.d_t ** -3.) * qc, -6. * (self.d_t ** -2.) * qc, 4. * (self.d_t ** -1.) * qc
+        return torch.cat((torch.cat((m1, m2), dim=-1), torch.cat((m2, m3), dim=-1)), dim=-2)
+
+    def get_error(self, x_traj, calc_jacobian=False):
+        if calc_jacobian:
+            raise NotImplementedError("Jacobians belong to the GPMP planner (out of scope, SURVEY.md 8f)")
+        return (x_traj[:, 1:] - x_traj[:, :-1] @ self.phi.t()).unsqueeze(-1)

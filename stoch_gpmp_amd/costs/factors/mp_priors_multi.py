@@ -1,0 +1,100 @@
+"""MultiMPPrior -- same interface as reference costs/factors/mp_priors_multi.py, backed by the HIP
+prior factor (K1) and sampler (K2).
+
+The reference materialises Sigma^-1 [M,M], replicates it per mode and lets torch's
+MultivariateNormal re-factor it on every `set_mean`; here the factor is the T pairs of d x d scan
+blocks K1 emits once, `set_mean` only swaps the mean pointer, and `sample` is the O(T d) scan.
+`Sigma_inv` is assembled densely from K1's four distinct blocks on first access, for API parity.
+"""
+import torch
+
+from .. import _lib as L
+from ..engine import Engine
+
+
+class MultiMPPrior:
+
+    def __init__(self, num_steps, dt, state_dim, dof, K_s_inv, K_gp_inv, start_state, means=None,
+                 K_g_inv=None, goal_states=None, use_numpy=False, tensor_args=None, seed=0):
+        self.state_dim, self.dof, self.num_steps = state_dim, dof, num_steps
+        self.M = state_dim * (num_steps + 1)
+        self.tensor_args = tensor_args
+        self.dt = dt
+        self.goal_directed = goal_states is not None
+        T = num_steps + 1
+        if means is None:                                            # mp_priors_multi.py:72-79
+            self.num_modes = goal_states.shape[0] if self.goal_directed else 1
+            means = self.get_const_vel_mean(start_state, goal_states, dt, num_steps, dof)
+        else:
+            self.num_modes = means.shape[0]
+        self.means = means.reshape(self.num_modes, -1).contiguous()
+        # K_s, K_g are I/sigma^2 in the reference's API (unary_factor.py:19); recover the sigmas
+        sigma_start = float(K_s_inv[0, 0]) ** -0.5
+        sigma_goal = float(K_g_inv[0, 0]) ** -0.5 if (self.goal_directed and K_g_inv is not None) else None
+        # Q^-1 = [[12 dt^-3 Qc, .], ..] (gp_factor.py:44-52)  ->  Qc^-1 = Q^-1[:n,:n] dt^3 / 12
+        qc = (K_gp_inv[:dof, :dof].detach().double().cpu() / (12. * dt ** -3.))
+        iso = torch.allclose(qc, torch.eye(dof, dtype=torch.float64) * qc[0, 0], rtol=1e-12, atol=0)
+        self._engine = Engine(dof, T, self.num_modes, 1, tensor_args=tensor_args)
+        if iso:
+            self._engine.set_prior(L.PRIOR_SAMPLE, dt, sigma_start, float(qc[0, 0]) ** -0.5, sigma_goal)
+        else:
+            self._engine.set_prior(L.PRIOR_SAMPLE, dt, sigma_start, None, sigma_goal, Q_c_inv=qc)
+        self._seed, self._draw = seed, 0
+        self._Sigma_inv = None
+
+    # ---- reference API
+    @property
+    def Sigma_inv(self):
+        if self._Sigma_inv is None:
+            blocks, _, _ = self._engine.get_prior(L.PRIOR_SAMPLE)
+            d, T = self.state_dim, self.num_steps + 1
+            S = torch.zeros(self.M, self.M, dtype=torch.float64)
+            for t in range(T):
+                S[t * d:(t + 1) * d, t * d:(t + 1) * d] = blocks[0 if t == 0 else (2 if t == T - 1 else 1)]
+                if t + 1 < T:
+                    S[(t + 1) * d:(t + 2) * d, t * d:(t + 1) * d] = blocks[3]
+                    S[t * d:(t + 1) * d, (t + 1) * d:(t + 2) * d] = blocks[3].t()
+            self._Sigma_inv = S.to(**self.tensor_args)
+        return self._Sigma_inv
+
+    @property
+    def Sigma_invs(self):
+        return self.Sigma_inv.unsqueeze(0).expand(self.num_modes, -1, -1)
+
+    def get_mean(self, reshape=True):
+        if reshape:
+            return self.means.clone().detach().reshape(self.num_modes, self.num_steps + 1, self.state_dim)
+        return self.means.clone().detach()
+
+    def set_mean(self, means_new):
+        assert means_new.shape == self.means.shape
+        self.means = means_new.clone().detach().contiguous()
+
+    def set_Sigma_invs(self, Sigma_invs_new):
+        raise NotImplementedError("per-mode covariance adaptation has no caller in the reference "
+                                  "(mp_priors_multi.py:125-128) and is not built")
+
+    def const_vel_trajectory(self, start_state, goal_state, dt, num_steps, dof):
+        traj = torch.zeros(num_steps + 1, 2 * dof, **self.tensor_args)
+        mean_vel = (goal_state[:dof] - start_state[:dof]) / (num_steps * dt)
+        for i in range(num_steps + 1):
+            traj[i, :dof] = start_state[:dof] * (num_steps - i) * 1. / num_steps + goal_state[:dof] * i * 1. / num_steps
+        traj[:, dof:] = mean_vel.unsqueeze(0)
+        return traj
+
+    def get_const_vel_mean(self, start_state, goal_states, dt, num_steps, dof):
+        if self.goal_directed:
+            return torch.stack([self.const_vel_trajectory(start_state, goal_states[i], dt, num_steps, dof)
+                                for i in range(self.num_modes)], dim=0)
+        return start_state.repeat(num_steps + 1, 1).unsqueeze(0)
+
+    def sample(self, num_samples, eps=None):
+        """-> [num_modes, num_samples, T, state_dim] (contiguous; the reference returns a
+        transposed view of [num_samples, num_modes, ...] with the same logical layout)."""
+        out = self._engine.sample(L.PRIOR_SAMPLE, self._seed, self._draw, self.means.view(
+            self.num_modes, self.num_steps + 1, self.state_dim), num_samples, eps=eps)
+        self._draw += 1
+        return out
+
+    def log_prob(self, x):
+        raise NotImplementedError("log_prob is not on the StochGPMP path")

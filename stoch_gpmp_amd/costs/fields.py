@@ -1,0 +1,112 @@
+"""Link distance fields -- same classes and signatures as reference `stoch_gpmp/costs/fields.py`,
+evaluated by the HIP kernels in csrc/cost_sweep.hip.
+
+Inside a `CostComposite` these objects are only *descriptors* (the cost sweep fuses FK and the field
+into one pass); `compute_cost(link_tensor, ...)` on explicit frames is kept for API parity and runs
+`field_eval_kernel`.
+"""
+from abc import ABC, abstractmethod
+
+import torch
+
+from .. import _lib as L
+from ..engine import Engine
+
+
+def _linspace_alpha(num_interpolate):
+    # fields.py:69 -- torch.linspace(0, 1, K + 2)[1:K + 1] evaluated in fp32 then cast
+    if num_interpolate <= 0:
+        return []
+    return [float(v) for v in torch.linspace(0, 1, num_interpolate + 2)[1:num_interpolate + 1]]
+
+
+class DistanceField(ABC):
+    def __init__(self, tensor_args=None):
+        self.tensor_args = tensor_args
+        self._engines = {}
+
+    @abstractmethod
+    def descriptor(self, sigma):
+        """-> dict understood by Engine.set_costs (one cost term with weight 1/sigma^2)."""
+
+    @abstractmethod
+    def compute_cost(self, *args, **kwargs):
+        pass
+
+    def zero_grad(self):
+        pass
+
+    def _engine(self, dtype, device):
+        key = (dtype, str(device))
+        if key not in self._engines:
+            eng = Engine(1, 2, 0, 1, tensor_args={"device": device, "dtype": dtype})
+            eng.set_costs([self.descriptor(1.0)])
+            self._engines[key] = eng
+        return self._engines[key]
+
+
+class LinkDistanceField(DistanceField):
+    """reference fields.py:30-89 (rbf / sdf / occupancy against sphere obstacles)."""
+    _TYPES = {"rbf": L.FIELD_RBF, "sdf": L.FIELD_SDF, "occupancy": L.FIELD_OCCUPANCY}
+
+    def __init__(self, field_type='rbf', clamp_sdf=False, num_interpolate=0,
+                 link_interpolate_range=[5, 7], **kwargs):
+        super().__init__(**kwargs)
+        if field_type not in self._TYPES:
+            raise ValueError(f"unknown field_type {field_type!r}")
+        self.field_type = field_type
+        self.clamp_sdf = clamp_sdf
+        self.num_interpolate = num_interpolate
+        self.link_interpolate_range = link_interpolate_range
+
+    def descriptor(self, sigma):
+        return dict(kind=L.COST_SPHERES,
+                    flags=self._TYPES[self.field_type] | (L.FLAG_SDF_CLAMP if self.clamp_sdf else 0),
+                    sigma=sigma, num_interpolate=self.num_interpolate,
+                    interp_lo=self.link_interpolate_range[0], interp_hi=self.link_interpolate_range[1],
+                    alpha=_linspace_alpha(self.num_interpolate))
+
+    def compute_cost(self, link_tensor, obstacle_spheres=None, **kwargs):
+        if obstacle_spheres is None:
+            return 0                                        # fields.py:64-65
+        shape = link_tensor.shape[:-3]
+        frames = link_tensor.contiguous()
+        sph = obstacle_spheres.to(frames.dtype).contiguous()
+        out = self._engine(frames.dtype, frames.device).field_eval(0, frames, sph)
+        return out.reshape(shape)
+
+
+class LinkSelfDistanceField(DistanceField):
+    """reference fields.py:92-127 (pairwise rbf over all link points, diagonal included)."""
+
+    def __init__(self, margin=0.03, num_interpolate=0, link_interpolate_range=[5, 7], **kwargs):
+        super().__init__(**kwargs)
+        self.num_interpolate = num_interpolate
+        self.link_interpolate_range = link_interpolate_range
+        self.margin = margin
+
+    def descriptor(self, sigma):
+        return dict(kind=L.COST_SELF, sigma=sigma, sigma2=self.margin,
+                    num_interpolate=self.num_interpolate,
+                    interp_lo=self.link_interpolate_range[0], interp_hi=self.link_interpolate_range[1],
+                    alpha=_linspace_alpha(self.num_interpolate))
+
+    def compute_cost(self, link_tensor, **kwargs):
+        shape = link_tensor.shape[:-3]
+        frames = link_tensor.contiguous()
+        return self._engine(frames.dtype, frames.device).field_eval(0, frames).reshape(shape)
+
+
+class EESE3DistanceField(DistanceField):
+    """reference fields.py:130-153.  Its arithmetic (`SE3_distance`) lives in the un-vendored
+    `torch_robotics`; SURVEY.md 8(f) ranks it "next" -- not built in this round."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError(
+            "EESE3DistanceField / CostGoal are outside the hot path built so far (SURVEY.md 8f)")
+
+    def descriptor(self, sigma):  # pragma: no cover
+        raise NotImplementedError
+
+    def compute_cost(self, *a, **k):  # pragma: no cover
+        raise NotImplementedError

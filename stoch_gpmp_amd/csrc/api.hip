@@ -1,0 +1,479 @@
+// Host side of libsgpmp.so: the C ABI declared in include/sgpmp.h.
+// Context bookkeeping, descriptor compilation and kernel sequencing only -- no arithmetic on
+// trajectory data happens on the host.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sgpmp_internal.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(SGPMP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+struct StepEvents { hipEvent_t ev[5]; };
+
+struct sgpmp_ctx {
+    sgpmp_dims dims;
+    int d, M;
+    size_t esz;
+    PriorDev prior[2];
+    double* d_qc;                 // scratch [n*n] for K1's Q_c^-1
+    CostProgram h_prog;
+    CostProgram* d_prog;
+    bool have_costs, prog_dirty;
+    ChainDev h_chain;
+    ChainDev* d_chain;
+    bool have_chain;
+    std::vector<void*> owned;     // device buffers holding term data (start / goal states)
+    void* d_isw;                  // [P, T+1, d] importance-sampling weights (K5 output)
+    double* d_costs64;            // [P, S]
+    bool profiling;
+    std::vector<StepEvents> events;
+};
+
+extern "C" int sgpmp_abi_version(void) { return SGPMP_ABI_VERSION; }
+extern "C" const char* sgpmp_last_error(void) { return g_err.c_str(); }
+
+static int alloc_prior(sgpmp_ctx* c, PriorDev& p) {
+    const int d = c->d, T = c->dims.traj_len;
+    std::memset(&p, 0, sizeof(p));
+    HIPCHK(hipMalloc(&p.blocks, sizeof(double) * 4 * d * d));
+    HIPCHK(hipMalloc(&p.G, sizeof(double) * T * d * d));
+    HIPCHK(hipMalloc(&p.H, sizeof(double) * T * d * d));
+    HIPCHK(hipMalloc(&p.iso64, sizeof(double) * T * 8));
+    HIPCHK(hipMalloc(&p.iso32, sizeof(float) * T * 8));
+    HIPCHK(hipMalloc(&p.Qinv, sizeof(double) * d * d));
+    HIPCHK(hipMalloc(&p.G32, sizeof(float) * T * d * d));
+    HIPCHK(hipMalloc(&p.H32, sizeof(float) * T * d * d));
+    HIPCHK(hipMalloc(&p.status, sizeof(int)));
+    return SGPMP_OK;
+}
+
+static void free_prior(PriorDev& p) {
+    hipFree(p.blocks); hipFree(p.G); hipFree(p.H); hipFree(p.iso64); hipFree(p.iso32);
+    hipFree(p.Qinv); hipFree(p.G32); hipFree(p.H32); hipFree(p.status);
+    std::memset(&p, 0, sizeof(p));
+}
+
+extern "C" int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out) {
+    if (!dims || !out) return fail(SGPMP_EINVAL, "sgpmp_create: null argument");
+    if (dims->n_dof < 1 || dims->n_dof > SGPMP_MAX_DOF)
+        return fail(SGPMP_EINVAL, "sgpmp_create: n_dof must be in [1, 8] (state block = one 16x16 tile)");
+    if (dims->traj_len < 2) return fail(SGPMP_EINVAL, "sgpmp_create: traj_len must be >= 2");
+    if (dims->num_particles < 0 || dims->num_samples < 1 || dims->num_goals < 1 ||
+        dims->num_particles_per_goal < 1)
+        return fail(SGPMP_EINVAL, "sgpmp_create: bad particle/sample/goal counts");
+    if (dims->dtype != SGPMP_F32 && dims->dtype != SGPMP_F64)
+        return fail(SGPMP_EINVAL, "sgpmp_create: dtype must be SGPMP_F32 or SGPMP_F64");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(SGPMP_EHIP, "sgpmp_create: no HIP device visible (this library has no CPU path)");
+    sgpmp_ctx* c = new sgpmp_ctx();
+    c->dims = *dims;
+    c->d = 2 * dims->n_dof;
+    c->M = c->d * dims->traj_len;
+    c->esz = dims->dtype == SGPMP_F64 ? 8 : 4;
+    c->d_qc = nullptr; c->d_prog = nullptr; c->d_chain = nullptr; c->d_isw = nullptr;
+    c->d_costs64 = nullptr;
+    c->have_costs = false; c->prog_dirty = false; c->have_chain = false; c->profiling = false;
+    std::memset(&c->h_prog, 0, sizeof(c->h_prog));
+    std::memset(&c->h_chain, 0, sizeof(c->h_chain));
+    int rc;
+    if ((rc = alloc_prior(c, c->prior[0])) != SGPMP_OK) return rc;
+    if ((rc = alloc_prior(c, c->prior[1])) != SGPMP_OK) return rc;
+    HIPCHK(hipMalloc(&c->d_qc, sizeof(double) * dims->n_dof * dims->n_dof));
+    HIPCHK(hipMalloc(&c->d_prog, sizeof(CostProgram)));
+    HIPCHK(hipMalloc(&c->d_chain, sizeof(ChainDev)));
+    const size_t P = (size_t)(dims->num_particles > 0 ? dims->num_particles : 1);
+    HIPCHK(hipMalloc(&c->d_isw, P * (dims->traj_len + 1) * c->d * c->esz));
+    HIPCHK(hipMalloc(&c->d_costs64, P * dims->num_samples * sizeof(double)));
+    *out = c;
+    return SGPMP_OK;
+}
+
+extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
+    if (!c) return;
+    free_prior(c->prior[0]);
+    free_prior(c->prior[1]);
+    hipFree(c->d_qc); hipFree(c->d_prog); hipFree(c->d_chain); hipFree(c->d_isw);
+    hipFree(c->d_costs64);
+    for (void* p : c->owned) hipFree(p);
+    for (auto& se : c->events)
+        for (auto& e : se.ev) hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" int sgpmp_set_prior(sgpmp_ctx* c, int which, double dt, double sigma_start, double sigma_gp,
+                               double sigma_goal, const double* qc_inv, void* stream) {
+    if (!c || (which != 0 && which != 1)) return fail(SGPMP_EINVAL, "sgpmp_set_prior: bad argument");
+    if (!(dt > 0.) || !(sigma_start > 0.) || (!qc_inv && !(sigma_gp > 0.)))
+        return fail(SGPMP_EINVAL, "sgpmp_set_prior: dt and sigmas must be positive");
+    const int n = c->dims.n_dof;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<double> qc((size_t)n * n, 0.);
+    if (qc_inv) std::memcpy(qc.data(), qc_inv, sizeof(double) * n * n);
+    else for (int i = 0; i < n; ++i) qc[(size_t)i * n + i] = 1. / (sigma_gp * sigma_gp);   // gp_factor.py:25-26
+    HIPCHK(hipMemcpyAsync(c->d_qc, qc.data(), sizeof(double) * n * n, hipMemcpyHostToDevice, st));
+    PriorDev& p = c->prior[which];
+    p.ks = 1. / (sigma_start * sigma_start);                     // unary_factor.py:19
+    p.kg = sigma_goal > 0. ? 1. / (sigma_goal * sigma_goal) : -1.;
+    p.dt = dt;
+    p.isotropic = qc_inv ? 0 : 1;
+    p.valid = 0;
+    HIPCHK(launch_prior_factor(n, c->dims.traj_len, dt, p.ks, p.kg, c->d_qc, p.isotropic, p, st));
+    int status = 0;
+    HIPCHK(hipMemcpyAsync(&status, p.status, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (status != 0)
+        return fail(SGPMP_ENOTPD, "sgpmp_set_prior: prior precision matrix is not positive definite");
+    p.valid = 1;
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_get_prior(sgpmp_ctx* c, int which, double* blocks, double* G, double* H) {
+    if (!c || (which != 0 && which != 1)) return fail(SGPMP_EINVAL, "sgpmp_get_prior: bad argument");
+    const PriorDev& p = c->prior[which];
+    if (!p.valid) return fail(SGPMP_ESTATE, "sgpmp_get_prior: prior not set");
+    const size_t dd = (size_t)c->d * c->d, T = c->dims.traj_len;
+    HIPCHK(hipDeviceSynchronize());
+    if (blocks) HIPCHK(hipMemcpy(blocks, p.blocks, sizeof(double) * 4 * dd, hipMemcpyDeviceToHost));
+    if (G) HIPCHK(hipMemcpy(G, p.G, sizeof(double) * T * dd, hipMemcpyDeviceToHost));
+    if (H) HIPCHK(hipMemcpy(H, p.H, sizeof(double) * T * dd, hipMemcpyDeviceToHost));
+    return SGPMP_OK;
+}
+
+static int upload_as_dtype(sgpmp_ctx* c, const double* host, size_t count, const void** dev_out) {
+    void* dev = nullptr;
+    HIPCHK(hipMalloc(&dev, count * c->esz));
+    if (c->dims.dtype == SGPMP_F64) {
+        HIPCHK(hipMemcpy(dev, host, count * 8, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> tmp(count);
+        for (size_t i = 0; i < count; ++i) tmp[i] = (float)host[i];
+        HIPCHK(hipMemcpy(dev, tmp.data(), count * 4, hipMemcpyHostToDevice));
+    }
+    c->owned.push_back(dev);
+    *dev_out = dev;
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_set_costs(sgpmp_ctx* c, const sgpmp_cost_desc* descs, int n_desc) {
+    if (!c || (n_desc > 0 && !descs)) return fail(SGPMP_EINVAL, "sgpmp_set_costs: null argument");
+    if (n_desc < 0 || n_desc > SGPMP_MAX_TERMS)
+        return fail(SGPMP_EINVAL, "sgpmp_set_costs: at most 8 cost terms are supported");
+    CostProgram prog;
+    std::memset(&prog, 0, sizeof(prog));
+    prog.n_terms = n_desc;
+    const int d = c->d;
+    for (int i = 0; i < n_desc; ++i) {
+        const sgpmp_cost_desc& s = descs[i];
+        CostTerm& t = prog.terms[i];
+        t.kind = s.kind;
+        t.flags = s.flags;
+        if (!(s.sigma > 0.)) return fail(SGPMP_EINVAL, "sgpmp_set_costs: sigma must be positive");
+        t.K = 1. / (s.sigma * s.sigma);                           // field_factor.py:16, unary_factor.py:19
+        int rc;
+        switch (s.kind) {
+            case SGPMP_COST_GP:
+                if (!(s.dt > 0.)) return fail(SGPMP_EINVAL, "sgpmp_set_costs: GP term needs dt > 0");
+                t.dt = s.dt;
+                t.c11 = 12. * std::pow(s.dt, -3.);                // gp_factor.py:45-47
+                t.c12 = -6. * std::pow(s.dt, -2.);
+                t.c22 = 4. * std::pow(s.dt, -1.);
+                if (s.flags & SGPMP_FLAG_GP_START) {
+                    if (!s.data || !(s.sigma2 > 0.))
+                        return fail(SGPMP_EINVAL, "sgpmp_set_costs: CostGP needs start state and sigma_start");
+                    t.K2 = 1. / (s.sigma2 * s.sigma2);
+                    if ((rc = upload_as_dtype(c, (const double*)s.data, d, &t.dev_data)) != SGPMP_OK) return rc;
+                }
+                break;
+            case SGPMP_COST_GOAL_PRIOR:
+                if (!s.data || s.dim0 < 1 || s.dim1 < 1)
+                    return fail(SGPMP_EINVAL, "sgpmp_set_costs: goal prior needs goals [G,d] and nppg*S");
+                t.dim0 = s.dim0;
+                t.rows_per_goal = s.dim1;
+                if ((rc = upload_as_dtype(c, (const double*)s.data, (size_t)s.dim0 * d, &t.dev_data)) != SGPMP_OK)
+                    return rc;
+                break;
+            case SGPMP_COST_GRID:
+                if (!s.data || s.dim0 < 1 || s.dim1 < 1 || !(s.p0 > 0.))
+                    return fail(SGPMP_EINVAL, "sgpmp_set_costs: grid term needs a device grid and cell size");
+                if (c->dims.n_dof < 2)
+                    return fail(SGPMP_EINVAL, "sgpmp_set_costs: grid term needs n_dof >= 2");
+                t.dev_data = s.data;
+                t.dim0 = s.dim0; t.dim1 = s.dim1;
+                t.inv_cell = 1. / s.p0;                           // obst_map.py:172
+                t.off_x = s.p1; t.off_y = s.p2;
+                break;
+            case SGPMP_COST_SPHERES:
+            case SGPMP_COST_SELF:
+                if (s.num_interpolate < 0 || s.num_interpolate > SGPMP_MAX_INTERP)
+                    return fail(SGPMP_EINVAL, "sgpmp_set_costs: num_interpolate must be in [0, 8]");
+                t.n_interp = s.num_interpolate;
+                t.interp_lo = s.interp_lo; t.interp_hi = s.interp_hi;
+                for (int a = 0; a < s.num_interpolate; ++a) t.alpha[a] = s.alpha[a];
+                if (s.kind == SGPMP_COST_SELF) {
+                    if (!(s.sigma2 > 0.)) return fail(SGPMP_EINVAL, "sgpmp_set_costs: self field needs margin > 0");
+                    t.K2 = 1. / (-(s.sigma2 * s.sigma2) * 2.);    // fields.py:124
+                }
+                prog.needs_fk = 1;
+                break;
+            default:
+                return fail(SGPMP_EINVAL, "sgpmp_set_costs: unknown cost kind");
+        }
+    }
+    c->h_prog = prog;
+    c->have_costs = true;
+    c->prog_dirty = true;
+    return SGPMP_OK;
+}
+
+static void rpy_to_R(const double rpy[3], double R[9]) {
+    const double cr = std::cos(rpy[0]), sr = std::sin(rpy[0]), cp = std::cos(rpy[1]), sp = std::sin(rpy[1]),
+                 cy = std::cos(rpy[2]), sy = std::sin(rpy[2]);
+    R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+    R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+    R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+
+extern "C" int sgpmp_set_fk(sgpmp_ctx* c, const sgpmp_joint* chain, int n_joints) {
+    if (!c || !chain) return fail(SGPMP_EINVAL, "sgpmp_set_fk: null argument");
+    if (n_joints < 1 || n_joints > SGPMP_MAX_JOINTS)
+        return fail(SGPMP_EINVAL, "sgpmp_set_fk: 1..16 joints supported");
+    ChainDev ch;
+    std::memset(&ch, 0, sizeof(ch));
+    ch.n_joints = n_joints;
+    ch.n_links = n_joints + 1;
+    int q = 0;
+    for (int j = 0; j < n_joints; ++j) {
+        rpy_to_R(chain[j].rpy, ch.j[j].R);
+        for (int i = 0; i < 3; ++i) ch.j[j].t[i] = chain[j].xyz[i];
+        ch.j[j].revolute = chain[j].revolute ? 1 : 0;
+        ch.j[j].qidx = chain[j].revolute ? q++ : -1;
+    }
+    if (q != c->dims.n_dof)
+        return fail(SGPMP_EINVAL, "sgpmp_set_fk: number of revolute joints must equal n_dof");
+    c->h_chain = ch;
+    HIPCHK(hipMemcpy(c->d_chain, &ch, sizeof(ch), hipMemcpyHostToDevice));
+    c->have_chain = true;
+    c->prog_dirty = true;
+    return SGPMP_OK;
+}
+
+// Resolve point counts (they depend on the chain) and push the program to the device.
+static int finalize_program(sgpmp_ctx* c) {
+    if (!c->have_costs) return fail(SGPMP_ESTATE, "cost program not set (sgpmp_set_costs)");
+    if (!c->prog_dirty) return SGPMP_OK;
+    CostProgram& p = c->h_prog;
+    if (p.needs_fk && !c->have_chain)
+        return fail(SGPMP_ESTATE, "link-distance cost terms need an FK chain (sgpmp_set_fk)");
+    for (int i = 0; i < p.n_terms; ++i) {
+        CostTerm& t = p.terms[i];
+        if (t.kind != SGPMP_COST_SPHERES && t.kind != SGPMP_COST_SELF) continue;
+        const int L = c->h_chain.n_links;
+        int extra = 0;
+        if (t.n_interp > 0) {
+            if (t.interp_lo < 0 || t.interp_hi > L - 1 || t.interp_lo > t.interp_hi)
+                return fail(SGPMP_EINVAL, "link_interpolate_range outside the link table");
+            extra = t.n_interp * (t.interp_hi - t.interp_lo);
+        }
+        t.n_points = L + extra;
+        if (t.n_points > SGPMP_MAX_POINTS) return fail(SGPMP_EINVAL, "too many link points (max 32)");
+    }
+    HIPCHK(hipMemcpy(c->d_prog, &p, sizeof(p), hipMemcpyHostToDevice));
+    c->prog_dirty = false;
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_sample(sgpmp_ctx* c, int which, uint64_t seed, uint64_t draw, const void* means,
+                            int n_modes, int mode_offset, int n_samples, const void* eps, int eps_modes,
+                            int eps_mode_offset, void* out, void* stream) {
+    if (!c || !means || !out || (which != 0 && which != 1) || n_modes < 0 || n_samples < 1)
+        return fail(SGPMP_EINVAL, "sgpmp_sample: bad argument");
+    if (!c->prior[which].valid) return fail(SGPMP_ESTATE, "sgpmp_sample: prior not set");
+    if (eps && (eps_modes < 1 || eps_mode_offset < 0 || eps_mode_offset + n_modes > eps_modes))
+        return fail(SGPMP_EINVAL, "sgpmp_sample: eps mode window out of range");
+    if (n_modes == 0) return SGPMP_OK;
+    HIPCHK(launch_sample(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, c->prior[which], seed, draw, means,
+                         n_modes, mode_offset, n_samples, eps, eps_modes, eps_mode_offset, out,
+                         (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
+static int check_spheres(sgpmp_ctx* c, const void* spheres, int n_spheres) {
+    for (int i = 0; i < c->h_prog.n_terms; ++i)
+        if (c->h_prog.terms[i].kind == SGPMP_COST_SPHERES && (!spheres || n_spheres < 1))
+            return fail(SGPMP_EINVAL, "LinkDistanceField cost needs obstacle_spheres");
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_cost_eval(sgpmp_ctx* c, const void* trajs, int64_t batch, int64_t batch_offset,
+                               const void* spheres, int n_spheres, const void* is_weights,
+                               int rows_per_particle, void* costs, double* costs64, void* stream) {
+    if (!c || !trajs || batch < 0) return fail(SGPMP_EINVAL, "sgpmp_cost_eval: bad argument");
+    int rc;
+    if ((rc = finalize_program(c)) != SGPMP_OK) return rc;
+    if ((rc = check_spheres(c, spheres, n_spheres)) != SGPMP_OK) return rc;
+    if (batch == 0) return SGPMP_OK;
+    HIPCHK(launch_cost(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, c->d_prog, c->h_prog, c->d_chain,
+                       c->h_chain.n_links, trajs, batch, batch_offset, spheres, n_spheres, is_weights,
+                       rows_per_particle, c->prior[SGPMP_PRIOR_SAMPLE].dt, costs, costs64,
+                       (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_is_weights(sgpmp_ctx* c, const void* means, int n_particles, double temperature,
+                                void* out, void* stream) {
+    if (!c || !means || !out || n_particles < 0) return fail(SGPMP_EINVAL, "sgpmp_is_weights: bad argument");
+    if (!c->prior[SGPMP_PRIOR_SAMPLE].valid) return fail(SGPMP_ESTATE, "sgpmp_is_weights: sampling prior not set");
+    HIPCHK(launch_is_weights(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, c->prior[SGPMP_PRIOR_SAMPLE], means,
+                             n_particles, temperature, out, nullptr, (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_update(sgpmp_ctx* c, const void* costs, int costs_dtype, const void* samples, void* means,
+                            double temperature, double step_size, void* weights, void* grad, void* means_prev,
+                            double* stats, void* stream) {
+    if (!c || !costs || !samples || !means) return fail(SGPMP_EINVAL, "sgpmp_update: null argument");
+    if (costs_dtype != SGPMP_F64 && costs_dtype != c->dims.dtype)
+        return fail(SGPMP_EINVAL, "sgpmp_update: costs must be fp64 or the context dtype");
+    if (!(temperature > 0.)) return fail(SGPMP_EINVAL, "sgpmp_update: temperature must be positive");
+    HIPCHK(launch_update(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, c->dims.num_particles,
+                         c->dims.num_samples, costs, costs_dtype, samples, means, temperature, step_size,
+                         weights, grad, means_prev, stats, (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void* eps, int eps_modes,
+                          int eps_mode_offset, void* means, void* samples, void* costs, void* weights,
+                          void* grad, void* means_prev, const void* spheres, int n_spheres, double temperature,
+                          double step_size, double* stats, void* stream) {
+    if (!c || !means || !samples) return fail(SGPMP_EINVAL, "sgpmp_step: null argument");
+    if (!c->prior[SGPMP_PRIOR_SAMPLE].valid) return fail(SGPMP_ESTATE, "sgpmp_step: sampling prior not set");
+    if (!(temperature > 0.)) return fail(SGPMP_EINVAL, "sgpmp_step: temperature must be positive");
+    int rc;
+    if ((rc = finalize_program(c)) != SGPMP_OK) return rc;
+    if ((rc = check_spheres(c, spheres, n_spheres)) != SGPMP_OK) return rc;
+    const sgpmp_dims& D = c->dims;
+    const int P = D.num_particles, S = D.num_samples;
+    if (P == 0) return SGPMP_OK;
+    if (eps && (eps_modes < 1 || eps_mode_offset < 0 || eps_mode_offset + P > eps_modes))
+        return fail(SGPMP_EINVAL, "sgpmp_step: eps particle window out of range");
+    hipStream_t st = (hipStream_t)stream;
+    StepEvents* se = nullptr;
+    if (c->profiling) {
+        c->events.emplace_back();
+        se = &c->events.back();
+        for (auto& e : se->ev) HIPCHK(hipEventCreate(&e));
+        HIPCHK(hipEventRecord(se->ev[0], st));
+    }
+    const PriorDev& pr = c->prior[SGPMP_PRIOR_SAMPLE];
+    HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, means, P, temperature, c->d_isw, stats, st));
+    if (se) HIPCHK(hipEventRecord(se->ev[1], st));
+    HIPCHK(launch_sample(D.dtype, D.n_dof, D.traj_len, pr, seed, draw, means, P, D.particle_offset, S, eps,
+                         eps_modes, eps_mode_offset, samples, st));
+    if (se) HIPCHK(hipEventRecord(se->ev[2], st));
+    HIPCHK(launch_cost(D.dtype, D.n_dof, D.traj_len, c->d_prog, c->h_prog, c->d_chain, c->h_chain.n_links,
+                       samples, (long long)P * S, (long long)D.particle_offset * S, spheres, n_spheres,
+                       c->d_isw, S, pr.dt, costs, c->d_costs64, st));
+    if (se) HIPCHK(hipEventRecord(se->ev[3], st));
+    HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
+                         temperature, step_size, weights, grad, means_prev, stats, st));
+    if (se) HIPCHK(hipEventRecord(se->ev[4], st));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_fk(sgpmp_ctx* c, const void* q, int64_t batch, void* frames, void* stream) {
+    if (!c || !q || !frames || batch < 0) return fail(SGPMP_EINVAL, "sgpmp_fk: bad argument");
+    if (!c->have_chain) return fail(SGPMP_ESTATE, "sgpmp_fk: FK chain not set");
+    HIPCHK(launch_fk(c->dims.dtype, c->dims.n_dof, c->d_chain, c->h_chain.n_links, q, batch, frames,
+                     (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_grid_lookup(sgpmp_ctx* c, int term, const void* xy, int64_t batch, void* out, void* stream) {
+    if (!c || !xy || !out || batch < 0) return fail(SGPMP_EINVAL, "sgpmp_grid_lookup: bad argument");
+    if (!c->have_costs || term < 0 || term >= c->h_prog.n_terms || c->h_prog.terms[term].kind != SGPMP_COST_GRID)
+        return fail(SGPMP_EINVAL, "sgpmp_grid_lookup: term is not a grid term");
+    HIPCHK(launch_grid_lookup(c->dims.dtype, c->h_prog.terms[term], xy, batch, out, (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_field_eval(sgpmp_ctx* c, int term, const void* frames, int64_t batch, int n_links,
+                                const void* spheres, int n_spheres, void* out, void* stream) {
+    if (!c || !frames || !out || batch < 0 || n_links < 1)
+        return fail(SGPMP_EINVAL, "sgpmp_field_eval: bad argument");
+    if (!c->have_costs || term < 0 || term >= c->h_prog.n_terms)
+        return fail(SGPMP_EINVAL, "sgpmp_field_eval: bad term index");
+    CostTerm t = c->h_prog.terms[term];
+    if (t.kind != SGPMP_COST_SPHERES && t.kind != SGPMP_COST_SELF)
+        return fail(SGPMP_EINVAL, "sgpmp_field_eval: term is not a link field");
+    if (t.kind == SGPMP_COST_SPHERES && (!spheres || n_spheres < 1))
+        return fail(SGPMP_EINVAL, "LinkDistanceField cost needs obstacle_spheres");
+    int extra = 0;
+    if (t.n_interp > 0) {
+        if (t.interp_lo < 0 || t.interp_hi > n_links - 1 || t.interp_lo > t.interp_hi)
+            return fail(SGPMP_EINVAL, "link_interpolate_range outside the link table");
+        extra = t.n_interp * (t.interp_hi - t.interp_lo);
+    }
+    t.n_points = n_links + extra;
+    if (t.n_points > SGPMP_MAX_POINTS) return fail(SGPMP_EINVAL, "too many link points (max 32)");
+    HIPCHK(launch_field_eval(c->dims.dtype, t, frames, batch, n_links, spheres, n_spheres, out,
+                             (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
+// ---------------------------------------------------------------------------------- timing helpers
+extern "C" int sgpmp_event_create(void** ev) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    *ev = (void*)e;
+    return SGPMP_OK;
+}
+extern "C" int sgpmp_event_record(void* ev, void* stream) {
+    HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return SGPMP_OK;
+}
+extern "C" int sgpmp_event_elapsed_ms(void* start, void* stop, float* ms) {
+    HIPCHK(hipEventSynchronize((hipEvent_t)stop));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return SGPMP_OK;
+}
+extern "C" int sgpmp_event_destroy(void* ev) {
+    HIPCHK(hipEventDestroy((hipEvent_t)ev));
+    return SGPMP_OK;
+}
+extern "C" int sgpmp_profile_enable(sgpmp_ctx* c, int on) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_profile_enable: null ctx");
+    c->profiling = on != 0;
+    return SGPMP_OK;
+}
+extern "C" int sgpmp_profile_read(sgpmp_ctx* c, double* ms4, int64_t* launches) {
+    if (!c || !ms4) return fail(SGPMP_EINVAL, "sgpmp_profile_read: null argument");
+    for (int k = 0; k < 4; ++k) ms4[k] = 0.;
+    for (auto& se : c->events) {
+        HIPCHK(hipEventSynchronize(se.ev[4]));
+        for (int k = 0; k < 4; ++k) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, se.ev[k], se.ev[k + 1]));
+            ms4[k] += ms;
+        }
+    }
+    if (launches) *launches = (int64_t)c->events.size();
+    for (auto& se : c->events)
+        for (auto& e : se.ev) hipEventDestroy(e);
+    c->events.clear();
+    return SGPMP_OK;
+}

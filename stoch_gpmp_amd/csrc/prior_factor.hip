@@ -1,0 +1,198 @@
+// K1 -- GP-prior precision blocks and their reverse block-Cholesky, fp64, one wave, one launch.
+//
+// Replaces (reference file:line, relative to the reference tree, stoch_gpmp/):
+//   costs/factors/gp_factor.py:36-52      Phi, Q^-1
+//   costs/factors/unary_factor.py:19      K = I / sigma^2
+//   costs/factors/mp_priors_multi.py:170-202   Sigma^-1 = A^T blkdiag(K_s, Q^-1.., K_g) A
+//   costs/factors/mp_priors_multi.py:100-110 -> torch multivariate_normal.py:80-86
+//                                          scale_tril = (flip-Cholesky of Sigma^-1)^-1
+//
+// Sigma^-1 is block-tridiagonal with d x d blocks
+//   D_0 = K_s + Phi^T Q^-1 Phi,  D_i = Q^-1 + Phi^T Q^-1 Phi,  D_{T-1} = Q^-1 + K_g,
+//   E = Sigma^-1[i+1, i] = -Q^-1 Phi,
+// and torch's L_inv (lower, Sigma^-1 = L_inv^T L_inv) is block-BIdiagonal with diagonal blocks B_t
+// (lower triangular) and sub-diagonal blocks C_t.  Matching blocks gives the reverse recursion
+//   B_{T-1}^T B_{T-1} = D_{T-1};   C_t = B_t^-T E;   B_{t-1}^T B_{t-1} = D_{t-1} - C_t^T C_t.
+// A sample  x = mu + scale_tril @ eps  solves  L_inv (x - mu) = eps, i.e. the scan
+//   y_t = G_t eps_t + H_t y_{t-1},   G_t = B_t^-1,  H_t = -B_t^-1 C_t,
+// so K1 emits G_t, H_t (T blocks each) instead of the dense M x M scale_tril.
+//
+// The d x d products run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64) with the state block
+// padded to one 16x16 tile; the triangular factorisations are d sequential steps across lanes.
+#include "sgpmp_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define TS SGPMP_TILE
+
+// C = alpha * op(A) * op(B) + beta * Cin, all 16x16 row-major tiles in LDS, executed by one wave.
+// v_mfma_f64_16x16x4_f64 operand maps: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// D[row = (l>>4) + 4*r][col = l&15], r = 0..3.
+__device__ __forceinline__ void mm16(double* C, const double* A, const double* B, bool tA, bool tB,
+                                     double alpha, const double* Cin, double beta) {
+    const int l = threadIdx.x;
+    const int i = l & 15, kq = l >> 4;
+    d4 acc = {0., 0., 0., 0.};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int k = 4 * kb + kq;
+        const double a = tA ? A[k * TS + i] : A[i * TS + k];
+        const double b = tB ? B[i * TS + k] : B[k * TS + i];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    double cin[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cin[r] = Cin ? Cin[(kq + 4 * r) * TS + i] : 0.;
+    __syncthreads();                       // C may alias an operand
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[(kq + 4 * r) * TS + i] = alpha * acc[r] + beta * cin[r];
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(64)
+prior_factor_kernel(int n, int T, double c11, double c12, double c22, double dt, double ks, double kg,
+                    const double* __restrict__ qc_inv, int isotropic, PriorDev out) {
+    __shared__ double Phi[TS * TS], Qi[TS * TS], W[TS * TS], PQP[TS * TS];
+    __shared__ double Dm[TS * TS], S[TS * TS], B[TS * TS], C[TS * TS], G[TS * TS], Hh[TS * TS];
+    __shared__ double tmp[TS];
+    __shared__ int bad;
+    const int l = threadIdx.x;
+    const int d = 2 * n;
+    if (l == 0) bad = 0;
+
+    // ---- assemble Phi and Q^-1 (gp_factor.py:36-52), zero padded to 16x16
+    for (int e = l; e < TS * TS; e += 64) {
+        const int r = e / TS, c = e % TS;
+        double phi = 0., q = 0.;
+        if (r < d && c < d) {
+            phi = (r == c) ? 1. : 0.;
+            if (r < n && c == r + n) phi = dt;
+            const double qc = qc_inv[(r % n) * n + (c % n)];
+            const double coef = (r < n) ? ((c < n) ? c11 : c12) : ((c < n) ? c12 : c22);
+            q = coef * qc;
+        }
+        Phi[e] = phi;
+        Qi[e] = q;
+        B[e] = 0.; C[e] = 0.; G[e] = 0.; Hh[e] = 0.;
+    }
+    __syncthreads();
+    mm16(W, Qi, Phi, false, false, 1., nullptr, 0.);        // W = Q^-1 Phi
+    mm16(PQP, Phi, W, true, false, 1., nullptr, 0.);        // Phi^T Q^-1 Phi
+
+    // ---- the four distinct blocks of Sigma^-1 (mp_priors_multi.py:170-202, closed form)
+    for (int e = l; e < d * d; e += 64) {
+        const int r = e / d, c = e % d;
+        const double eye = (r == c) ? 1. : 0.;
+        const double pqp = PQP[r * TS + c], q = Qi[r * TS + c];
+        out.blocks[0 * d * d + e] = ks * eye + pqp;
+        out.blocks[1 * d * d + e] = q + pqp;
+        out.blocks[2 * d * d + e] = q + (kg >= 0. ? kg * eye : 0.);
+        out.blocks[3 * d * d + e] = -W[r * TS + c];
+        out.Qinv[e] = q;
+    }
+    // E = -W kept in W (sign folded into the solves below): E[r][c] = -W[r][c]
+    for (int e = l; e < TS * TS; e += 64) W[e] = -W[e];
+    // S = D_{T-1}
+    for (int e = l; e < TS * TS; e += 64) {
+        const int r = e / TS, c = e % TS;
+        double v = 0.;
+        if (r < d && c < d) {
+            const double eye = (r == c) ? 1. : 0.;
+            if (T == 1) v = ks * eye + (kg >= 0. ? kg * eye : 0.);
+            else v = Qi[e] + (kg >= 0. ? kg * eye : 0.);
+        }
+        S[e] = v;
+    }
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        // ---- reverse Cholesky: B lower triangular with B^T B = S
+        for (int j = d - 1; j >= 0; --j) {
+            if (l <= j) {
+                double v = S[j * TS + l];
+                for (int k = j + 1; k < d; ++k) v -= B[k * TS + j] * B[k * TS + l];
+                tmp[l] = v;
+            }
+            __syncthreads();
+            const double piv = tmp[j];
+            if (!(piv > 0.) || !(piv < 1e300)) { if (l == 0) bad = 1; }
+            const double r = sqrt(piv > 0. ? piv : 1.);
+            if (l < j) B[j * TS + l] = tmp[l] / r;
+            else if (l == j) B[j * TS + l] = r;
+            else if (l < TS) B[j * TS + l] = 0.;
+            __syncthreads();
+        }
+        // ---- G = B^-1 (forward substitution, lanes over columns)
+        for (int i = 0; i < d; ++i) {
+            if (l < d) {
+                double v = (i == l) ? 1. : 0.;
+                for (int k = 0; k < i; ++k) v -= B[i * TS + k] * G[k * TS + l];
+                G[i * TS + l] = v / B[i * TS + i];
+            }
+            __syncthreads();
+        }
+        if (t >= 1) {
+            // ---- C = B^-T E (back substitution on the upper-triangular B^T)
+            for (int i = d - 1; i >= 0; --i) {
+                if (l < d) {
+                    double v = W[i * TS + l];
+                    for (int k = i + 1; k < d; ++k) v -= B[k * TS + i] * C[k * TS + l];
+                    C[i * TS + l] = v / B[i * TS + i];
+                }
+                __syncthreads();
+            }
+            mm16(Hh, G, C, false, false, -1., nullptr, 0.);            // H_t = -B^-1 C
+        } else {
+            for (int e = l; e < TS * TS; e += 64) Hh[e] = 0.;
+            __syncthreads();
+        }
+        // ---- emit G_t, H_t
+        for (int e = l; e < d * d; e += 64) {
+            const int r = e / d, c = e % d;
+            const double g = G[r * TS + c], h = Hh[r * TS + c];
+            out.G[(size_t)t * d * d + e] = g;
+            out.H[(size_t)t * d * d + e] = h;
+            out.G32[(size_t)t * d * d + e] = (float)g;
+            out.H32[(size_t)t * d * d + e] = (float)h;
+        }
+        if (l < 8) {
+            double v = 0.;
+            switch (l) {
+                case 0: v = G[0]; break;                 // g11
+                case 1: v = G[n * TS + 0]; break;        // g21
+                case 2: v = G[n * TS + n]; break;        // g22
+                case 3: v = Hh[0]; break;                // h11
+                case 4: v = Hh[n]; break;                // h12
+                case 5: v = Hh[n * TS + 0]; break;       // h21
+                case 6: v = Hh[n * TS + n]; break;       // h22
+                default: v = 0.;
+            }
+            out.iso64[t * 8 + l] = v;
+            out.iso32[t * 8 + l] = (float)v;
+        }
+        if (t >= 1) {
+            // ---- Schur complement: S = D_{t-1} - C^T C
+            for (int e = l; e < TS * TS; e += 64) {
+                const int r = e / TS, c = e % TS;
+                double v = 0.;
+                if (r < d && c < d) {
+                    const double eye = (r == c) ? 1. : 0.;
+                    v = PQP[e] + ((t - 1 == 0) ? ks * eye : Qi[e]);
+                }
+                Dm[e] = v;
+            }
+            __syncthreads();
+            mm16(S, C, C, true, false, -1., Dm, 1.);
+        }
+    }
+    if (l == 0) *out.status = bad;
+}
+
+hipError_t launch_prior_factor(int n, int T, double dt, double ks, double kg, const double* d_qc_inv,
+                               int isotropic, PriorDev out, hipStream_t stream) {
+    // coefficients exactly as gp_factor.py:45-47 evaluates them in Python floats
+    const double c11 = 12. * pow(dt, -3.), c12 = -6. * pow(dt, -2.), c22 = 4. * pow(dt, -1.);
+    hipLaunchKernelGGL(prior_factor_kernel, dim3(1), dim3(64), 0, stream, n, T, c11, c12, c22, dt,
+                       ks, kg, d_qc_inv, isotropic, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,87 @@
+// Counter-based standard-normal noise for the sampler (K2): Philox4x32-10 + Box-Muller.
+//
+// The reference draws eps = randn(S, P, M) from torch's global CPU generator
+// (planner.py:48-49 -> torch multivariate_normal.py:250-253); that stream is sequential and cannot
+// be reproduced per element.  The native path therefore keys every normal on
+// (seed, draw, global particle, sample, waypoint, dof) so that results are independent of how
+// particles are sharded over GPUs and nothing has to be stored to revisit a sample.
+// Parity with the reference is checked in the separate external-eps mode of the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct Philox4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+
+// Two independent N(0,1) from two 32-bit words (fp32).  u1 in (0,1], tail reach 6.7 sigma.
+__device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float u1 = fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    const float u2 = (float)b * 2.3283064365386963e-10f;            // revolutions
+    const float r = sqrtf(-2.0f * 0.6931471805599453f * __log2f(u1));
+    z0 = r * __builtin_amdgcn_cosf(u2);                              // cos(2 pi u2)
+    z1 = r * __builtin_amdgcn_sinf(u2);
+}
+
+__device__ __forceinline__ void box_muller_f64(uint32_t a, uint32_t b, uint32_t c, uint32_t d,
+                                               double& z0, double& z1) {
+    const uint64_t m1 = (((uint64_t)a << 32) | b) >> 11;             // 53 bits
+    const uint64_t m2 = (((uint64_t)c << 32) | d) >> 11;
+    const double u1 = ((double)m1 + 0.5) * 1.1102230246251565e-16;   // (0,1)
+    const double u2 = (double)m2 * 1.1102230246251565e-16;           // [0,1)
+    const double r = sqrt(-2.0 * log(u1));
+    double s, co;
+    sincospi(2.0 * u2, &s, &co);
+    z0 = r * co;
+    z1 = r * s;
+}
+
+// Noise for waypoint t, dof k of (mode, sample): returns (eps[t, k], eps[t, n + k]).
+// fp32: one Philox call serves waypoints (t, t^1); the caller may cache it via `cache`.
+template <typename real> struct NoiseGen;
+
+template <> struct NoiseGen<float> {
+    uint32_t k0, k1, c1, c2, c3, kk;
+    float z[4];
+    int have = -1;
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t draw, uint32_t mode, uint32_t s,
+                                         uint32_t k) {
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+        c1 = s; c2 = mode; c3 = (uint32_t)draw; kk = k << 20;
+    }
+    __device__ __forceinline__ void get(int t, float& e_pos, float& e_vel) {
+        const int blk = t >> 1;
+        if (blk != have) {
+            const Philox4 r = philox4x32_10((uint32_t)blk | kk, c1, c2, c3, k0, k1);
+            box_muller_f32(r.x, r.y, z[0], z[1]);
+            box_muller_f32(r.z, r.w, z[2], z[3]);
+            have = blk;
+        }
+        e_pos = (t & 1) ? z[2] : z[0];
+        e_vel = (t & 1) ? z[3] : z[1];
+    }
+};
+
+template <> struct NoiseGen<double> {
+    uint32_t k0, k1, c1, c2, c3, kk;
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t draw, uint32_t mode, uint32_t s,
+                                         uint32_t k) {
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+        c1 = s; c2 = mode; c3 = (uint32_t)draw; kk = k << 20;
+    }
+    __device__ __forceinline__ void get(int t, double& e_pos, double& e_vel) {
+        const Philox4 r = philox4x32_10((uint32_t)t | kk, c1, c2, c3 ^ 0x80000000u, k0, k1);
+        box_muller_f64(r.x, r.y, r.z, r.w, e_pos, e_vel);
+    }
+};

@@ -1,0 +1,137 @@
+// K2 -- trajectory sampler:  out[m, s] = means[m] + scale_tril @ eps[s, m]   as an O(T d) scan.
+//
+// Replaces MultiMPPrior.sample (costs/factors/mp_priors_multi.py:204-207) ->
+// torch MultivariateNormal.rsample (multivariate_normal.py:250-253), whose dense
+// [P,M,M] @ [S,P,M,1] product is 81 % of the reference's iteration time.
+//
+// scale_tril @ eps solves L_inv y = eps with L_inv block-bidiagonal (prior_factor.hip), i.e.
+//     y_t = G_t eps_t + H_t y_{t-1}.
+// Isotropic path (every prior the public API can build: K_s, K_g, Q_c are multiples of I, so
+// G_t = g_t (x) I_n and H_t = h_t (x) I_n with 2x2 g_t, h_t): one thread per (sample, dof) runs a
+// 7-FMA recurrence on (position_k, velocity_k); coefficients are wave-uniform scalar loads.
+// Dense path (user-supplied Q_c_inv): one thread per sample carries the full d-vector.
+#include "sgpmp_internal.h"
+#include "rng.h"
+
+template <typename real>
+__global__ void __launch_bounds__(256)
+sample_iso_kernel(int n, int T, int S, int spb, const real* __restrict__ coef /*[T][8]*/,
+                  const real* __restrict__ means, const real* __restrict__ eps, int eps_modes,
+                  int eps_mode_offset, int mode_offset, uint64_t seed, uint64_t draw,
+                  real* __restrict__ out) {
+    const int m = blockIdx.y;
+    const int sl = threadIdx.x / n, k = threadIdx.x - sl * n;
+    const int s = blockIdx.x * spb + sl;
+    if (sl >= spb || s >= S) return;
+    const int d = 2 * n;
+    const size_t M = (size_t)T * d;
+    const real* mu = means + (size_t)m * M;
+    real* row = out + ((size_t)m * S + s) * M;
+    const real* erow = eps ? eps + ((size_t)s * eps_modes + eps_mode_offset + m) * M : nullptr;
+    NoiseGen<real> gen;
+    gen.init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)s, (uint32_t)k);
+    real p = 0, v = 0;
+    for (int t = 0; t < T; ++t) {
+        const real* c = coef + t * 8;
+        real e1, e2;
+        if (erow) { e1 = erow[t * d + k]; e2 = erow[t * d + n + k]; }
+        else gen.get(t, e1, e2);
+        const real pn = c[0] * e1 + c[3] * p + c[4] * v;
+        const real vn = c[1] * e1 + c[2] * e2 + c[5] * p + c[6] * v;
+        p = pn; v = vn;
+        row[t * d + k] = mu[t * d + k] + p;
+        row[t * d + n + k] = mu[t * d + n + k] + v;
+    }
+}
+
+template <typename real, int N>
+__global__ void __launch_bounds__(128)
+sample_dense_kernel(int T, int S, const real* __restrict__ G, const real* __restrict__ H,
+                    const real* __restrict__ means, const real* __restrict__ eps, int eps_modes,
+                    int eps_mode_offset, int mode_offset, uint64_t seed, uint64_t draw,
+                    real* __restrict__ out) {
+    constexpr int D = 2 * N;
+    const int m = blockIdx.y;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const size_t M = (size_t)T * D;
+    const real* mu = means + (size_t)m * M;
+    real* row = out + ((size_t)m * S + s) * M;
+    const real* erow = eps ? eps + ((size_t)s * eps_modes + eps_mode_offset + m) * M : nullptr;
+    NoiseGen<real> gen[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        gen[k].init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)s, (uint32_t)k);
+    real y[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) y[i] = 0;
+    for (int t = 0; t < T; ++t) {
+        real e[D];
+        if (erow) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) e[i] = erow[t * D + i];
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) gen[k].get(t, e[k], e[N + k]);
+        }
+        const real* Gt = G + (size_t)t * D * D;
+        const real* Ht = H + (size_t)t * D * D;
+        real yn[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            real acc = 0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                if (j <= i) acc += Gt[i * D + j] * e[j];
+                acc += Ht[i * D + j] * y[j];
+            }
+            yn[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) { y[i] = yn[i]; row[t * D + i] = mu[t * D + i] + yn[i]; }
+    }
+}
+
+template <typename real>
+static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t seed, uint64_t draw,
+                                  const real* means, int n_modes, int mode_offset, int S,
+                                  const real* eps, int eps_modes, int eps_mode_offset, real* out,
+                                  hipStream_t stream) {
+    constexpr bool f64 = sizeof(real) == 8;
+    if (prior.isotropic) {
+        const real* coef = f64 ? (const real*)prior.iso64 : (const real*)prior.iso32;
+        int spb = 256 / n;
+        if (spb > S) spb = S;
+        dim3 grid((S + spb - 1) / spb, n_modes), block(((spb * n + 63) / 64) * 64);
+        hipLaunchKernelGGL((sample_iso_kernel<real>), grid, block, 0, stream, n, T, S, spb, coef,
+                           means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, out);
+        return hipGetLastError();
+    }
+    const real* G = f64 ? (const real*)prior.G : (const real*)prior.G32;
+    const real* H = f64 ? (const real*)prior.H : (const real*)prior.H32;
+    dim3 grid((S + 127) / 128, n_modes), block(128);
+#define DENSE(NN)                                                                                  \
+    case NN:                                                                                       \
+        hipLaunchKernelGGL((sample_dense_kernel<real, NN>), grid, block, 0, stream, T, S, G, H,    \
+                           means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, out);  \
+        break;
+    switch (n) {
+        DENSE(1) DENSE(2) DENSE(3) DENSE(4) DENSE(5) DENSE(6) DENSE(7) DENSE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef DENSE
+    return hipGetLastError();
+}
+
+hipError_t launch_sample(int dtype, int n, int T, const PriorDev& prior, uint64_t seed, uint64_t draw,
+                         const void* means, int n_modes, int mode_offset, int n_samples,
+                         const void* eps, int eps_modes, int eps_mode_offset, void* out,
+                         hipStream_t stream) {
+    if (dtype == SGPMP_F64)
+        return sample_dispatch<double>(n, T, prior, seed, draw, (const double*)means, n_modes,
+                                       mode_offset, n_samples, (const double*)eps, eps_modes,
+                                       eps_mode_offset, (double*)out, stream);
+    return sample_dispatch<float>(n, T, prior, seed, draw, (const float*)means, n_modes, mode_offset,
+                                  n_samples, (const float*)eps, eps_modes, eps_mode_offset,
+                                  (float*)out, stream);
+}

@@ -1,0 +1,98 @@
+// Internal declarations shared by the HIP translation units of libsgpmp.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sgpmp.h"
+
+#define SGPMP_TILE 16                       // state blocks padded to one 16x16 MFMA tile
+#define SGPMP_MAX_D (2 * SGPMP_MAX_DOF)
+#define SGPMP_MAX_LINKS (SGPMP_MAX_JOINTS + 1)
+#define SGPMP_MAX_POINTS 32                 // links + interpolated points per field term
+#define SGPMP_WAVE 64
+
+// ---------------------------------------------------------------------------------- prior factor
+// Device-resident result of K1 for one prior (INIT or SAMPLE).
+struct PriorDev {
+    double* blocks;    // [4][d][d]  D0, D, Dlast, E
+    double* G;         // [T][d][d]
+    double* H;         // [T][d][d]
+    double* iso64;     // [T][8]  g11 g21 g22 h11 h12 h21 h22 0   (valid when isotropic)
+    float* iso32;      // [T][8]
+    double* Qinv;      // [d][d]   one-step GP precision of this prior
+    float* G32;        // [T][d][d] fp32 copies for the dense sampler
+    float* H32;
+    int* status;       // 0 ok, 1 not PD / non-finite
+    double ks, kg;     // 1/sigma_start^2, 1/sigma_goal^2 (kg < 0: not goal-directed)
+    double dt;
+    int isotropic;
+    int valid;
+};
+
+// ---------------------------------------------------------------------------------- cost program
+struct CostTerm {
+    int kind;
+    int flags;
+    double K;             // term weight: GP 1/sigma_gp^2, others 1/sigma^2
+    double K2;            // GP: 1/sigma_start^2 ; SELF: -1/(2 margin^2)
+    double dt;
+    double c11, c12, c22; // GP: 12/dt^3, -6/dt^2, 4/dt
+    const void* dev_data; // GP: start [d]; GOAL_PRIOR: goals [G,d]; GRID: grid [dim0,dim1]  (ctx dtype)
+    int dim0, dim1;
+    long long rows_per_goal;   // GOAL_PRIOR: nppg * S
+    double inv_cell, off_x, off_y;
+    int n_points;         // links + interpolated points
+    int n_interp, interp_lo, interp_hi;
+    double alpha[SGPMP_MAX_INTERP];
+};
+
+struct CostProgram {
+    int n_terms;
+    int needs_fk;
+    CostTerm terms[SGPMP_MAX_TERMS];
+};
+
+struct JointDev {
+    double R[9];          // fixed rotation of the joint origin (RPY)
+    double t[3];          // fixed translation
+    int revolute;
+    int qidx;
+};
+
+struct ChainDev {
+    int n_joints;
+    int n_links;          // n_joints + 1
+    JointDev j[SGPMP_MAX_JOINTS];
+};
+
+// ---------------------------------------------------------------------------------- launchers
+// (defined in the .hip files; all asynchronous on `stream`)
+hipError_t launch_prior_factor(int n, int T, double dt, double ks, double kg, const double* d_qc_inv,
+                               int isotropic, PriorDev out, hipStream_t stream);
+
+hipError_t launch_sample(int dtype, int n, int T, const PriorDev& prior, uint64_t seed, uint64_t draw,
+                         const void* means, int n_modes, int mode_offset, int n_samples,
+                         const void* eps, int eps_modes, int eps_mode_offset, void* out,
+                         hipStream_t stream);
+
+hipError_t launch_cost(int dtype, int n, int T, const CostProgram* d_prog, const CostProgram& h_prog,
+                       const ChainDev* d_chain, int n_links, const void* trajs, long long batch,
+                       long long batch_offset, const void* spheres, int n_spheres,
+                       const void* is_weights, int rows_per_particle, double is_dt, void* costs,
+                       double* costs64, hipStream_t stream);
+
+hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& prior, const void* means,
+                             int n_particles, double temperature, void* out, double* zero_stats,
+                             hipStream_t stream);
+
+hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int costs_dtype,
+                         const void* samples, void* means, double temperature, double step_size,
+                         void* weights, void* grad, void* means_prev, double* stats,
+                         hipStream_t stream);
+
+hipError_t launch_fk(int dtype, int n, const ChainDev* d_chain, int n_links, const void* q,
+                     long long batch, void* frames, hipStream_t stream);
+hipError_t launch_grid_lookup(int dtype, const CostTerm& term, const void* xy, long long batch,
+                              void* out, hipStream_t stream);
+hipError_t launch_field_eval(int dtype, const CostTerm& term, const void* frames, long long batch,
+                             int n_links, const void* spheres, int n_spheres, void* out,
+                             hipStream_t stream);

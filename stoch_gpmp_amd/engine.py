@@ -1,0 +1,232 @@
+"""Thin object wrapper over one `sgpmp_ctx` (include/sgpmp.h).  Plumbing only: it converts torch
+tensors to raw device pointers and Python descriptors to the C structs; no arithmetic happens here.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class Engine:
+    def __init__(self, n_dof, traj_len, num_particles, num_samples, num_goals=1,
+                 num_particles_per_goal=None, particle_offset=0, num_particles_global=None,
+                 tensor_args=None):
+        self.lib = L.load()
+        self.tensor_args = tensor_args
+        self.device = L.require_cuda(tensor_args)
+        self.dtype = tensor_args["dtype"]
+        nppg = num_particles_per_goal if num_particles_per_goal is not None else max(num_particles, 1)
+        self.dims = L.Dims(n_dof, traj_len, num_particles, particle_offset,
+                           num_particles_global if num_particles_global is not None
+                           else num_particles, num_samples, num_goals, nppg,
+                           L.dtype_code(self.dtype), 0)
+        self.n, self.T, self.d = n_dof, traj_len, 2 * n_dof
+        self.P, self.S = num_particles, num_samples
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_create(C.byref(self.dims), C.byref(self._ctx)))
+        self._keep = []          # tensors whose device memory the cost program points at
+        self.n_links = None
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self.lib.sgpmp_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ setup
+    def set_prior(self, which, dt, sigma_start, sigma_gp, sigma_goal=None, Q_c_inv=None):
+        qc = None
+        if Q_c_inv is not None:
+            flat = [float(v) for v in torch.as_tensor(Q_c_inv).detach().cpu().double().flatten()]
+            assert len(flat) == self.n * self.n
+            qc = (C.c_double * len(flat))(*flat)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_set_prior(
+                self._ctx, which, float(dt), float(sigma_start),
+                float(sigma_gp) if sigma_gp is not None else -1.0,
+                float(sigma_goal) if sigma_goal is not None else -1.0, qc, L.stream_ptr()))
+
+    def get_prior(self, which):
+        """-> (blocks [4,d,d], G [T,d,d], H [T,d,d]) as fp64 CPU tensors (inspection/tests)."""
+        d, T = self.d, self.T
+        blocks = (C.c_double * (4 * d * d))()
+        G = (C.c_double * (T * d * d))()
+        H = (C.c_double * (T * d * d))()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_get_prior(self._ctx, which, blocks, G, H))
+        to_t = lambda a, shape: torch.tensor(list(a), dtype=torch.float64).reshape(shape)
+        return to_t(blocks, (4, d, d)), to_t(G, (T, d, d)), to_t(H, (T, d, d))
+
+    def set_costs(self, descs):
+        """descs: list of dicts produced by the Cost classes' `descriptor()`."""
+        arr = (L.CostDesc * max(len(descs), 1))()
+        self._keep = []
+        host_keep = []
+        for i, dsc in enumerate(descs):
+            cd = arr[i]
+            cd.kind = dsc["kind"]
+            cd.flags = dsc.get("flags", 0)
+            cd.sigma = float(dsc["sigma"])
+            cd.sigma2 = float(dsc.get("sigma2", 0.0))
+            cd.dt = float(dsc.get("dt", 0.0))
+            cd.dim0, cd.dim1 = int(dsc.get("dim0", 0)), int(dsc.get("dim1", 0))
+            cd.p0, cd.p1, cd.p2 = (float(dsc.get(k, 0.0)) for k in ("p0", "p1", "p2"))
+            cd.num_interpolate = int(dsc.get("num_interpolate", 0))
+            cd.interp_lo, cd.interp_hi = int(dsc.get("interp_lo", 0)), int(dsc.get("interp_hi", 0))
+            for a, v in enumerate(dsc.get("alpha", [])):
+                cd.alpha[a] = float(v)
+            if "host_data" in dsc:
+                vals = [float(v) for v in dsc["host_data"]]
+                buf = (C.c_double * len(vals))(*vals)
+                host_keep.append(buf)
+                cd.data = C.cast(buf, C.c_void_p)
+            elif "device_tensor" in dsc:
+                t = dsc["device_tensor"].to(device=self.device, dtype=self.dtype).contiguous()
+                self._keep.append(t)
+                cd.data = C.c_void_p(t.data_ptr())
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_set_costs(self._ctx, arr, len(descs)))
+
+    def set_fk(self, chain):
+        """chain: list of (name, 'revolute'|'fixed', rpy, xyz)."""
+        arr = (L.Joint * len(chain))()
+        for i, (_, kind, rpy, xyz) in enumerate(chain):
+            arr[i].rpy = (C.c_double * 3)(*[float(v) for v in rpy])
+            arr[i].xyz = (C.c_double * 3)(*[float(v) for v in xyz])
+            arr[i].revolute = 1 if kind == "revolute" else 0
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_set_fk(self._ctx, arr, len(chain)))
+        self.n_links = len(chain) + 1
+
+    # ------------------------------------------------------------------ kernels
+    def _chk(self, t, name):
+        if t is None:
+            return
+        if not t.is_cuda or t.dtype != self.dtype or not t.is_contiguous():
+            raise ValueError(f"{name}: expected a contiguous {self.dtype} tensor on {self.device}")
+
+    def sample(self, which, seed, draw, means, n_samples, out=None, eps=None, eps_mode_offset=0,
+               mode_offset=0):
+        n_modes = means.shape[0]
+        self._chk(means, "means")
+        if out is None:
+            out = torch.empty(n_modes, n_samples, self.T, self.d, **self.tensor_args)
+        self._chk(out, "out")
+        eps_modes = 0
+        if eps is not None:
+            self._chk(eps, "eps")
+            assert eps.dim() == 3 and eps.shape[0] == n_samples and eps.shape[2] == self.T * self.d
+            eps_modes = eps.shape[1]
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_sample(self._ctx, which, int(seed), int(draw), L.ptr(means),
+                                          n_modes, mode_offset, n_samples, L.ptr(eps), eps_modes,
+                                          eps_mode_offset, L.ptr(out), L.stream_ptr()))
+        return out
+
+    def cost_eval(self, trajs, batch_offset=0, spheres=None, is_weights=None, rows_per_particle=1,
+                  out=None, out64=None):
+        self._chk(trajs, "trajs")
+        B = trajs.numel() // (self.T * self.d)
+        if out is None and out64 is None:
+            out = torch.empty(B, **self.tensor_args)
+        n_sph = 0
+        if spheres is not None:
+            spheres = spheres.reshape(-1, 4)
+            self._chk(spheres, "obstacle_spheres")
+            n_sph = spheres.shape[0]
+        self._chk(is_weights, "is_weights")
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_cost_eval(self._ctx, L.ptr(trajs), B, batch_offset,
+                                             L.ptr(spheres), n_sph, L.ptr(is_weights),
+                                             rows_per_particle, L.ptr(out), L.ptr(out64),
+                                             L.stream_ptr()))
+        return out if out is not None else out64
+
+    def is_weights(self, means, temperature, out=None):
+        self._chk(means, "means")
+        P = means.shape[0]
+        if out is None:
+            out = torch.empty(P, self.T + 1, self.d, **self.tensor_args)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_is_weights(self._ctx, L.ptr(means), P, float(temperature),
+                                              L.ptr(out), L.stream_ptr()))
+        return out
+
+    def update(self, costs, samples, means, temperature, step_size, weights=None, grad=None,
+               means_prev=None, stats=None):
+        self._chk(samples, "samples")
+        self._chk(means, "means")
+        if costs.dtype == torch.float64:
+            cd = L.SGPMP_F64
+        else:
+            cd = L.dtype_code(costs.dtype)
+        assert costs.is_cuda and costs.is_contiguous()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_update(self._ctx, L.ptr(costs), cd, L.ptr(samples), L.ptr(means),
+                                          float(temperature), float(step_size), L.ptr(weights),
+                                          L.ptr(grad), L.ptr(means_prev), L.ptr(stats),
+                                          L.stream_ptr()))
+
+    def step(self, seed, draw, means, samples, temperature, step_size, costs=None, weights=None,
+             grad=None, means_prev=None, spheres=None, eps=None, eps_mode_offset=0, stats=None):
+        n_sph = 0
+        if spheres is not None:
+            n_sph = spheres.shape[0]
+        eps_modes = 0 if eps is None else eps.shape[1]
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_step(self._ctx, int(seed), int(draw), L.ptr(eps), eps_modes,
+                                        eps_mode_offset, L.ptr(means), L.ptr(samples), L.ptr(costs),
+                                        L.ptr(weights), L.ptr(grad), L.ptr(means_prev),
+                                        L.ptr(spheres), n_sph,
+                                        float(temperature), float(step_size), L.ptr(stats),
+                                        L.stream_ptr()))
+
+    def fk(self, q):
+        self._chk(q, "q")
+        B = q.shape[0]
+        out = torch.empty(B, self.n_links, 4, 4, **self.tensor_args)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_fk(self._ctx, L.ptr(q), B, L.ptr(out), L.stream_ptr()))
+        return out
+
+    def grid_lookup(self, term, xy):
+        self._chk(xy, "X")
+        B = xy.numel() // 2
+        out = torch.empty(B, **self.tensor_args)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_grid_lookup(self._ctx, term, L.ptr(xy), B, L.ptr(out),
+                                               L.stream_ptr()))
+        return out
+
+    def field_eval(self, term, frames, spheres=None):
+        self._chk(frames, "link_tensor")
+        n_links = frames.shape[-3]
+        B = frames.numel() // (n_links * 16)
+        out = torch.empty(B, **self.tensor_args)
+        n_sph = 0
+        if spheres is not None:
+            spheres = spheres.reshape(-1, 4)
+            self._chk(spheres, "obstacle_spheres")
+            n_sph = spheres.shape[0]
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_field_eval(self._ctx, term, L.ptr(frames), B, n_links,
+                                              L.ptr(spheres), n_sph, L.ptr(out), L.stream_ptr()))
+        return out
+
+    # ------------------------------------------------------------------ profiling
+    def profile_enable(self, on=True):
+        L.check(self.lib.sgpmp_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self):
+        ms = (C.c_double * 4)()
+        n = C.c_int64()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_profile_read(self._ctx, ms, C.byref(n)))
+        return dict(zip(("is_weights", "sample", "cost_sweep", "update"), list(ms))), n.value

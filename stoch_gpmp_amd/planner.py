@@ -1,0 +1,423 @@
+"""StochGPMP -- the sampling planner of reference `stoch_gpmp/planner.py:18-348` with the same
+constructor, `reset`, `optimize`, `sample_and_eval`, `_update_distribution`, `get_recent_samples`
+and `sample_trajectories`, running on the HIP kernels of libsgpmp.so.
+
+Per iteration (the loop body at reference planner.py:289-299) the reference rebuilds a
+MultivariateNormal over a replicated [P,M,M] precision, samples through a dense M x M factor,
+evaluates the costs with a dozen torch ops and a dense importance-sampling matmul.  Here one call,
+`sgpmp_step`, enqueues K5 (IS weights) -> K2 (scan sampler) -> K3 (cost sweep) -> K4 (reweight +
+mean update) on the current HIP stream; Python only passes pointers.
+
+Additions over the reference API (all optional keyword arguments):
+  noise='philox' | 'torch'   'philox' (default) draws counter-based noise inside K2, keyed on
+                             (seed, draw, global particle, sample, element) -- independent of how
+                             particles are sharded.  'torch' replays the reference's noise stream:
+                             eps = torch.randn(S, P, M) from the global CPU generator in the
+                             reference's call order (planner.py:48-49,213,227,243), fed to K2 --
+                             identical seeds then give the reference's trajectories (parity mode).
+  rank / world_size          shard the particles over one process per GPU (contiguous ranges);
+                             statistics are all-reduced over RCCL once per iteration.
+  step()                     one loop body, public (the reference only has it inline).
+"""
+import time
+
+import torch
+
+from . import _lib as L
+from .costs.factors.gp_factor import GPFactor
+from .costs.factors.unary_factor import UnaryFactor
+from .dist import allgather_means, allreduce_stats_async, shard_range
+from .engine import Engine
+
+
+class StochGPMP:
+
+    def __init__(
+            self,
+            num_particles_per_goal,
+            num_samples,
+            traj_len,
+            opt_iters,
+            dt=None,
+            n_dof=None,
+            step_size=1.,
+            temperature=1.,
+            start_state=None,
+            multi_goal_states=None,
+            initial_particle_means=None,
+            cost=None,
+            sigma_start_init=None,
+            sigma_start_sample=None,
+            sigma_goal_init=None,
+            sigma_goal_sample=None,
+            sigma_gp_init=None,
+            sigma_gp_sample=None,
+            seed=None,
+            tensor_args=None,
+            noise='philox',
+            rank=None,
+            world_size=None,
+            process_group=None,
+            **kwargs
+    ):
+        if tensor_args is None:
+            tensor_args = {'device': torch.device('cuda:0'), 'dtype': torch.float32}
+        self.tensor_args = tensor_args
+        L.require_cuda(tensor_args)
+        if noise not in ('philox', 'torch'):
+            raise ValueError("noise must be 'philox' or 'torch'")
+        self.noise = noise
+
+        if seed is not None:
+            torch.manual_seed(seed)              # same global side effect as planner.py:48-49
+        self.seed = 0 if seed is None else int(seed)
+
+        self.n_dof = n_dof
+        self.d_state_opt = 2 * self.n_dof
+        self.dt = dt
+        self.traj_len = traj_len
+        self.goal_directed = (multi_goal_states is not None)
+        if not self.goal_directed:
+            self.num_goals = 1
+        else:
+            assert multi_goal_states.dim() == 2
+            self.num_goals = multi_goal_states.shape[0]
+        self.num_particles_per_goal = num_particles_per_goal
+        self.num_particles = num_particles_per_goal * self.num_goals        # global P
+        self.num_samples = num_samples
+        self.opt_iters = opt_iters
+        self.step_size = step_size
+        self.temperature = temperature
+        self.sigma_start_init = sigma_start_init
+        self.sigma_start_sample = sigma_start_sample
+        self.sigma_goal_init = sigma_goal_init
+        self.sigma_goal_sample = sigma_goal_sample
+        self.sigma_gp_init = sigma_gp_init
+        self.sigma_gp_sample = sigma_gp_sample
+        self.start_states = start_state
+        self.multi_goal_states = multi_goal_states
+        self.cost = cost
+
+        # particle sharding (one process per GPU)
+        if world_size is None:
+            if torch.distributed.is_available() and torch.distributed.is_initialized() \
+                    and kwargs.get('distributed', False):
+                world_size = torch.distributed.get_world_size(process_group)
+                rank = torch.distributed.get_rank(process_group)
+            else:
+                world_size, rank = 1, 0
+        self.world_size, self.rank, self.process_group = world_size, rank or 0, process_group
+        self.p0, self.p1 = shard_range(self.num_particles, self.rank, self.world_size)
+        self.num_particles_local = self.p1 - self.p0
+
+        self._mean = None
+        self._weights = None
+        self._sample_dist = None
+        self._engine = None
+        self._draw = 0
+        self._pending_reduce = []
+
+        self.reset(start_state, multi_goal_states, initial_particle_means=initial_particle_means)
+
+    # ------------------------------------------------------------------------------- factors
+    def set_prior_factors(self):
+        """Descriptor objects with the reference's attribute names (planner.py:84-140)."""
+        ta, d, n, T = self.tensor_args, self.d_state_opt, self.n_dof, self.traj_len
+        self.start_prior_init = UnaryFactor(d, self.sigma_start_init, self.start_states, ta)
+        self.gp_prior_init = GPFactor(n, self.sigma_gp_init, self.dt, T - 1, ta)
+        self.start_prior_sample = UnaryFactor(d, self.sigma_start_sample, self.start_states, ta)
+        self.gp_prior_sample = GPFactor(n, self.sigma_gp_sample, self.dt, T - 1, ta)
+        self.multi_goal_prior_init, self.multi_goal_prior_sample = [], []
+        if self.goal_directed:
+            for i in range(self.num_goals):
+                self.multi_goal_prior_init.append(
+                    UnaryFactor(d, self.sigma_goal_init, self.multi_goal_states[i], ta))
+                self.multi_goal_prior_sample.append(
+                    UnaryFactor(d, self.sigma_goal_sample, self.multi_goal_states[i], ta))
+
+    def const_vel_trajectories(self, start_state, multi_goal_states):
+        """planner.py:142-155 (velocity uses /(T dt)); setup-time, tiny."""
+        T, n = self.traj_len, self.n_dof
+        traj_dim = (multi_goal_states.shape[0], self.num_particles_per_goal, T, self.d_state_opt)
+        state_traj = torch.zeros(traj_dim, **self.tensor_args)
+        mean_vel = (multi_goal_states[:, :n] - start_state[:n]) / (T * self.dt)
+        for i in range(T):
+            interp = start_state[:n] * (T - i - 1) / (T - 1) + multi_goal_states[:, :n] * i / (T - 1)
+            state_traj[:, :, i, :n] = interp.unsqueeze(1)
+        state_traj[:, :, :, n:] = mean_vel.unsqueeze(1).unsqueeze(1)
+        return state_traj
+
+    def _const_vel_prior_means(self):
+        """Means of the initialisation prior (mp_priors_multi.py:130-168): [G,T,d]."""
+        T, n = self.traj_len, self.n_dof
+        steps = T - 1
+        if not self.goal_directed:
+            return self.start_state.repeat(T, 1).unsqueeze(0).contiguous()
+        means = torch.zeros(self.num_goals, T, self.d_state_opt, **self.tensor_args)
+        vel = (self.multi_goal_states[:, :n] - self.start_state[:n]) / (steps * self.dt)
+        for i in range(T):
+            means[:, i, :n] = self.start_state[:n] * (steps - i) * 1. / steps \
+                + self.multi_goal_states[:, :n] * i * 1. / steps
+        means[:, :, n:] = vel.unsqueeze(1)
+        return means
+
+    # ------------------------------------------------------------------------------- reset
+    def reset(self, start_state=None, multi_goal_states=None, initial_particle_means=None):
+        if start_state is not None:
+            self.start_state = start_state.detach().clone()
+        if multi_goal_states is not None:
+            self.multi_goal_states = multi_goal_states.detach().clone()
+        self.set_prior_factors()
+
+        ta = self.tensor_args
+        T, d, n, S = self.traj_len, self.d_state_opt, self.n_dof, self.num_samples
+        G, nppg, P, Pl = self.num_goals, self.num_particles_per_goal, self.num_particles, \
+            self.num_particles_local
+        M = T * d
+
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = Engine(n, T, Pl, S, G, nppg, self.p0, P, tensor_args=ta)
+        eng = self._engine
+        goal_init = self.sigma_goal_init if self.goal_directed else None
+        goal_sample = self.sigma_goal_sample if self.goal_directed else None
+        # K1 twice (init + sampling priors): planner.py:206-212, 218-225
+        eng.set_prior(L.PRIOR_SAMPLE, self.dt, self.sigma_start_sample, self.sigma_gp_sample, goal_sample)
+        self._draw = 0
+
+        if initial_particle_means is not None:
+            if isinstance(initial_particle_means, str) and initial_particle_means == 'const_vel':
+                pm = self.const_vel_trajectories(self.start_state, self.multi_goal_states)
+            else:
+                pm = initial_particle_means
+            pm = pm.to(**ta)
+        else:
+            eng.set_prior(L.PRIOR_INIT, self.dt, self.sigma_start_init, self.sigma_gp_init, goal_init)
+            init_means = self._const_vel_prior_means().contiguous()
+            eps = None
+            if self.noise == 'torch':                      # reference draw #1: randn(nppg, G, M)
+                eps = torch.randn(nppg, G, M, dtype=ta['dtype']).to(ta['device'])
+            pm = eng.sample(L.PRIOR_INIT, self.seed, self._draw, init_means, nppg, eps=eps)
+        self._draw += 1
+        # flatten(0,1): p = g * nppg + k (planner.py:215); keep this rank's shard
+        self.particle_means = pm.reshape(P, T, d)[self.p0:self.p1].contiguous().clone()
+
+        # persistent buffers of the iteration
+        self.state_samples = torch.empty(Pl, S, T, d, **ta)
+        self._costs = torch.empty(Pl, S, **ta)
+        self._costs64 = torch.empty(Pl, S, device=ta['device'], dtype=torch.float64)
+        self._costs64_fresh = False
+        self._weights_buf = torch.empty(Pl, S, **ta)
+        self._grad = torch.empty(Pl, T, d, **ta)
+        self._means_prev = torch.empty(Pl, T, d, **ta)
+        self._stats = torch.zeros(2, 4, device=ta['device'], dtype=torch.float64)
+        self._stats_slot = 0
+        self._Sigma_inv = None
+        self._obs_cache = (None, None)
+
+        # cost program: our CostComposite is compiled into the engine; anything else with .eval is
+        # called as user code on the samples tensor (planner.py:76,231)
+        self._native_cost = hasattr(self.cost, "compile_into")
+        if self._native_cost:
+            self.cost.compile_into(eng)
+        else:
+            eng.set_costs([])
+
+        # the reference draws one throw-away batch here (planner.py:227); keep the stream aligned
+        eps = None
+        if self.noise == 'torch':
+            eps = torch.randn(S, P, M, dtype=ta['dtype']).to(ta['device'])
+        if Pl > 0:
+            eng.sample(L.PRIOR_SAMPLE, self.seed, self._draw, self.particle_means, S,
+                       out=self.state_samples, eps=eps, eps_mode_offset=self.p0 if eps is not None else 0,
+                       mode_offset=self.p0)
+        self._draw += 1
+
+    @property
+    def Sigma_inv(self):
+        """Dense [M,M] precision of the sampling prior (planner.py:226), assembled on demand from
+        K1's blocks -- the kernels never materialise it."""
+        if self._Sigma_inv is None:
+            blocks, _, _ = self._engine.get_prior(L.PRIOR_SAMPLE)
+            d, T = self.d_state_opt, self.traj_len
+            S = torch.zeros(T * d, T * d, dtype=torch.float64)
+            for t in range(T):
+                S[t * d:(t + 1) * d, t * d:(t + 1) * d] = blocks[0 if t == 0 else (2 if t == T - 1 else 1)]
+                if t + 1 < T:
+                    S[(t + 1) * d:(t + 2) * d, t * d:(t + 1) * d] = blocks[3]
+                    S[t * d:(t + 1) * d, (t + 1) * d:(t + 2) * d] = blocks[3].t()
+            self._Sigma_inv = S.to(**self.tensor_args)
+        return self._Sigma_inv
+
+    # ------------------------------------------------------------------------------- helpers
+    def _spheres(self, observation):
+        sph = observation.get('obstacle_spheres', None)
+        if sph is None:
+            return None
+        key = (id(sph), sph._version)
+        if self._obs_cache[0] != key:
+            self._obs_cache = (key, sph.to(**self.tensor_args).reshape(-1, 4).contiguous())
+        return self._obs_cache[1]
+
+    def _draw_eps(self):
+        if self.noise != 'torch':
+            return None
+        ta = self.tensor_args
+        return torch.randn(self.num_samples, self.num_particles, self.traj_len * self.d_state_opt,
+                           dtype=ta['dtype']).to(ta['device'])
+
+    def _reduce_stats(self, slot):
+        if self.world_size > 1:
+            self._pending_reduce.append(allreduce_stats_async(self._stats[slot], self.process_group))
+            if len(self._pending_reduce) > 1:           # never gate the next iteration's kernels
+                self._pending_reduce.pop(0).wait()
+
+    def global_stats(self):
+        """(mean over particles of sum_s cost, mean over particles of min_s cost) of the last
+        iteration, over ALL ranks (reference print_info statistic, planner.py:668-672)."""
+        for w in self._pending_reduce:
+            w.wait()
+        self._pending_reduce = []
+        s = self._stats[self._stats_slot ^ 1].cpu()
+        cnt = max(float(s[2]), 1.0)
+        return float(s[0]) / cnt, float(s[1]) / cnt
+
+    # ------------------------------------------------------------------------------- the loop
+    def step(self, **observation):
+        """One body of the loop at planner.py:289-299 on this rank's particle shard."""
+        if not self._native_cost:
+            return self._step_foreign_cost(**observation)
+        slot = self._stats_slot
+        if self.num_particles_local > 0:
+            self._engine.step(self.seed, self._draw, self.particle_means, self.state_samples,
+                              self.temperature, self.step_size, costs=self._costs,
+                              weights=self._weights_buf, grad=self._grad, means_prev=self._means_prev,
+                              spheres=self._spheres(observation), eps=self._draw_eps(),
+                              eps_mode_offset=self.p0, stats=self._stats[slot])
+        self._draw += 1
+        self._reduce_stats(slot)
+        self._stats_slot ^= 1
+        self._weights = self._weights_buf.view(-1, self.num_samples, 1, 1)
+        return self._costs, self._grad
+
+    def _step_foreign_cost(self, **observation):
+        """`cost` is user code with .eval(trajs, **obs) (e.g. a learned EBM, reference README.md:3):
+        sample with K2, hand the samples tensor to it, add the IS term (K5 + K3 with an empty
+        program) and update with K4."""
+        eng = self._engine
+        eps = self._draw_eps()
+        eng.sample(L.PRIOR_SAMPLE, self.seed, self._draw, self.particle_means, self.num_samples,
+                   out=self.state_samples, eps=eps, eps_mode_offset=self.p0 if eps is not None else 0,
+                   mode_offset=self.p0)
+        self._draw += 1
+        costs = self._get_costs(**observation)
+        grad = self._update_distribution(costs, self.state_samples)
+        return costs, grad
+
+    def _get_costs(self, **observation):
+        """planner.py:229-237 as separate calls (cost.eval + importance-sampling term)."""
+        eng = self._engine
+        Pl, S = self.num_particles_local, self.num_samples
+        isw = eng.is_weights(self.particle_means, self.temperature)
+        if self._native_cost:
+            eng.cost_eval(self.state_samples, batch_offset=self.p0 * S,
+                          spheres=self._spheres(observation), is_weights=isw, rows_per_particle=S,
+                          out=self._costs, out64=self._costs64)
+            self._costs64_fresh = True       # fp64 twin of the costs just returned
+            return self._costs
+        user = self.cost.eval(self.state_samples, **observation).reshape(Pl, S)
+        eng.cost_eval(self.state_samples, batch_offset=self.p0 * S, is_weights=isw,
+                      rows_per_particle=S, out=self._costs)
+        return user.to(self._costs.dtype) + self._costs
+
+    def sample_and_eval(self, **observation):
+        """planner.py:239-261."""
+        eps = self._draw_eps()
+        self._engine.sample(L.PRIOR_SAMPLE, self.seed, self._draw, self.particle_means,
+                            self.num_samples, out=self.state_samples, eps=eps,
+                            eps_mode_offset=self.p0 if eps is not None else 0, mode_offset=self.p0)
+        self._draw += 1
+        costs = self._get_costs(**observation)
+        n = self.n_dof
+        return (self.state_samples[..., -n:], self.state_samples[..., :n],
+                self.particle_means[..., -n:].clone(), self.particle_means[..., :n].clone(), costs)
+
+    def _update_distribution(self, costs, traj_samples):
+        """planner.py:263-275 (K4)."""
+        if costs is self._costs and self._costs64_fresh:
+            costs = self._costs64            # our own costs handed back: keep their fp64 accumulators
+        self._costs64_fresh = False
+        costs = costs.contiguous()
+        self._engine.update(costs, traj_samples.contiguous(), self.particle_means, self.temperature,
+                            self.step_size, weights=self._weights_buf, grad=self._grad,
+                            means_prev=self._means_prev)
+        self._weights = self._weights_buf.view(-1, self.num_samples, 1, 1)
+        return self._grad
+
+    def optimize(self, opt_iters=None, debug=False, **observation):
+        """planner.py:277-317.  Returns (state_particles, control_particles, state_trajectories,
+        control_samples, costs, approx_grad) of the LAST iteration; the particle tensors are the
+        PRE-update means, as in the reference (planner.py:252-253)."""
+        if opt_iters is None:
+            opt_iters = self.opt_iters
+        start_time = time.time()
+        costs = approx_grad = None
+        for opt_step in range(opt_iters):
+            start_time_iter = time.time()
+            costs, approx_grad = self.step(**observation)
+            if debug and opt_step % 50 == 0:
+                print_info(opt_step, opt_iters, start_time_iter, start_time, costs)
+        n = self.n_dof
+        state_trajectories = self.state_samples[..., :n]
+        control_samples = self.state_samples[..., -n:]
+        state_particles = self._means_prev[..., :n]
+        control_particles = self._means_prev[..., -n:]
+        self._recent_control_samples = control_samples
+        self._recent_control_particles = control_particles
+        self._recent_state_trajectories = state_trajectories
+        self._recent_state_particles = state_particles
+        self._recent_weights = self._weights
+        return (state_particles, control_particles, state_trajectories, control_samples, costs,
+                approx_grad)
+
+    def _get_traj(self, mode='best'):
+        if mode == 'best':
+            particle_ind = self._weights.argmax()        # same (flat) indexing as planner.py:321-323
+            return self.state_samples[particle_ind].clone()
+        elif mode == 'mean':
+            return self._mean.clone()
+        raise ValueError('Unidentified sampling mode in get_next_action')
+
+    def get_recent_samples(self):
+        return (self._recent_state_trajectories.detach().clone(),
+                self._recent_control_samples.detach().clone())
+
+    def sample_trajectories(self, num_samples_per_particle):
+        """planner.py:339-348: fresh draws about the current means."""
+        Pl, T, d = self.num_particles_local, self.traj_len, self.d_state_opt
+        eps = None
+        if self.noise == 'torch':
+            eps = torch.randn(num_samples_per_particle, self.num_particles, T * d,
+                              dtype=self.tensor_args['dtype']).to(self.tensor_args['device'])
+        self.state_samples = self._engine.sample(
+            L.PRIOR_SAMPLE, self.seed, self._draw, self.particle_means, num_samples_per_particle,
+            eps=eps, eps_mode_offset=self.p0 if eps is not None else 0, mode_offset=self.p0)
+        self._draw += 1
+        return self.state_samples[..., :self.n_dof], self.state_samples[..., -self.n_dof:]
+
+    def gather_particle_means(self):
+        """All ranks' particle means [P,T,d] (RCCL all-gather over xGMI); identity on one GPU."""
+        if self.world_size == 1:
+            return self.particle_means
+        return allgather_means(self.particle_means, self.num_particles, self.world_size,
+                               self.process_group)
+
+
+def print_info(opt_step, opt_iters, start_time_iter, start_time, costs):
+    """Same line format as reference planner.py:664-672."""
+    now = time.time()
+    fields = ['Iteration: %5d/%5d ' % (opt_step, opt_iters),
+              ' Iter Time: %.3f' % (now - start_time_iter),
+              ' Total Time: %.3f ' % (now - start_time),
+              ' Cost: %.6f' % float(costs.sum(-1).mean())]
+    print('|'.join(fields))

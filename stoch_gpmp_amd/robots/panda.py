@@ -1,0 +1,72 @@
+"""Franka Panda (no gripper) kinematic chain as plain URDF constants.
+
+The reference gets FK from the third-party `torch_robotics.DifferentiableFrankaPanda`
+(reference examples/panda_environment.py:13,47,98), which is neither vendored nor versioned; this
+class provides the same call -- `compute_forward_kinematics_all_links(q) -> [B, L, 4, 4]` -- backed by
+the HIP FK kernel, with the joint origins typed from
+assets/franka_description/robots/panda_arm_no_gripper.urdf:41-47,66-72,91-97,116-122,141-147,
+166-172,191-197 (revolute, axis z) and :200-204,206-210,230-235 (fixed).  Link table (documented
+choice, the third-party one cannot be verified): panda_link0..8, panda_hand, ee_link (L = 11).
+"""
+import torch
+
+from ..engine import Engine
+
+PANDA_CHAIN = [
+    ("panda_joint1", "revolute", (0.0, 0.0, 0.0), (0.0, 0.0, 0.333)),
+    ("panda_joint2", "revolute", (-1.57079632679, 0.0, 0.0), (0.0, 0.0, 0.0)),
+    ("panda_joint3", "revolute", (1.57079632679, 0.0, 0.0), (0.0, -0.316, 0.0)),
+    ("panda_joint4", "revolute", (1.57079632679, 0.0, 0.0), (0.0825, 0.0, 0.0)),
+    ("panda_joint5", "revolute", (-1.57079632679, 0.0, 0.0), (-0.0825, 0.384, 0.0)),
+    ("panda_joint6", "revolute", (1.57079632679, 0.0, 0.0), (0.0, 0.0, 0.0)),
+    ("panda_joint7", "revolute", (1.57079632679, 0.0, 0.0), (0.088, 0.0, 0.0)),
+    ("panda_joint8", "fixed", (0.0, 0.0, 0.0), (0.0, 0.0, 0.107)),
+    ("panda_hand_joint", "fixed", (0.0, 0.0, -0.785398163397), (0.0, 0.0, 0.0)),
+    ("ee_fixed_joint", "fixed", (0.0, 0.0, -1.57), (0.0, 0.0, 0.1)),
+]
+PANDA_LINK_NAMES = ["panda_link0", "panda_link1", "panda_link2", "panda_link3", "panda_link4",
+                    "panda_link5", "panda_link6", "panda_link7", "panda_link8", "panda_hand",
+                    "ee_link"]
+# joint limits (URDF :47,72,97,122,147,172,197)
+PANDA_Q_LOWER = [-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973]
+PANDA_Q_UPPER = [2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973]
+
+
+class URDFChain:
+    """A serial chain of revolute(z)/fixed joints; FK runs in the HIP kernel `fk_frames_kernel`."""
+
+    def __init__(self, chain, link_names=None, device=None, tensor_args=None):
+        self.chain = list(chain)
+        self._n_dofs = sum(1 for j in self.chain if j[1] == "revolute")
+        self.link_names = link_names or [f"link{i}" for i in range(len(self.chain) + 1)]
+        if tensor_args is None:
+            tensor_args = {"device": device if device is not None else torch.device("cuda:0"),
+                           "dtype": torch.float32}
+        self.tensor_args = tensor_args
+        self._engines = {}
+
+    def print_link_names(self):
+        for i, name in enumerate(self.link_names):
+            print(i, name)
+
+    def _engine(self, dtype, device):
+        key = (dtype, str(device))
+        if key not in self._engines:
+            eng = Engine(self._n_dofs, 2, 0, 1, tensor_args={"device": device, "dtype": dtype})
+            eng.set_fk(self.chain)
+            self._engines[key] = eng
+        return self._engines[key]
+
+    def compute_forward_kinematics_all_links(self, q):
+        """q [B, n_dofs] -> homogeneous link frames [B, L, 4, 4]."""
+        q = q.contiguous()
+        return self._engine(q.dtype, q.device).fk(q)
+
+
+class DifferentiableFrankaPanda(URDFChain):
+    """Name-compatible stand-in for torch_robotics' class (forward pass only)."""
+
+    def __init__(self, gripper=False, device=None, tensor_args=None):
+        if gripper:
+            raise NotImplementedError("only the gripper-less chain of the reference example is built")
+        super().__init__(PANDA_CHAIN, PANDA_LINK_NAMES, device=device, tensor_args=tensor_args)

@@ -9,29 +9,7 @@ import torch
 
 from oracle import ref_equiv as R
 
-PLANAR = dict(n_dof=2, dt=0.02, start=[-9., -9., 0., 0.],
-              cost_sigma_start=1e-3, cost_sigma_gp=0.1, sigma_coll=1e-5, sigma_goal_prior=1e-3,
-              sigma_start_init=1e-3, sigma_goal_init=1e-3, sigma_gp_init=20.,
-              sigma_start_sample=1e-3, sigma_goal_sample=1e-3, sigma_gp_sample=3.,
-              step_size=0.5, temperature=1.)
-
-PANDA = dict(n_dof=7, dt=0.05,
-             start_q=[0.012, -0.57, 0., -2.81, 0., 3.037, 0.741],
-             goal_q=[0.5, 0.2, 0.3, -1.5, 0.1, 2.0, 0.3],
-             cost_sigma_start=1e-4, cost_sigma_gp=7e-4, sigma_self=0.01, sigma_coll=0.01,
-             sigma_goal_prior=20., self_margin=0.03,
-             sigma_start_init=1e-4, sigma_goal_init=0.1, sigma_gp_init=0.8,
-             sigma_start_sample=1e-3, sigma_goal_sample=0.07, sigma_gp_sample=0.1,
-             step_size=0.1, temperature=1.)
-
-
-def panda_spheres(num=5, seed=0):
-    """Synthetic sphere obstacles [1,O,4]."""
-    rng = np.random.default_rng(seed)
-    sph = np.zeros((1, num, 4))
-    sph[0, :, :3] = rng.uniform([0.2, -0.5, 0.2], [1.0, 0.5, 1.0], size=(num, 3))
-    sph[0, :, 3] = rng.uniform(0.1, 0.2, size=num)
-    return sph
+from stoch_gpmp_amd.workloads import PANDA, PLANAR, panda_spheres  # noqa: E402,F401
 
 
 def oracle_planar_cost(c, T, goals, nppg, S, grid, cell_size, c_offset, dtype):

@@ -1,0 +1,190 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/sgpmp.h declares, the
+ctypes structs match the C layout, host logic (sharding, descriptors, rasteriser) behaves, and the
+product fails loudly without a GPU instead of falling back.  No kernel is launched here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sgpmp.h")
+CPU = {"device": torch.device("cpu"), "dtype": torch.float64}
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sgpmp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from stoch_gpmp_amd import _lib
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"libsgpmp.so does not export {name}"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in stoch_gpmp_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.sgpmp_abi_version() == 1
+
+
+def test_ctypes_structs_match_the_c_layout(tmp_path):
+    from stoch_gpmp_amd import _lib
+    prog = tmp_path / "layout.c"
+    prog.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "sgpmp.h"
+int main(void) {
+  printf("%zu %zu %zu\n", sizeof(sgpmp_dims), sizeof(sgpmp_cost_desc), sizeof(sgpmp_joint));
+  printf("%zu %zu %zu %zu %zu %zu\n", offsetof(sgpmp_cost_desc, sigma), offsetof(sgpmp_cost_desc, data),
+         offsetof(sgpmp_cost_desc, dim0), offsetof(sgpmp_cost_desc, p0),
+         offsetof(sgpmp_cost_desc, num_interpolate), offsetof(sgpmp_cost_desc, alpha));
+  printf("%zu %zu\n", offsetof(sgpmp_joint, xyz), offsetof(sgpmp_joint, revolute));
+  return 0;
+}''')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    vals = [int(v) for v in out]
+    assert vals[:3] == [ctypes.sizeof(_lib.Dims), ctypes.sizeof(_lib.CostDesc), ctypes.sizeof(_lib.Joint)]
+    cd = _lib.CostDesc
+    assert vals[3:9] == [cd.sigma.offset, cd.data.offset, cd.dim0.offset, cd.p0.offset,
+                         cd.num_interpolate.offset, cd.alpha.offset]
+    assert vals[9:] == [_lib.Joint.xyz.offset, _lib.Joint.revolute.offset]
+
+
+def test_product_fails_loudly_without_a_gpu():
+    """No CPU fallback: constructing anything that would compute raises on a CPU device."""
+    from stoch_gpmp_amd.engine import Engine
+    from stoch_gpmp_amd.planner import StochGPMP
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Engine(2, 8, 1, 1, tensor_args=CPU)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        StochGPMP(2, 4, 8, 1, dt=0.1, n_dof=2, start_state=torch.zeros(4),
+                  multi_goal_states=torch.ones(1, 4), sigma_start_init=1., sigma_start_sample=1.,
+                  sigma_goal_init=1., sigma_goal_sample=1., sigma_gp_init=1., sigma_gp_sample=1.,
+                  tensor_args=CPU)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            Engine(2, 8, 1, 1, tensor_args={"device": torch.device("cuda:0"), "dtype": torch.float32})
+
+
+def test_no_product_module_imports_the_oracle():
+    pkg = os.path.join(ROOT, "stoch_gpmp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "/root/reference" not in text, f
+
+
+def test_shard_range_partitions_particles():
+    from stoch_gpmp_amd.dist import shard_range
+    for P in (1, 7, 8, 1024, 4096, 8192, 1000):
+        for W in (1, 2, 3, 4, 8):
+            rs = [shard_range(P, r, W) for r in range(W)]
+            assert rs[0][0] == 0 and rs[-1][1] == P
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(W - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(8192, 3, 8) == (3072, 4096)
+
+
+def test_cost_descriptors_follow_the_reference_constructors():
+    from stoch_gpmp_amd import _lib as L
+    from stoch_gpmp_amd.costs.cost_functions import (CostCollision, CostComposite, CostGoal, CostGP,
+                                                     CostGPTrajectory, CostGoalPrior)
+    from stoch_gpmp_amd.costs.fields import (EESE3DistanceField, LinkDistanceField,
+                                             LinkSelfDistanceField)
+    from stoch_gpmp_amd.envs.obst_map import ObstacleMap
+    from stoch_gpmp_amd.robots.panda import DifferentiableFrankaPanda
+    n, T = 7, 16
+    start = torch.arange(14, dtype=torch.float64)
+    goals = torch.ones(3, 14, dtype=torch.float64)
+    gp = CostGP(n, T, start, 0.05, dict(sigma_start=1e-4, sigma_gp=7e-4), CPU)
+    d = gp.descriptors()[0]
+    assert d["kind"] == L.COST_GP and d["flags"] == L.FLAG_GP_START and d["sigma"] == 7e-4
+    assert d["sigma2"] == 1e-4 and d["host_data"] == list(map(float, range(14)))
+    assert CostGPTrajectory(n, T, start, 0.05, dict(sigma_gp=0.1), CPU).descriptors()[0]["flags"] == 0
+    gl = CostGoalPrior(n, T, multi_goal_states=goals, num_particles_per_goal=5, num_samples=8,
+                       sigma_goal_prior=20., tensor_args=CPU).descriptors()[0]
+    assert gl["kind"] == L.COST_GOAL_PRIOR and gl["dim0"] == 3 and gl["dim1"] == 40
+    sp = CostCollision(n, T, field=LinkDistanceField(field_type='sdf', clamp_sdf=True, num_interpolate=2,
+                                                     tensor_args=CPU), sigma_coll=0.01).descriptors()[0]
+    assert sp["kind"] == L.COST_SPHERES and sp["flags"] == (L.FIELD_SDF | L.FLAG_SDF_CLAMP)
+    assert sp["interp_lo"] == 5 and sp["interp_hi"] == 7
+    np.testing.assert_allclose(sp["alpha"], [np.float32(1 / 3), np.float32(2 / 3)], rtol=1e-7)
+    se = CostCollision(n, T, field=LinkSelfDistanceField(margin=0.03, tensor_args=CPU),
+                       sigma_coll=0.01).descriptors()[0]
+    assert se["kind"] == L.COST_SELF and se["sigma2"] == 0.03
+    assert CostCollision(n, T, field=None, sigma_coll=1.).descriptors() == []
+    om = ObstacleMap([20, 20], 0.1, tensor_args=CPU)
+    gr = CostCollision(2, T, field=om, sigma_coll=1e-5).descriptors()[0]
+    assert gr["kind"] == L.COST_GRID and (gr["dim0"], gr["dim1"]) == (200, 200)
+    assert (gr["p0"], gr["p1"], gr["p2"]) == (0.1, 100.0, 100.0)
+    fk = DifferentiableFrankaPanda(gripper=False, tensor_args=CPU)
+    cc = CostComposite(n, T, [gp, CostCollision(n, T, field=LinkSelfDistanceField(tensor_args=CPU),
+                                                sigma_coll=0.01)],
+                       FK=fk.compute_forward_kinematics_all_links, tensor_args=CPU)
+    assert len(cc.descriptors()) == 2 and len(cc.chain) == 10 and not cc.needs_spheres()
+    with pytest.raises(TypeError):
+        CostComposite(n, T, [gp], FK=lambda q: q)       # arbitrary FK callables cannot run in HIP
+    with pytest.raises(NotImplementedError):
+        gp.get_linear_system(None)                      # GPMP-only, out of scope
+    with pytest.raises(NotImplementedError):
+        CostGoal(n, T)
+    with pytest.raises(NotImplementedError):
+        EESE3DistanceField(None)
+
+
+def test_rasteriser_and_synthetic_scene(golden):
+    from stoch_gpmp_amd.envs.obst_map import (ObstacleCircle, ObstacleMap, ObstacleRectangle,
+                                              synthetic_obstacle_map)
+    om = ObstacleMap([20, 20], 0.1, tensor_args=CPU)
+    assert om.map.shape == (200, 200) and (om.origin_xi, om.origin_yi) == (100, 100)
+    ObstacleRectangle(1.0, -2.0, 2, 2)._add_to_map(om)
+    assert om.map.sum() == 400 and om.map[80, 110] == 1 and om.map[69, 110] == 0 and om.map[70, 100] == 1
+    ObstacleCircle(-3.0, 3.0, 1.0)._add_to_map(om)
+    ys, xs = np.nonzero(om.map[120:141, 60:81])
+    assert abs((om.map.sum() - 400) - np.pi * 100) < 15 and om.map[130, 70] == 1 and om.map[130, 59] == 0
+    a = synthetic_obstacle_map(seed=3, tensor_args=CPU)
+    b = synthetic_obstacle_map(seed=3, tensor_args=CPU)
+    c = synthetic_obstacle_map(seed=4, tensor_args=CPU)
+    assert np.array_equal(a.map, b.map) and not np.array_equal(a.map, c.map)
+    assert a.map.max() == 1 and 2000 < a.map.sum() < 7000           # 15 non-overlapping obstacles
+    g = golden("g2_planar_e2e.npz")
+    ref = ObstacleMap.from_grid(g["grid"], float(g["cell_size"]), tensor_args=CPU)
+    assert np.array_equal(ref.map, g["grid"].astype(np.float64))
+    assert [ref.origin_xi, ref.origin_yi] == list(g["c_offset"])
+    assert ref.map_torch.shape == (200, 200)
+
+
+def test_factor_mirrors_expose_the_reference_quantities():
+    from oracle import ref_equiv as R
+    from stoch_gpmp_amd.costs.factors.field_factor import FieldFactor
+    from stoch_gpmp_amd.costs.factors.gp_factor import GPFactor
+    from stoch_gpmp_amd.costs.factors.unary_factor import UnaryFactor
+    gp = GPFactor(3, 0.7, 0.1, 5, CPU)
+    assert torch.equal(gp.phi, R.phi_matrix(3, 0.1, torch.float64))
+    assert torch.equal(gp.Q_inv[0], R.q_inv_matrix(3, 0.1, 0.7, torch.float64))
+    assert gp.Q_inv.shape == (5, 6, 6)
+    uf = UnaryFactor(6, 0.05, torch.ones(6, dtype=torch.float64), CPU)
+    assert torch.equal(uf.K, R.unary_K(6, 0.05, torch.float64))
+    assert torch.equal(uf.get_error(torch.zeros(2, 1, 6, dtype=torch.float64)),
+                       torch.ones(2, 1, 6, dtype=torch.float64))
+    assert FieldFactor(2, 1e-5, [1, 64]).K == 1. / (1e-5 ** 2) and FieldFactor(2, 1., [1, 64]).length == 63
+
+
+def test_bench_and_entry_points_exist():
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    assert callable(ge.build) and callable(ge.smoke)
+    assert os.path.exists(os.path.join(ROOT, "bench.py"))

@@ -1,0 +1,341 @@
+"""Kernel-level parity of the HIP path (through the C ABI) against the CPU oracle and the
+reference-generated golden fixtures.  Needs the MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_equiv as R
+from oracle.fk import fk_all_links, PANDA_CHAIN
+from tests import scenarios as SC
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device("cuda:0")
+F64 = {"device": DEV, "dtype": torch.float64}
+F32 = {"device": DEV, "dtype": torch.float32}
+
+
+def TA(dtype):
+    return {"device": DEV, "dtype": dtype}
+
+
+def close(a, b, rtol, atol=0.0):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def engine(n, T, P, S, dtype=torch.float64, **kw):
+    from stoch_gpmp_amd.engine import Engine
+    return Engine(n, T, P, S, tensor_args=TA(dtype), **kw)
+
+
+def oracle_prior(n, T, dt, ss, sg, sgoal, modes=1):
+    d = 2 * n
+    start = torch.zeros(d, dtype=torch.float64)
+    goals = None if sgoal is None else torch.zeros(modes, d, dtype=torch.float64)
+    return R.TrajPrior(T, n, dt, R.unary_K(d, ss, torch.float64),
+                       R.q_inv_matrix(n, dt, sg, torch.float64), start,
+                       K_g=None if sgoal is None else R.unary_K(d, sgoal, torch.float64),
+                       goals=goals, dtype=torch.float64)
+
+
+PRIOR_CASES = [  # n, T, dt, sigma_start, sigma_gp, sigma_goal
+    (2, 8, 0.02, 1e-3, 3., 1e-3),
+    (2, 64, 0.02, 1e-3, 20., 1e-3),
+    (2, 128, 0.02, 1e-3, 3., 1e-3),
+    (3, 6, 0.1, 0.05, 0.7, None),
+    (7, 16, 0.05, 1e-3, 0.1, 0.07),
+    (7, 64, 0.05, 1e-4, 0.8, 0.1),
+    (1, 5, 0.3, 0.5, 1.5, 2.0),
+    (8, 4, 0.1, 0.1, 0.5, 0.3),
+]
+
+
+# ------------------------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("n,T,dt,ss,sg,sgoal", PRIOR_CASES)
+def test_prior_blocks_and_factor_match_oracle(n, T, dt, ss, sg, sgoal):
+    from stoch_gpmp_amd import _lib as L
+    d = 2 * n
+    eng = engine(n, T, 1, 1)
+    eng.set_prior(L.PRIOR_SAMPLE, dt, ss, sg, sgoal)
+    blocks, G, H = eng.get_prior(L.PRIOR_SAMPLE)
+    pr = oracle_prior(n, T, dt, ss, sg, sgoal)
+    Si = pr.Sigma_inv
+    close(blocks[0], Si[:d, :d], 1e-13)
+    close(blocks[3], Si[d:2 * d, :d], 1e-13)
+    close(blocks[2], Si[-d:, -d:], 1e-13)
+    if T > 2:
+        close(blocks[1], Si[d:2 * d, d:2 * d], 1e-13)
+    # scan coefficients reproduce torch's scale_tril: apply both to the same noise
+    g = torch.Generator().manual_seed(0)
+    eps = torch.randn(3, 1, T * d, generator=g, dtype=torch.float64)
+    y_ref = torch.matmul(pr.scale_tril()[0], eps.squeeze(1).t()).t()            # [3, M]
+    y = torch.zeros(3, d, dtype=torch.float64)
+    out = []
+    for t in range(T):
+        y = eps[:, 0, t * d:(t + 1) * d] @ G[t].t() + y @ H[t].t()
+        out.append(y)
+    y_scan = torch.cat(out, dim=1)
+    close(y_scan, y_ref, 1e-7, atol=1e-9 * float(y_ref.abs().max()))
+
+
+def test_prior_not_positive_definite_raises_value_error():
+    from stoch_gpmp_amd import _lib as L
+    eng = engine(2, 8, 1, 1)
+    bad = torch.tensor([[1.0, 2.0], [2.0, 1.0]], dtype=torch.float64)      # indefinite Q_c^-1
+    with pytest.raises(ValueError):
+        eng.set_prior(L.PRIOR_SAMPLE, 0.1, 1.0, None, 1.0, Q_c_inv=bad)
+
+
+# ------------------------------------------------------------------------------------------- K2
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-8), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("n,T,dt,ss,sg,sgoal", PRIOR_CASES[:6])
+def test_sampler_external_eps_matches_oracle(n, T, dt, ss, sg, sgoal, dtype, rtol):
+    from stoch_gpmp_amd import _lib as L
+    d, modes, S = 2 * n, 3, 5
+    g = torch.Generator().manual_seed(1)
+    means = torch.randn(modes, T, d, generator=g, dtype=torch.float64)
+    pr = R.TrajPrior(T, n, dt, R.unary_K(d, ss, torch.float64), R.q_inv_matrix(n, dt, sg, torch.float64),
+                     torch.zeros(d, dtype=torch.float64), means=means,
+                     K_g=None if sgoal is None else R.unary_K(d, sgoal, torch.float64),
+                     goals=None if sgoal is None else torch.zeros(modes, d, dtype=torch.float64))
+    eps = torch.randn(S, modes + 2, T * d, generator=g, dtype=torch.float64)
+    ref = pr.sample(S, eps=eps[:, 1:1 + modes].contiguous())                # [modes,S,T,d]
+    eng = engine(n, T, modes, S, dtype)
+    eng.set_prior(L.PRIOR_SAMPLE, dt, ss, sg, sgoal)
+    out = eng.sample(L.PRIOR_SAMPLE, 0, 0, means.to(**TA(dtype)), S, eps=eps.to(**TA(dtype)),
+                     eps_mode_offset=1)
+    scale = float((ref - means.unsqueeze(1)).abs().max())
+    close(out, ref, rtol, atol=rtol * scale)
+
+
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 1e-4)])
+def test_dense_sampler_equals_isotropic_sampler(dtype, rtol):
+    """A user-supplied full Q_c_inv takes the d x d block path; with Q_c_inv = I/sigma^2 it must
+    reproduce the per-DOF path."""
+    from stoch_gpmp_amd import _lib as L
+    n, T, dt, ss, sg, sgoal, modes, S = 3, 12, 0.05, 0.01, 0.3, 0.05, 2, 7
+    g = torch.Generator().manual_seed(2)
+    means = torch.randn(modes, T, 2 * n, generator=g, dtype=torch.float64).to(**TA(dtype))
+    eps = torch.randn(S, modes, T * 2 * n, generator=g, dtype=torch.float64).to(**TA(dtype))
+    a = engine(n, T, modes, S, dtype)
+    a.set_prior(L.PRIOR_SAMPLE, dt, ss, sg, sgoal)
+    b = engine(n, T, modes, S, dtype)
+    b.set_prior(L.PRIOR_SAMPLE, dt, ss, None, sgoal, Q_c_inv=torch.eye(n, dtype=torch.float64) / sg ** 2)
+    xa = a.sample(L.PRIOR_SAMPLE, 0, 0, means, S, eps=eps)
+    xb = b.sample(L.PRIOR_SAMPLE, 0, 0, means, S, eps=eps)
+    close(xb, xa, rtol, atol=rtol)
+    # and with native noise both paths consume the same Philox stream
+    ya = a.sample(L.PRIOR_SAMPLE, 7, 3, means, S)
+    yb = b.sample(L.PRIOR_SAMPLE, 7, 3, means, S)
+    close(yb, ya, rtol, atol=rtol)
+
+
+def test_dense_sampler_with_full_Qc_matches_oracle():
+    from stoch_gpmp_amd import _lib as L
+    n, T, dt, ss, sgoal, modes, S = 3, 10, 0.1, 0.05, 0.2, 2, 4
+    d = 2 * n
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(n, n, generator=g, dtype=torch.float64)
+    Qc_inv = A @ A.t() + n * torch.eye(n, dtype=torch.float64)
+    means = torch.randn(modes, T, d, generator=g, dtype=torch.float64)
+    eps = torch.randn(S, modes, T * d, generator=g, dtype=torch.float64)
+    pr = R.TrajPrior(T, n, dt, R.unary_K(d, ss, torch.float64),
+                     R.q_inv_matrix(n, dt, None, torch.float64, Q_c_inv=Qc_inv),
+                     torch.zeros(d, dtype=torch.float64), means=means,
+                     K_g=R.unary_K(d, sgoal, torch.float64),
+                     goals=torch.zeros(modes, d, dtype=torch.float64))
+    ref = pr.sample(S, eps=eps)
+    eng = engine(n, T, modes, S)
+    eng.set_prior(L.PRIOR_SAMPLE, dt, ss, None, sgoal, Q_c_inv=Qc_inv)
+    out = eng.sample(L.PRIOR_SAMPLE, 0, 0, means.to(**F64), S, eps=eps.to(**F64))
+    close(out, ref, 1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_native_noise_statistics_and_sharding_invariance(dtype):
+    """Philox path: sample mean ~ mu and covariance ~ (Sigma^-1)^-1; particle p's draws do not
+    depend on which shard holds it."""
+    from stoch_gpmp_amd import _lib as L
+    n, T, dt, ss, sg, sgoal = 2, 6, 0.1, 0.3, 1.0, 0.4
+    d, M, S = 2 * n, 6 * 4, 60000
+    pr = oracle_prior(n, T, dt, ss, sg, sgoal)
+    cov = torch.linalg.inv(pr.Sigma_inv)
+    eng = engine(n, T, 4, S, dtype)
+    eng.set_prior(L.PRIOR_SAMPLE, dt, ss, sg, sgoal)
+    means = torch.zeros(4, T, d, **TA(dtype))
+    means[1] += 2.0
+    x = eng.sample(L.PRIOR_SAMPLE, 1234, 5, means, S).double().cpu().reshape(4, S, M)
+    for p in range(4):
+        emp_mean = x[p].mean(0)
+        emp_cov = torch.cov(x[p].t())
+        sd = cov.diag().sqrt()
+        assert float(((emp_mean - means[p].cpu().double().reshape(-1)) / sd).abs().max()) < 0.03
+        assert float(((emp_cov - cov) / torch.outer(sd, sd)).abs().max()) < 0.03
+    # different particles / draws / seeds are different streams
+    assert float((x[0] - x[2]).abs().max()) > 0.1
+    # shard = particles [2,4) only, addressed by their global index
+    xs = eng.sample(L.PRIOR_SAMPLE, 1234, 5, means[2:].contiguous(), S, mode_offset=2)
+    assert torch.equal(xs.cpu().double().reshape(2, S, M), x[2:])
+
+
+# ------------------------------------------------------------------------------------------- K3
+@pytest.mark.parametrize("tag,dtype,rtol", [("f64", torch.float64, 1e-11), ("f32", torch.float32, 3e-6)])
+def test_planar_cost_terms_match_reference_fixture(golden, tag, dtype, rtol):
+    from stoch_gpmp_amd.costs.cost_functions import CostCollision, CostComposite, CostGP, CostGoalPrior
+    from stoch_gpmp_amd.envs.obst_map import ObstacleMap
+    z, g = golden("g3_cost_terms.npz"), golden("g2_planar_e2e.npz")
+    ta = TA(dtype)
+    trajs = torch.as_tensor(z[tag + "/trajs"]).to(**ta)
+    n, T, dt, G, nppg, S = 2, 5, 0.02, 2, 1, 3
+    start = torch.tensor([-9., -9., 0., 0.], **ta)
+    goals = torch.tensor([[9., 6., 0., 0.], [9., -3., 0., 0.]], **ta)
+    om = ObstacleMap.from_grid(g["grid"], float(g["cell_size"]), tensor_args=ta)
+    cgp = CostGP(n, T, start, dt, dict(sigma_start=1e-3, sigma_gp=0.1), ta)
+    cgl = CostGoalPrior(n, T, multi_goal_states=goals, num_particles_per_goal=nppg, num_samples=S,
+                        sigma_goal_prior=1e-3, tensor_args=ta)
+    cco = CostCollision(n, T, field=om, sigma_coll=1e-5, tensor_args=ta)
+    close(cgp.eval(trajs), z[tag + "/cost_gp"], rtol)
+    close(cgl.eval(trajs), z[tag + "/cost_goal_prior"], rtol)
+    close(cco.eval(trajs), z[tag + "/cost_collision"], rtol)
+    close(om.compute_cost(trajs[:, :, :2].reshape(-1, 2)), z[tag + "/grid_vals"], 0)
+    cc = CostComposite(n, T, [cgp, cgl, cco], tensor_args=ta)
+    close(cc.eval(trajs.reshape(G * nppg, S, T, 2 * n)), z[tag + "/composite"], rtol)
+
+
+def test_grid_lookup_edges_match_oracle():
+    """floor on negatives, clamping far outside, exact cell boundaries, both dtypes."""
+    from stoch_gpmp_amd.envs.obst_map import ObstacleMap
+    rng = np.random.default_rng(0)
+    grid = rng.integers(0, 3, size=(40, 40)).astype(np.float64)
+    for dtype in (torch.float64, torch.float32):
+        ta = TA(dtype)
+        om = ObstacleMap.from_grid(grid, 0.25, tensor_args=ta)
+        pts = torch.cat([
+            torch.as_tensor(rng.uniform(-7, 7, size=(4000, 2))),
+            torch.as_tensor(rng.integers(-24, 24, size=(500, 2)) * 0.25),      # on boundaries
+            torch.tensor([[-5.0, 4.999999], [1e6, -1e6], [-0.0, 0.0], [4.75, 4.75], [5.0, -5.0]]),
+        ]).to(dtype)
+        ref = R.grid_lookup(pts, torch.as_tensor(grid).to(dtype), 0.25,
+                            torch.tensor([om.origin_xi, om.origin_yi], dtype=dtype))
+        close(om.compute_cost(pts.to(DEV)), ref, 0)
+
+
+@pytest.mark.parametrize("tag,dtype,rtol", [("f64", torch.float64, 1e-11), ("f32", torch.float32, 2e-5)])
+def test_link_fields_on_frames_match_reference_fixture(golden, tag, dtype, rtol):
+    from stoch_gpmp_amd.costs.fields import LinkDistanceField, LinkSelfDistanceField
+    z = golden("g4_panda_fields.npz")
+    ta = TA(dtype)
+    fr = torch.as_tensor(z["frames"]).to(**ta)
+    sp = torch.as_tensor(z["spheres"]).to(**ta)
+    cases = [("rbf", dict(field_type='rbf')), ("sdf", dict(field_type='sdf')),
+             ("sdf_clamp", dict(field_type='sdf', clamp_sdf=True)),
+             ("occ", dict(field_type='occupancy')),
+             ("rbf_interp2", dict(field_type='rbf', num_interpolate=2)),
+             ("sdf_interp3", dict(field_type='sdf', num_interpolate=3, link_interpolate_range=[2, 6]))]
+    for name, kw in cases:
+        f = LinkDistanceField(tensor_args=ta, **kw)
+        close(f.compute_cost(fr, obstacle_spheres=sp), z[f"{tag}/{name}"], rtol, atol=rtol)
+        close(f.compute_cost(fr, obstacle_spheres=sp[0]), z[f"{tag}/{name}_2dsph"], rtol, atol=rtol)
+    close(LinkSelfDistanceField(margin=0.03, tensor_args=ta).compute_cost(fr), z[f"{tag}/self"], rtol)
+    close(LinkSelfDistanceField(margin=0.2, num_interpolate=2, tensor_args=ta).compute_cost(fr),
+          z[f"{tag}/self_m2_interp2"], rtol)
+    assert LinkDistanceField(tensor_args=ta).compute_cost(fr) == 0          # fields.py:64-65
+
+
+@pytest.mark.parametrize("tag,dtype,rtol", [("f64", torch.float64, 1e-10), ("f32", torch.float32, 2e-4)])
+def test_panda_fk_and_composite_match_reference_fixture(golden, tag, dtype, rtol):
+    from stoch_gpmp_amd.costs.cost_functions import CostCollision, CostComposite, CostGP, CostGoalPrior
+    from stoch_gpmp_amd.costs.fields import LinkDistanceField, LinkSelfDistanceField
+    from stoch_gpmp_amd.robots.panda import DifferentiableFrankaPanda
+    z = golden("g4_panda_fields.npz")
+    ta = TA(dtype)
+    c = SC.PANDA
+    n, T, nppg, S = 7, 8, 2, 4
+    trajs = torch.as_tensor(z[f"panda/{tag}/trajs"]).to(**ta)
+    sph = torch.as_tensor(z["panda/spheres"]).to(**ta)
+    fk = DifferentiableFrankaPanda(gripper=False, device=DEV)
+    q = trajs.reshape(-1, 2 * n)[:, :n].contiguous()
+    close(fk.compute_forward_kinematics_all_links(q), z[f"panda/{tag}/fk_oracle"],
+          1e-12 if tag == "f64" else 1e-5, atol=1e-12 if tag == "f64" else 2e-6)
+    start = torch.tensor(c["start_q"] + [0.] * n, **ta)
+    goals = torch.tensor([c["goal_q"] + [0.] * n], **ta)
+    FK = fk.compute_forward_kinematics_all_links
+    terms = dict(
+        gp=CostGP(n, T, start, c["dt"], dict(sigma_start=1e-4, sigma_gp=7e-4), ta),
+        goal_prior=CostGoalPrior(n, T, multi_goal_states=goals, num_particles_per_goal=nppg,
+                                 num_samples=S, sigma_goal_prior=20., tensor_args=ta),
+        self=CostCollision(n, T, field=LinkSelfDistanceField(margin=0.03, tensor_args=ta), sigma_coll=0.01),
+        coll_rbf=CostCollision(n, T, field=LinkDistanceField(tensor_args=ta), sigma_coll=0.01),
+        coll_sdf=CostCollision(n, T, field=LinkDistanceField(field_type='sdf', tensor_args=ta), sigma_coll=0.01),
+        coll_occ=CostCollision(n, T, field=LinkDistanceField(field_type='occupancy', tensor_args=ta),
+                               sigma_coll=0.01),
+    )
+    for name, term in terms.items():
+        cc = CostComposite(n, T, [term], FK=FK, tensor_args=ta)
+        ref = z[f"panda/{tag}/{name}"]
+        close(cc.eval(trajs, obstacle_spheres=sph), ref, rtol, atol=rtol * float(np.abs(ref).max()))
+    cc = CostComposite(n, T, [terms["gp"], terms["goal_prior"], terms["self"], terms["coll_rbf"]],
+                       FK=FK, tensor_args=ta)
+    close(cc.eval(trajs, obstacle_spheres=sph), z[f"panda/{tag}/composite"], rtol)
+    with pytest.raises(AttributeError):                  # the reference fails without spheres too
+        cc.eval(trajs)
+
+
+@pytest.mark.parametrize("T", [64, 65, 128, 130])
+def test_cost_sweep_multi_pass_trajectories_match_oracle(T):
+    """T > 64 takes several 64-waypoint passes per wave with a carried neighbour waypoint."""
+    from tests.hip_builders import hip_planar_cost
+    from stoch_gpmp_amd.envs.obst_map import synthetic_obstacle_map
+    G, nppg, S = 3, 2, 5
+    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.]]
+    om = synthetic_obstacle_map(seed=1, tensor_args=F64)
+    g = torch.Generator().manual_seed(T)
+    trajs = (torch.rand(G * nppg, S, T, 4, generator=g, dtype=torch.float64) * 20 - 10)
+    ref = SC.oracle_planar_cost(SC.PLANAR, T, goals, nppg, S, om.map, om.cell_size,
+                                [om.origin_xi, om.origin_yi], torch.float64).eval(trajs)
+    out = hip_planar_cost(SC.PLANAR, T, goals, nppg, S, om, F64).eval(trajs.to(DEV))
+    close(out, ref, 1e-11)
+
+
+# ------------------------------------------------------------------------------------------- K4/K5
+def test_update_and_is_term_match_reference_fixture(golden):
+    from tests.hip_builders import hip_planar_planner
+    from stoch_gpmp_amd.envs.obst_map import ObstacleMap
+    z, g = golden("g5_update_is.npz"), golden("g2_planar_e2e.npz")
+    T, nppg, S = [int(v) for v in z["dims"]]
+    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.]]
+    om = ObstacleMap.from_grid(g["grid"], float(g["cell_size"]), tensor_args=F64)
+    init = torch.as_tensor(z["means_in"]).reshape(2, nppg, T, 4).to(**F64)
+    pl = hip_planar_planner(SC.PLANAR, T, goals, nppg, S, om, F64, initial_particle_means=init,
+                            temperature=3.0, seed=5)
+    samples = torch.as_tensor(z["samples"]).to(**F64)
+    pl.state_samples.copy_(samples)
+    close(pl.cost.eval(pl.state_samples).reshape(pl.num_particles, S), z["costs_no_is"], 1e-11)
+    close(pl._get_costs(), z["costs_with_is"], 1e-9)
+    for tag in ("spread", "neartie", "huge"):
+        pl.particle_means.copy_(torch.as_tensor(z["means_in"]).to(**F64))
+        grad = pl._update_distribution(torch.as_tensor(z[f"{tag}/costs"]).to(**F64), samples)
+        close(pl._weights.reshape(pl.num_particles, S), z[f"{tag}/weights"], 1e-11, atol=1e-300)
+        close(grad, z[f"{tag}/grad"], 1e-10, atol=1e-14)
+        close(pl.particle_means, z[f"{tag}/means_out"], 1e-12)
+        close(pl._means_prev, z["means_in"], 0)
+
+
+def test_update_with_fp32_costs_tensor():
+    from stoch_gpmp_amd import _lib as L
+    n, T, P, S = 2, 6, 3, 9
+    eng = engine(n, T, P, S, torch.float32)
+    g = torch.Generator().manual_seed(4)
+    means = torch.randn(P, T, 2 * n, generator=g)
+    samples = means.unsqueeze(1) + 0.1 * torch.randn(P, S, T, 2 * n, generator=g)
+    costs = torch.rand(P, S, generator=g) * 4
+    w = torch.softmax(-costs.double() / 0.7, dim=1)
+    grad = (w.view(P, S, 1, 1) * (samples.double() - means.double().unsqueeze(1))).sum(1)
+    m_dev, wts, gr = means.to(DEV).clone(), torch.empty(P, S, device=DEV), torch.empty(P, T, 2 * n, device=DEV)
+    eng.update(costs.to(DEV), samples.to(DEV).contiguous(), m_dev, 0.7, 0.25, weights=wts, grad=gr)
+    close(wts, w, 1e-6)
+    close(gr, grad, 1e-5, atol=1e-7)
+    close(m_dev, means.double() + 0.25 * grad, 1e-6, atol=1e-7)
