@@ -267,7 +267,8 @@ class StochGPMP:
                            dtype=ta['dtype']).to(ta['device'])
 
     def _reduce_stats(self, slot):
-        if self.world_size > 1:
+        # (a shard run stand-alone -- world_size > 1 without a process group -- has no peers to reduce with)
+        if self.world_size > 1 and torch.distributed.is_initialized():
             self._pending_reduce.append(allreduce_stats_async(self._stats[slot], self.process_group))
             if len(self._pending_reduce) > 1:           # never gate the next iteration's kernels
                 self._pending_reduce.pop(0).wait()
