@@ -1,12 +1,14 @@
 // Host side of libsgpmp.so: the C ABI declared in include/sgpmp.h.
 // Context bookkeeping, descriptor compilation and kernel sequencing only -- no arithmetic on
 // trajectory data happens on the host.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
+#include "chain_code_generated.h"
 #include "sgpmp_internal.h"
 
 static thread_local std::string g_err;
@@ -248,6 +250,90 @@ static void rpy_to_R(const double rpy[3], double R[9]) {
     R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
 }
 
+// Link positions of the chain for joint vector q, in double, on the host (setup-time analysis only).
+static void host_fk_points(const ChainDev& ch, const double* q, double (*pos)[3]) {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    pos[0][0] = pos[0][1] = pos[0][2] = 0.;
+    for (int j = 0; j < ch.n_joints; ++j) {
+        const JointDev& J = ch.j[j];
+        double Rn[9];
+        for (int r = 0; r < 3; ++r) p[r] += R[r * 3] * J.t[0] + R[r * 3 + 1] * J.t[1] + R[r * 3 + 2] * J.t[2];
+        for (int r = 0; r < 3; ++r)
+            for (int cc = 0; cc < 3; ++cc)
+                Rn[r * 3 + cc] = R[r * 3] * J.R[cc] + R[r * 3 + 1] * J.R[3 + cc] + R[r * 3 + 2] * J.R[6 + cc];
+        if (J.revolute) {
+            const double s = std::sin(q[J.qidx]), co = std::cos(q[J.qidx]);
+            for (int r = 0; r < 3; ++r) {
+                const double a = Rn[r * 3], b = Rn[r * 3 + 1];
+                Rn[r * 3] = a * co + b * s;
+                Rn[r * 3 + 1] = b * co - a * s;
+            }
+        }
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+        for (int i = 0; i < 3; ++i) pos[j + 1][i] = p[i];
+    }
+}
+
+// Chain analysis for the register-resident FK path of the cost sweep (see FkPlan).  The link
+// geometry is probed at pseudo-random joint vectors: links whose frames coincide for every probe
+// are merged (multiplicity), and pairs whose distance never changes are rigid and become constants.
+// Both are identities of the sums in reference fields.py:79,86,124, not approximations.
+static void analyse_chain(ChainDev& ch) {
+    FkPlan& pl = ch.plan;
+    std::memset(&pl, 0, sizeof(pl));
+    const int L = ch.n_links, ML = SGPMP_MAX_LINKS, K = 24;
+    int nrev = 0;
+    bool rev_first = true;
+    for (int j = 0; j < ch.n_joints; ++j) {
+        if (ch.j[j].revolute) { if (ch.j[j].qidx != j) rev_first = false; ++nrev; }
+    }
+    pl.fast = rev_first ? 1 : 0;
+    std::vector<double> d2min((size_t)L * L, 1e300), d2max((size_t)L * L, 0.), d2sum((size_t)L * L, 0.);
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    for (int k = 0; k < K; ++k) {
+        double q[SGPMP_MAX_JOINTS], pos[SGPMP_MAX_LINKS][3];
+        for (int i = 0; i < nrev; ++i) {
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            q[i] = ((double)(lcg >> 11) / 9007199254740992.0 * 2. - 1.) * 3.0;
+        }
+        host_fk_points(ch, q, pos);
+        for (int i = 0; i < L; ++i)
+            for (int j = 0; j < i; ++j) {
+                double d2 = 0.;
+                for (int a = 0; a < 3; ++a) d2 += (pos[i][a] - pos[j][a]) * (pos[i][a] - pos[j][a]);
+                const size_t e = (size_t)i * L + j;
+                d2min[e] = std::min(d2min[e], d2); d2max[e] = std::max(d2max[e], d2); d2sum[e] += d2;
+            }
+    }
+    // representatives: the lowest-index link of each coincident cluster
+    int rep[SGPMP_MAX_LINKS];
+    for (int i = 0; i < L; ++i) {
+        rep[i] = i;
+        for (int j = 0; j < i; ++j)
+            if (d2max[(size_t)i * L + j] < 1e-20) { rep[i] = rep[j]; break; }
+    }
+    for (int i = 0; i < L; ++i) pl.mult[rep[i]] += 1.f;
+    for (int i = 0; i < L; ++i) {
+        if (rep[i] == i) ++pl.n_rep;
+        pl.diag += (rep[i] == i) ? (double)pl.mult[i] * pl.mult[i] : 0.;
+    }
+    for (int i = 0; i < L; ++i) {
+        if (rep[i] != i) continue;
+        for (int j = 0; j < i; ++j) {
+            if (rep[j] != j) continue;
+            const size_t e = (size_t)i * L + j;
+            const double w = 2. * pl.mult[i] * pl.mult[j];
+            if (d2max[e] - d2min[e] <= 1e-12 * std::max(1., d2max[e])) {      // rigid pair
+                pl.cpair_w[pl.n_cpairs] = w;
+                pl.cpair_d2[pl.n_cpairs] = d2sum[e] / K;
+                ++pl.n_cpairs;
+            } else {
+                pl.wpair[i * ML + j] = (float)w;
+            }
+        }
+    }
+}
+
 extern "C" int sgpmp_set_fk(sgpmp_ctx* c, const sgpmp_joint* chain, int n_joints) {
     if (!c || !chain) return fail(SGPMP_EINVAL, "sgpmp_set_fk: null argument");
     if (n_joints < 1 || n_joints > SGPMP_MAX_JOINTS)
@@ -265,6 +351,21 @@ extern "C" int sgpmp_set_fk(sgpmp_ctx* c, const sgpmp_joint* chain, int n_joints
     }
     if (q != c->dims.n_dof)
         return fail(SGPMP_EINVAL, "sgpmp_set_fk: number of revolute joints must equal n_dof");
+    for (int j = 0; j < n_joints; ++j) {
+        for (int i = 0; i < 9; ++i) ch.Rf[j][i] = (float)ch.j[j].R[i];
+        for (int i = 0; i < 3; ++i) ch.tf[j][i] = (float)ch.j[j].t[i];
+    }
+    analyse_chain(ch);
+    // does build-time generated code exist for exactly this chain? (chain_code_generated.h)
+    if (n_joints == ChainCode_panda::NJ) {
+        bool same = true;
+        for (int j = 0; j < n_joints && same; ++j) {
+            const double* g = ChainCode_panda::joints[j];
+            for (int i = 0; i < 3; ++i) same = same && chain[j].rpy[i] == g[i] && chain[j].xyz[i] == g[3 + i];
+            same = same && ((chain[j].revolute != 0) == (g[6] != 0.));
+        }
+        if (same) ch.plan.codegen_id = 1;
+    }
     c->h_chain = ch;
     HIPCHK(hipMemcpy(c->d_chain, &ch, sizeof(ch), hipMemcpyHostToDevice));
     c->have_chain = true;
@@ -291,6 +392,11 @@ static int finalize_program(sgpmp_ctx* c) {
         }
         t.n_points = L + extra;
         if (t.n_points > SGPMP_MAX_POINTS) return fail(SGPMP_EINVAL, "too many link points (max 32)");
+        if (t.kind == SGPMP_COST_SELF) {          // q-independent part of the LxL sum (see FkPlan)
+            const FkPlan& pl = c->h_chain.plan;
+            t.selfc = pl.diag;
+            for (int k = 0; k < pl.n_cpairs; ++k) t.selfc += pl.cpair_w[k] * std::exp(t.K2 * pl.cpair_d2[k]);
+        }
     }
     HIPCHK(hipMemcpy(c->d_prog, &p, sizeof(p), hipMemcpyHostToDevice));
     c->prog_dirty = false;
@@ -327,8 +433,8 @@ extern "C" int sgpmp_cost_eval(sgpmp_ctx* c, const void* trajs, int64_t batch, i
     if ((rc = finalize_program(c)) != SGPMP_OK) return rc;
     if ((rc = check_spheres(c, spheres, n_spheres)) != SGPMP_OK) return rc;
     if (batch == 0) return SGPMP_OK;
-    HIPCHK(launch_cost(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, c->d_prog, c->h_prog, c->d_chain,
-                       c->h_chain.n_links, trajs, batch, batch_offset, spheres, n_spheres, is_weights,
+    HIPCHK(launch_cost(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, c->h_prog, c->d_chain,
+                       c->h_chain, trajs, batch, batch_offset, spheres, n_spheres, is_weights,
                        rows_per_particle, c->prior[SGPMP_PRIOR_SAMPLE].dt, costs, costs64,
                        (hipStream_t)stream));
     return SGPMP_OK;
@@ -385,7 +491,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     HIPCHK(launch_sample(D.dtype, D.n_dof, D.traj_len, pr, seed, draw, means, P, D.particle_offset, S, eps,
                          eps_modes, eps_mode_offset, samples, st));
     if (se) HIPCHK(hipEventRecord(se->ev[2], st));
-    HIPCHK(launch_cost(D.dtype, D.n_dof, D.traj_len, c->d_prog, c->h_prog, c->d_chain, c->h_chain.n_links,
+    HIPCHK(launch_cost(D.dtype, D.n_dof, D.traj_len, c->h_prog, c->d_chain, c->h_chain,
                        samples, (long long)P * S, (long long)D.particle_offset * S, spheres, n_spheres,
                        c->d_isw, S, pr.dt, costs, c->d_costs64, st));
     if (se) HIPCHK(hipEventRecord(se->ev[3], st));

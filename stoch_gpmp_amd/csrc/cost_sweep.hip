@@ -15,8 +15,22 @@
 // Mapping: ONE WAVE PER TRAJECTORY, ONE LANE PER WAYPOINT (64 waypoints per pass).  A lane loads its
 // own d-vector (the wave reads one contiguous 64*d*w-byte span), gets x_{t-1} from its neighbour
 // lane, evaluates every per-waypoint term, and the wave reduces the 64 partial costs in fp64.
-// Link positions of the lane's waypoint live in LDS (structure-of-arrays, one column per lane, so
-// accesses are bank-conflict free) because the pair loops index them dynamically.
+//
+// Per-term constants travel in the kernel-argument segment (ProgK, by value) and per-joint constants
+// are read through the constant address space, so both are scalar loads into SGPRs; read through a
+// plain global pointer they become loop-invariant VECTOR loads that pin >200 VGPRs.
+//
+// Link fields have two paths:
+//   register path (FKMODE = number of joints): revolute-first chains without interpolated points.
+//     The link positions stay in registers (every loop over links is unrolled), coincident links
+//     are merged and rigid link pairs folded into a constant by the host analysis (FkPlan), exp is
+//     one v_exp_f32 (exp2 with log2(e) folded into the constant) and sin/cos are native in fp32.
+//   generic path (FKMODE = -1): any chain / interpolated points; link positions of the lane's
+//     waypoint live in LDS (structure-of-arrays, one column per lane: bank-conflict free) because
+//     the loops index them dynamically.
+#include <cstdlib>
+
+#include "chain_code_generated.h"
 #include "sgpmp_internal.h"
 
 template <typename real> struct RealOps;
@@ -27,6 +41,14 @@ template <> struct RealOps<float> {
     static __device__ __forceinline__ float sqrt_(float a) { return sqrtf(a); }
     static __device__ __forceinline__ float floor_(float a) { return floorf(a); }
     static __device__ __forceinline__ void sincos_(float a, float* s, float* c) { sincosf(a, s, c); }
+    // fast forms used by the register path
+    static __device__ __forceinline__ float exp2_(float a) { return __builtin_amdgcn_exp2f(a); }
+    static __device__ __forceinline__ void fsincos_(float a, float* s, float* c) {
+        const float rev = a * 0.15915494309189535f;            // radians -> revolutions
+        *s = __builtin_amdgcn_sinf(rev);
+        *c = __builtin_amdgcn_cosf(rev);
+    }
+    static __device__ __forceinline__ float rcp_(float a) { return __builtin_amdgcn_rcpf(a); }
 };
 template <> struct RealOps<double> {
     static __device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
@@ -35,8 +57,78 @@ template <> struct RealOps<double> {
     static __device__ __forceinline__ double sqrt_(double a) { return sqrt(a); }
     static __device__ __forceinline__ double floor_(double a) { return floor(a); }
     static __device__ __forceinline__ void sincos_(double a, double* s, double* c) { sincos(a, s, c); }
+    static __device__ __forceinline__ double exp2_(double a) { return exp2(a); }
+    static __device__ __forceinline__ void fsincos_(double a, double* s, double* c) { sincos(a, s, c); }
+    static __device__ __forceinline__ double rcp_(double a) { return 1.0 / a; }
 };
 
+#define SGPMP_LOG2E 1.4426950408889634
+
+// ---------------------------------------------------------------------------------- kernarg structs
+template <typename real>
+struct TermK {                    // CostTerm with every constant pre-converted to the compute type
+    int kind, flags;
+    real K, K2, dt, c11, c12, c22, selfc, inv_cell, off_x, off_y;
+    const void* dev_data;
+    int dim0, dim1;
+    long long rows_per_goal;
+    int n_points, n_interp, interp_lo, interp_hi;
+    real alpha[SGPMP_MAX_INTERP];
+};
+
+template <typename real>
+struct ProgK {
+    int n_terms, needs_fk;
+    TermK<real> t[SGPMP_MAX_TERMS];
+};
+
+// Chain constants and FkPlan weights are read through the CONSTANT address space (scalar loads into
+// SGPRs, usable directly as VALU operands).  `opaque` hides the pointer from loop-invariant code
+// motion: hoisted out of the trajectory loop the ~230 scalars would be spilled lane-by-lane into VGPRs.
+#define SGPMP_CONST __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const SGPMP_CONST T* as_const(const T* p) {
+    return (const SGPMP_CONST T*)p;
+}
+template <typename T>
+__device__ __forceinline__ const SGPMP_CONST T* opaque(const SGPMP_CONST T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+typedef const SGPMP_CONST ChainDev* ChainC;
+
+template <typename real> struct JointK;
+template <> struct JointK<float> {
+    static __device__ __forceinline__ float R(ChainC ch, int j, int i) { return ch->Rf[j][i]; }
+    static __device__ __forceinline__ float t(ChainC ch, int j, int i) { return ch->tf[j][i]; }
+};
+template <> struct JointK<double> {
+    static __device__ __forceinline__ double R(ChainC ch, int j, int i) { return ch->j[j].R[i]; }
+    static __device__ __forceinline__ double t(ChainC ch, int j, int i) { return ch->j[j].t[i]; }
+};
+
+template <typename real>
+static TermK<real> make_termk(const CostTerm& s) {
+    TermK<real> k;
+    k.kind = s.kind; k.flags = s.flags;
+    k.K = (real)s.K; k.K2 = (real)s.K2; k.dt = (real)s.dt;
+    k.c11 = (real)s.c11; k.c12 = (real)s.c12; k.c22 = (real)s.c22; k.selfc = (real)s.selfc;
+    k.inv_cell = (real)s.inv_cell; k.off_x = (real)s.off_x; k.off_y = (real)s.off_y;
+    k.dev_data = s.dev_data; k.dim0 = s.dim0; k.dim1 = s.dim1; k.rows_per_goal = s.rows_per_goal;
+    k.n_points = s.n_points; k.n_interp = s.n_interp; k.interp_lo = s.interp_lo; k.interp_hi = s.interp_hi;
+    for (int a = 0; a < SGPMP_MAX_INTERP; ++a) k.alpha[a] = (real)s.alpha[a];
+    return k;
+}
+
+template <typename real>
+static ProgK<real> make_progk(const CostProgram& p) {
+    ProgK<real> k;
+    k.n_terms = p.n_terms; k.needs_fk = p.needs_fk;
+    for (int i = 0; i < SGPMP_MAX_TERMS; ++i) k.t[i] = make_termk<real>(p.terms[i]);
+    return k;
+}
+
+// ---------------------------------------------------------------------------------- wave helpers
 template <typename real>
 __device__ __forceinline__ real shfl_up1(real v) { return __shfl_up(v, 1, 64); }
 template <typename real>
@@ -53,10 +145,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 // multiply and the add rounded separately (no FMA) so that cell boundaries fall where the
 // reference's do; x clamped by shape[0]-1, y by shape[1]-1, value = map[y, x].
 template <typename real>
-__device__ __forceinline__ real grid_value(const CostTerm& tm, real x, real y) {
+__device__ __forceinline__ real grid_value(const TermK<real>& tm, real x, real y) {
     using O = RealOps<real>;
-    const real fx = O::floor_(O::add_rn(O::mul_rn(x, (real)tm.inv_cell), (real)tm.off_x));
-    const real fy = O::floor_(O::add_rn(O::mul_rn(y, (real)tm.inv_cell), (real)tm.off_y));
+    const real fx = O::floor_(O::add_rn(O::mul_rn(x, tm.inv_cell), tm.off_x));
+    const real fy = O::floor_(O::add_rn(O::mul_rn(y, tm.inv_cell), tm.off_y));
     const real hx = (real)(tm.dim0 - 1), hy = (real)(tm.dim1 - 1);
     const int ix = (int)fmin(fmax(fx, (real)0), hx);       // clamp in float first: no int overflow
     const int iy = (int)fmin(fmax(fy, (real)0), hy);
@@ -64,10 +156,9 @@ __device__ __forceinline__ real grid_value(const CostTerm& tm, real x, real y) {
     return grid[(size_t)iy * tm.dim1 + ix];
 }
 
-// ---------------------------------------------------------------------------------- FK
+// ---------------------------------------------------------------------------------- generic FK (LDS)
 // Positions of all link frames for joint vector q, written to LDS column `col` (SoA, `stride`
 // reals between consecutive scalars).  H_child = H_parent * Trans(xyz) * RPY * Rz(q).
-template <typename real> struct JointConst;
 template <typename real, int N>
 __device__ __forceinline__ void fk_points(const ChainDev* __restrict__ ch, const real (&q)[N], real* col,
                                           int stride) {
@@ -113,14 +204,14 @@ __device__ __forceinline__ void fk_points(const ChainDev* __restrict__ ch, const
 
 // Append the interpolated points of a field term (fields.py:68-74) after the link points.
 template <typename real>
-__device__ __forceinline__ void add_interp_points(const CostTerm& tm, int n_links, real* col, int stride) {
+__device__ __forceinline__ void add_interp_points(const TermK<real>& tm, int n_links, real* col, int stride) {
     int o = n_links;
     for (int i = tm.interp_lo; i < tm.interp_hi; ++i) {
         const real ax = col[(i * 3 + 0) * stride], ay = col[(i * 3 + 1) * stride], az = col[(i * 3 + 2) * stride];
         const real bx = col[((i + 1) * 3 + 0) * stride], by = col[((i + 1) * 3 + 1) * stride],
                    bz = col[((i + 1) * 3 + 2) * stride];
         for (int a = 0; a < tm.n_interp; ++a, ++o) {
-            const real al = (real)tm.alpha[a];
+            const real al = tm.alpha[a];
             col[(o * 3 + 0) * stride] = ax + (bx - ax) * al;
             col[(o * 3 + 1) * stride] = ay + (by - ay) * al;
             col[(o * 3 + 2) * stride] = az + (bz - az) * al;
@@ -130,7 +221,7 @@ __device__ __forceinline__ void add_interp_points(const CostTerm& tm, int n_link
 
 // LinkDistanceField.compute_cost on the np points of this lane (fields.py:75-86).
 template <typename real>
-__device__ __forceinline__ real spheres_field(const CostTerm& tm, int np, const real* col, int stride,
+__device__ __forceinline__ real spheres_field(const TermK<real>& tm, int np, const real* col, int stride,
                                               const real* __restrict__ sph, int n_sph) {
     using O = RealOps<real>;
     const int type = tm.flags & 15;
@@ -158,9 +249,9 @@ __device__ __forceinline__ real spheres_field(const CostTerm& tm, int np, const 
 
 // LinkSelfDistanceField.compute_cost: full np x np sum incl. the diagonal (fields.py:124).
 template <typename real>
-__device__ __forceinline__ real self_field(const CostTerm& tm, int np, const real* col, int stride) {
+__device__ __forceinline__ real self_field(const TermK<real>& tm, int np, const real* col, int stride) {
     using O = RealOps<real>;
-    const real k = (real)tm.K2;                       // -1 / (2 margin^2)
+    const real k = tm.K2;                             // -1 / (2 margin^2)
     real acc = (real)np;                              // diagonal: exp(0)
     for (int i = 1; i < np; ++i) {
         const real ax = col[(i * 3 + 0) * stride], ay = col[(i * 3 + 1) * stride], az = col[(i * 3 + 2) * stride];
@@ -173,12 +264,188 @@ __device__ __forceinline__ real self_field(const CostTerm& tm, int np, const rea
     return acc;
 }
 
+// ---------------------------------------------------------------------------------- generated-chain path
+// FKMODE >= 1000: the chain has build-time generated code (chain_code_generated.h): FK is
+// straight-line code with the joint constants folded in, only the DISTINCT link positions exist,
+// the loops over links / q-dependent pairs are unrolled with immediate weights, and the sphere terms
+// of links that never move are evaluated once per wave (`stat`) instead of once per waypoint.
+template <int FKMODE> struct ChainOf { using type = ChainCode_panda; };     // 1000 -> panda
+
+template <typename real, class CC>
+__device__ __forceinline__ void fk_cg(const real (&q)[CC::N], real (&Pq)[CC::NREP][3]) {
+    using O = RealOps<real>;
+    if constexpr (sizeof(real) == 4) CC::template fk_snapped<real, O>(q, Pq);
+    else CC::template fk_exact<real, O>(q, Pq);
+}
+
+// sphere field restricted to the links with is_static == WANT_STATIC; `acc` carries the other part
+template <typename real, class CC, bool WANT_STATIC>
+__device__ __forceinline__ real spheres_field_cg(const TermK<real>& tm, const real (&Pq)[CC::NREP][3],
+                                                 const real* __restrict__ sph, int n_sph, real acc) {
+    using O = RealOps<real>;
+    const int type = tm.flags & 15;
+    for (int o = 0; o < n_sph; ++o) {
+        const real cx = sph[o * 4 + 0], cy = sph[o * 4 + 1], cz = sph[o * 4 + 2], r = sph[o * 4 + 3];
+        if (type == SGPMP_FIELD_RBF) {
+            const real k = (real)(-0.5 * SGPMP_LOG2E) * O::rcp_(r * r);
+#pragma unroll
+            for (int l = 0; l < CC::NREP; ++l) {
+                if (CC::is_static(l) != WANT_STATIC) continue;
+                const real dx = Pq[l][0] - cx, dy = Pq[l][1] - cy, dz = Pq[l][2] - cz;
+                acc += (real)CC::mult(l) * O::exp2_((dx * dx + dy * dy + dz * dz) * k);
+            }
+        } else if (type == SGPMP_FIELD_SDF) {
+#pragma unroll
+            for (int l = 0; l < CC::NREP; ++l) {
+                if (CC::is_static(l) != WANT_STATIC) continue;
+                const real dx = Pq[l][0] - cx, dy = Pq[l][1] - cy, dz = Pq[l][2] - cz;
+                real sdf = r - O::sqrt_(dx * dx + dy * dy + dz * dz);
+                if (tm.flags & SGPMP_FLAG_SDF_CLAMP) sdf = fmin(sdf, (real)0);
+                acc = fmax(acc, sdf);
+            }
+        } else {
+#pragma unroll
+            for (int l = 0; l < CC::NREP; ++l) {
+                if (CC::is_static(l) != WANT_STATIC) continue;
+                const real dx = Pq[l][0] - cx, dy = Pq[l][1] - cy, dz = Pq[l][2] - cz;
+                acc += (O::sqrt_(dx * dx + dy * dy + dz * dz) < r) ? (real)CC::mult(l) : (real)0;
+            }
+        }
+    }
+    return acc;
+}
+
+template <typename real, class CC>
+__device__ __forceinline__ real self_field_cg(const TermK<real>& tm, const real (&Pq)[CC::NREP][3]) {
+    using O = RealOps<real>;
+    const real k = tm.K2 * (real)SGPMP_LOG2E;
+    real acc = tm.selfc;                                 // diagonal, coincident and rigid pairs (host)
+#pragma unroll
+    for (int p = 0; p < CC::NPAIR; ++p) {
+        const int i = CC::pair_i(p), j = CC::pair_j(p);
+        const real dx = Pq[i][0] - Pq[j][0], dy = Pq[i][1] - Pq[j][1], dz = Pq[i][2] - Pq[j][2];
+        acc += (real)CC::pair_w(p) * O::exp2_((dx * dx + dy * dy + dz * dz) * k);
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------- register FK path
+template <typename real, int N, int NJ>
+__device__ __forceinline__ void fk_points_reg(ChainC chain, const real (&q)[N],
+                                              real (&PX)[NJ + 1], real (&PY)[NJ + 1], real (&PZ)[NJ + 1]) {
+    using O = RealOps<real>;
+    real R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    real p[3] = {0, 0, 0};
+    PX[0] = 0; PY[0] = 0; PZ[0] = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        ChainC ch = opaque(chain);                         // this joint's 12 constants: loaded here
+        real Fm[9], tt[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Fm[i] = JointK<real>::R(ch, j, i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tt[i] = JointK<real>::t(ch, j, i);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) p[r] += R[r * 3 + 0] * tt[0] + R[r * 3 + 1] * tt[1] + R[r * 3 + 2] * tt[2];
+        real Rn[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                Rn[r * 3 + c] = R[r * 3 + 0] * Fm[c] + R[r * 3 + 1] * Fm[3 + c] + R[r * 3 + 2] * Fm[6 + c];
+        if (j < N) {                                       // revolute-first chain: joint j turns by q[j]
+            real s, c;
+            O::fsincos_(q[j < N ? j : 0], &s, &c);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const real a = Rn[r * 3 + 0], b = Rn[r * 3 + 1];
+                Rn[r * 3 + 0] = a * c + b * s;
+                Rn[r * 3 + 1] = b * c - a * s;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+        PX[j + 1] = p[0]; PY[j + 1] = p[1]; PZ[j + 1] = p[2];
+    }
+}
+
+template <typename real, int NJ>
+__device__ __forceinline__ real spheres_field_reg(const TermK<real>& tm, ChainC chain,
+                                                  const real (&PX)[NJ + 1], const real (&PY)[NJ + 1],
+                                                  const real (&PZ)[NJ + 1], const real* __restrict__ sph,
+                                                  int n_sph) {
+    using O = RealOps<real>;
+    constexpr int NL = NJ + 1;
+    const int type = tm.flags & 15;
+    real acc = (type == SGPMP_FIELD_SDF) ? (real)-1e30 : (real)0;
+    ChainC ch = opaque(chain);
+    real mult[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) mult[l] = (real)ch->plan.mult[l];
+    for (int o = 0; o < n_sph; ++o) {
+        const real cx = sph[o * 4 + 0], cy = sph[o * 4 + 1], cz = sph[o * 4 + 2], r = sph[o * 4 + 3];
+        if (type == SGPMP_FIELD_RBF) {
+            const real k = (real)(-0.5 * SGPMP_LOG2E) * O::rcp_(r * r);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const real m = mult[l];
+                if (m != 0) {
+                    const real dx = PX[l] - cx, dy = PY[l] - cy, dz = PZ[l] - cz;
+                    acc += m * O::exp2_((dx * dx + dy * dy + dz * dz) * k);
+                }
+            }
+        } else if (type == SGPMP_FIELD_SDF) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                if (mult[l] != 0) {
+                    const real dx = PX[l] - cx, dy = PY[l] - cy, dz = PZ[l] - cz;
+                    real sdf = r - O::sqrt_(dx * dx + dy * dy + dz * dz);
+                    if (tm.flags & SGPMP_FLAG_SDF_CLAMP) sdf = fmin(sdf, (real)0);
+                    acc = fmax(acc, sdf);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const real m = mult[l];
+                if (m != 0) {
+                    const real dx = PX[l] - cx, dy = PY[l] - cy, dz = PZ[l] - cz;
+                    acc += (O::sqrt_(dx * dx + dy * dy + dz * dz) < r) ? m : (real)0;
+                }
+            }
+        }
+    }
+    return acc;
+}
+
+template <typename real, int NJ>
+__device__ __forceinline__ real self_field_reg(const TermK<real>& tm, ChainC chain,
+                                               const real (&PX)[NJ + 1], const real (&PY)[NJ + 1],
+                                               const real (&PZ)[NJ + 1]) {
+    using O = RealOps<real>;
+    constexpr int NL = NJ + 1;
+    const real k = tm.K2 * (real)SGPMP_LOG2E;            // exp(K2 d^2) = exp2(K2 log2(e) d^2)
+    real acc = tm.selfc;                                 // diagonal, coincident and rigid pairs
+#pragma unroll
+    for (int i = 1; i < NL; ++i) {
+        ChainC ch = opaque(chain);                         // one row of pair weights at a time
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            const real w = (real)ch->plan.wpair[i * SGPMP_MAX_LINKS + j];
+            if (w != 0) {
+                const real dx = PX[i] - PX[j], dy = PY[i] - PY[j], dz = PZ[i] - PZ[j];
+                acc += w * O::exp2_((dx * dx + dy * dy + dz * dz) * k);
+            }
+        }
+    }
+    return acc;
+}
+
 // ---------------------------------------------------------------------------------- the sweep
 template <typename real>
 struct CostArgs {
     int T;
-    const CostProgram* prog;
-    const ChainDev* chain;
+    const ChainDev* chain;      // generic path only
     int n_links;
     const real* trajs;
     long long batch, batch_offset;
@@ -191,9 +458,10 @@ struct CostArgs {
     double* costs64;
 };
 
-template <typename real, int N, bool HAS_FK>
+// FKMODE: 0 = no link fields; -1 = generic chain; NJ > 0 = register path with exactly NJ joints.
+template <typename real, int N, int FKMODE>
 __global__ void __launch_bounds__(256)
-cost_sweep_kernel(CostArgs<real> a) {
+cost_sweep_kernel(const CostArgs<real> a, const ProgK<real> P) {
     constexpr int D = 2 * N;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     real* lds = reinterpret_cast<real*>(lds_raw);
@@ -202,9 +470,25 @@ cost_sweep_kernel(CostArgs<real> a) {
     const int waves_per_block = blockDim.x >> 6;
     const int stride = blockDim.x;
     real* col = lds + threadIdx.x;
-    const CostProgram& P = *a.prog;
     const int T = a.T;
     const int nchunks = (T + 63) >> 6;
+
+    __shared__ double stat[4 * SGPMP_MAX_TERMS];         // per wave: sphere terms of the static links
+    if constexpr (FKMODE >= 1000) {
+        using CC = typename ChainOf<FKMODE>::type;
+        real q0[N], P0[CC::NREP][3];
+#pragma unroll
+        for (int k = 0; k < N; ++k) q0[k] = 0;
+        fk_cg<real, CC>(q0, P0);                         // static links do not depend on q
+        for (int ti = 0; ti < P.n_terms; ++ti) {
+            const TermK<real>& tm = P.t[ti];
+            if (tm.kind != SGPMP_COST_SPHERES) continue;
+            const real init = ((tm.flags & 15) == SGPMP_FIELD_SDF) ? (real)-1e30 : (real)0;
+            const real v = spheres_field_cg<real, CC, true>(tm, P0, a.spheres, a.n_spheres, init);
+            if (lane == 0) stat[wave * SGPMP_MAX_TERMS + ti] = (double)v;
+        }
+        __syncthreads();
+    }
 
     for (long long b = (long long)blockIdx.x * waves_per_block + wave; b < a.batch;
          b += (long long)gridDim.x * waves_per_block) {
@@ -220,8 +504,11 @@ cost_sweep_kernel(CostArgs<real> a) {
             const bool valid = t < T;
             real x[D], xp[D];
             if (valid) {
+                // D is even and rows start 2*sizeof(real)-aligned: paired loads
+                typedef real real2 __attribute__((ext_vector_type(2)));
+                const real2* r2 = reinterpret_cast<const real2*>(row + (size_t)t * D);
 #pragma unroll
-                for (int i = 0; i < D; ++i) x[i] = row[(size_t)t * D + i];
+                for (int i = 0; i < N; ++i) { const real2 v = r2[i]; x[2 * i] = v.x; x[2 * i + 1] = v.y; }
             } else {
 #pragma unroll
                 for (int i = 0; i < D; ++i) x[i] = 0;
@@ -236,17 +523,17 @@ cost_sweep_kernel(CostArgs<real> a) {
             double part64 = 0.;
 
             for (int ti = 0; ti < P.n_terms; ++ti) {
-                const CostTerm& tm = P.terms[ti];
+                const TermK<real>& tm = P.t[ti];
                 if (tm.kind == SGPMP_COST_GP) {
                     if (valid && t == 0 && (tm.flags & SGPMP_FLAG_GP_START)) {
                         const real* st = (const real*)tm.dev_data;
                         real sq = 0;
 #pragma unroll
                         for (int i = 0; i < D; ++i) { const real dd = st[i] - x[i]; sq += dd * dd; }
-                        part64 += (double)(sq * (real)tm.K2);
+                        part64 += (double)(sq * tm.K2);
                     }
                     if (valid && t >= 1) {           // e_{t-1} = x_t - Phi x_{t-1} (gp_factor.py:54-58)
-                        const real dt = (real)tm.dt;
+                        const real dt = tm.dt;
                         real pp = 0, pv = 0, vv = 0;
 #pragma unroll
                         for (int k = 0; k < N; ++k) {
@@ -254,8 +541,7 @@ cost_sweep_kernel(CostArgs<real> a) {
                             const real ev = x[N + k] - xp[N + k];
                             pp += ep * ep; pv += ep * ev; vv += ev * ev;
                         }
-                        part64 += (double)((real)tm.K * ((real)tm.c11 * pp + (real)2 * (real)tm.c12 * pv +
-                                                         (real)tm.c22 * vv));
+                        part64 += (double)(tm.K * (tm.c11 * pp + (real)2 * tm.c12 * pv + tm.c22 * vv));
                     }
                 } else if (tm.kind == SGPMP_COST_GOAL_PRIOR) {
                     if (valid && t == T - 1) {
@@ -264,29 +550,62 @@ cost_sweep_kernel(CostArgs<real> a) {
                         real sq = 0;
 #pragma unroll
                         for (int i = 0; i < D; ++i) { const real dd = gl[i] - x[i]; sq += dd * dd; }
-                        part64 += (double)(sq * (real)tm.K);
+                        part64 += (double)(sq * tm.K);
                     }
                 } else if (tm.kind == SGPMP_COST_GRID) {
-                    if (valid && t >= 1) part += (real)tm.K * grid_value<real>(tm, x[0], x[N > 1 ? 1 : 0]);
+                    if (valid && t >= 1) part += tm.K * grid_value<real>(tm, x[0], x[N > 1 ? 1 : 0]);
                 }
             }
-            if constexpr (HAS_FK) {
+            if constexpr (FKMODE != 0) {
                 if (P.needs_fk) {
                     // every lane runs FK (uniform control flow); invalid lanes work on zeros
                     real q[N];
 #pragma unroll
                     for (int k = 0; k < N; ++k) q[k] = x[k];
-                    fk_points<real, N>(a.chain, q, col, stride);
-                    for (int ti = 0; ti < P.n_terms; ++ti) {
-                        const CostTerm& tm = P.terms[ti];
-                        if (tm.kind != SGPMP_COST_SPHERES && tm.kind != SGPMP_COST_SELF) continue;
-                        if (tm.n_interp > 0) add_interp_points<real>(tm, a.n_links, col, stride);
-                        real f;
-                        if (tm.kind == SGPMP_COST_SPHERES)
-                            f = spheres_field<real>(tm, tm.n_points, col, stride, a.spheres, a.n_spheres);
-                        else
-                            f = self_field<real>(tm, tm.n_points, col, stride);
-                        if (valid && t >= 1) part += (real)tm.K * f;
+                    if constexpr (FKMODE >= 1000) {
+                        using CC = typename ChainOf<FKMODE>::type;
+                        real Pq[CC::NREP][3];
+                        fk_cg<real, CC>(q, Pq);
+                        for (int ti = 0; ti < P.n_terms; ++ti) {
+                            const TermK<real>& tm = P.t[ti];
+                            real f;
+                            if (tm.kind == SGPMP_COST_SPHERES)
+                                f = spheres_field_cg<real, CC, false>(tm, Pq, a.spheres, a.n_spheres,
+                                                                      (real)stat[wave * SGPMP_MAX_TERMS + ti]);
+                            else if (tm.kind == SGPMP_COST_SELF)
+                                f = self_field_cg<real, CC>(tm, Pq);
+                            else
+                                continue;
+                            if (valid && t >= 1) part += tm.K * f;
+                        }
+                    } else if constexpr (FKMODE > 0) {
+                        real PX[FKMODE + 1], PY[FKMODE + 1], PZ[FKMODE + 1];
+                        ChainC chain = as_const(a.chain);
+                        fk_points_reg<real, N, FKMODE>(chain, q, PX, PY, PZ);
+                        for (int ti = 0; ti < P.n_terms; ++ti) {
+                            const TermK<real>& tm = P.t[ti];
+                            real f;
+                            if (tm.kind == SGPMP_COST_SPHERES)
+                                f = spheres_field_reg<real, FKMODE>(tm, chain, PX, PY, PZ, a.spheres, a.n_spheres);
+                            else if (tm.kind == SGPMP_COST_SELF)
+                                f = self_field_reg<real, FKMODE>(tm, chain, PX, PY, PZ);
+                            else
+                                continue;
+                            if (valid && t >= 1) part += tm.K * f;
+                        }
+                    } else {
+                        fk_points<real, N>(a.chain, q, col, stride);
+                        for (int ti = 0; ti < P.n_terms; ++ti) {
+                            const TermK<real>& tm = P.t[ti];
+                            if (tm.kind != SGPMP_COST_SPHERES && tm.kind != SGPMP_COST_SELF) continue;
+                            if (tm.n_interp > 0) add_interp_points<real>(tm, a.n_links, col, stride);
+                            real f;
+                            if (tm.kind == SGPMP_COST_SPHERES)
+                                f = spheres_field<real>(tm, tm.n_points, col, stride, a.spheres, a.n_spheres);
+                            else
+                                f = self_field<real>(tm, tm.n_points, col, stride);
+                            if (valid && t >= 1) part += tm.K * f;
+                        }
                     }
                 }
             }
@@ -324,20 +643,27 @@ cost_sweep_kernel(CostArgs<real> a) {
 }
 
 template <typename real>
-static hipError_t cost_dispatch(int n, int T, const CostProgram* d_prog, const CostProgram& h_prog,
-                                const ChainDev* d_chain, int n_links, const real* trajs, long long batch,
+static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const ChainDev* d_chain,
+                                const ChainDev& h_chain, const real* trajs, long long batch,
                                 long long batch_offset, const real* spheres, int n_spheres,
                                 const real* isw, int rows_per_particle, double is_dt, real* costs,
                                 double* costs64, hipStream_t stream) {
+    const int n_links = h_chain.n_links;
     CostArgs<real> a;
-    a.T = T; a.prog = d_prog; a.chain = d_chain; a.n_links = n_links; a.trajs = trajs;
+    a.T = T; a.chain = d_chain; a.n_links = n_links; a.trajs = trajs;
     a.batch = batch; a.batch_offset = batch_offset; a.spheres = spheres; a.n_spheres = n_spheres;
     a.isw = isw; a.rows_per_particle = rows_per_particle > 0 ? rows_per_particle : 1;
     a.is_dt = (real)is_dt; a.costs = costs; a.costs64 = costs64;
+    const ProgK<real> P = make_progk<real>(h_prog);
     int block = 256;
     size_t lds = 0;
     const bool fk = h_prog.needs_fk != 0;
-    if (fk) {
+    // register path: revolute-first chain, no interpolated points, an instantiated (n, joints) pair
+    bool reg = fk && h_chain.plan.fast && !getenv("SGPMP_FORCE_GENERIC_FK");
+    for (int i = 0; i < h_prog.n_terms; ++i)
+        if (h_prog.terms[i].n_interp > 0) reg = false;
+    const int nj = n_links - 1;
+    if (fk && !reg) {
         int max_pts = n_links;
         for (int i = 0; i < h_prog.n_terms; ++i)
             if (h_prog.terms[i].n_points > max_pts) max_pts = h_prog.terms[i].n_points;
@@ -349,14 +675,34 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram* d_prog, const C
     const long long cap = 256LL * 32;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
+    if (reg && h_chain.plan.codegen_id == 1 && n == ChainCode_panda::N && !getenv("SGPMP_NO_CHAIN_CODEGEN")) {
+        hipLaunchKernelGGL((cost_sweep_kernel<real, ChainCode_panda::N, 1000>), dim3((unsigned)blocks),
+                           dim3(256), 0, stream, a, P);
+        return hipGetLastError();
+    }
+#define COST_REG(NN, NJJ)                                                                          \
+    if (reg && n == NN && nj == NJJ) {                                                             \
+        hipLaunchKernelGGL((cost_sweep_kernel<real, NN, NJJ>), dim3((unsigned)blocks), dim3(256), 0, \
+                           stream, a, P);                      \
+        return hipGetLastError();                                                                  \
+    }
+    COST_REG(7, 10) COST_REG(7, 7) COST_REG(6, 6) COST_REG(3, 3) COST_REG(2, 2)
+#undef COST_REG
+    if (reg) {               // no instantiation for this (n, joints): fall back to the generic path
+        int max_pts = n_links;
+        lds = (size_t)max_pts * 3 * block * sizeof(real);
+        while (lds > 64 * 1024 && block > 64) { block >>= 1; lds >>= 1; }
+        blocks = (batch + block / 64 - 1) / (block / 64);
+        if (blocks > cap) blocks = cap;
+    }
 #define COST_CASE(NN)                                                                              \
     case NN:                                                                                       \
         if (fk)                                                                                    \
-            hipLaunchKernelGGL((cost_sweep_kernel<real, NN, true>), dim3((unsigned)blocks),        \
-                               dim3(block), lds, stream, a);                                       \
+            hipLaunchKernelGGL((cost_sweep_kernel<real, NN, -1>), dim3((unsigned)blocks),          \
+                               dim3(block), lds, stream, a, P);                                    \
         else                                                                                       \
-            hipLaunchKernelGGL((cost_sweep_kernel<real, NN, false>), dim3((unsigned)blocks),       \
-                               dim3(block), 0, stream, a);                                         \
+            hipLaunchKernelGGL((cost_sweep_kernel<real, NN, 0>), dim3((unsigned)blocks),           \
+                               dim3(block), 0, stream, a, P);                                      \
         break;
     switch (n) {
         COST_CASE(1) COST_CASE(2) COST_CASE(3) COST_CASE(4) COST_CASE(5) COST_CASE(6) COST_CASE(7) COST_CASE(8)
@@ -366,17 +712,17 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram* d_prog, const C
     return hipGetLastError();
 }
 
-hipError_t launch_cost(int dtype, int n, int T, const CostProgram* d_prog, const CostProgram& h_prog,
-                       const ChainDev* d_chain, int n_links, const void* trajs, long long batch,
+hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const ChainDev* d_chain,
+                       const ChainDev& h_chain, const void* trajs, long long batch,
                        long long batch_offset, const void* spheres, int n_spheres,
                        const void* is_weights, int rows_per_particle, double is_dt, void* costs,
                        double* costs64, hipStream_t stream) {
     if (dtype == SGPMP_F64)
-        return cost_dispatch<double>(n, T, d_prog, h_prog, d_chain, n_links, (const double*)trajs, batch,
+        return cost_dispatch<double>(n, T, h_prog, d_chain, h_chain, (const double*)trajs, batch,
                                      batch_offset, (const double*)spheres, n_spheres,
                                      (const double*)is_weights, rows_per_particle, is_dt, (double*)costs,
                                      costs64, stream);
-    return cost_dispatch<float>(n, T, d_prog, h_prog, d_chain, n_links, (const float*)trajs, batch,
+    return cost_dispatch<float>(n, T, h_prog, d_chain, h_chain, (const float*)trajs, batch,
                                 batch_offset, (const float*)spheres, n_spheres, (const float*)is_weights,
                                 rows_per_particle, is_dt, (float*)costs, costs64, stream);
 }
@@ -439,7 +785,7 @@ hipError_t launch_fk(int dtype, int n, const ChainDev* d_chain, int n_links, con
 }
 
 template <typename real>
-__global__ void grid_lookup_kernel(CostTerm tm, const real* __restrict__ xy, long long batch,
+__global__ void grid_lookup_kernel(const TermK<real> tm, const real* __restrict__ xy, long long batch,
                                    real* __restrict__ out) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
@@ -452,17 +798,17 @@ hipError_t launch_grid_lookup(int dtype, const CostTerm& term, const void* xy, l
     const unsigned grid = (unsigned)((batch + block - 1) / block);
     if (grid == 0) return hipSuccess;
     if (dtype == SGPMP_F64)
-        hipLaunchKernelGGL((grid_lookup_kernel<double>), dim3(grid), dim3(block), 0, stream, term,
-                           (const double*)xy, batch, (double*)out);
+        hipLaunchKernelGGL((grid_lookup_kernel<double>), dim3(grid), dim3(block), 0, stream,
+                           make_termk<double>(term), (const double*)xy, batch, (double*)out);
     else
-        hipLaunchKernelGGL((grid_lookup_kernel<float>), dim3(grid), dim3(block), 0, stream, term,
-                           (const float*)xy, batch, (float*)out);
+        hipLaunchKernelGGL((grid_lookup_kernel<float>), dim3(grid), dim3(block), 0, stream,
+                           make_termk<float>(term), (const float*)xy, batch, (float*)out);
     return hipGetLastError();
 }
 
 // LinkDistanceField / LinkSelfDistanceField.compute_cost on explicit frames [B,L,4,4] -> [B].
 template <typename real>
-__global__ void field_eval_kernel(CostTerm tm, const real* __restrict__ frames, long long batch,
+__global__ void field_eval_kernel(const TermK<real> tm, const real* __restrict__ frames, long long batch,
                                   int n_links, const real* __restrict__ sph, int n_sph,
                                   real* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -489,12 +835,12 @@ hipError_t launch_field_eval(int dtype, const CostTerm& term, const void* frames
     const size_t esz = dtype == SGPMP_F64 ? 8 : 4;
     const size_t lds = (size_t)term.n_points * 3 * block * esz;
     if (dtype == SGPMP_F64)
-        hipLaunchKernelGGL((field_eval_kernel<double>), dim3(grid), dim3(block), lds, stream, term,
-                           (const double*)frames, batch, n_links, (const double*)spheres, n_spheres,
-                           (double*)out);
+        hipLaunchKernelGGL((field_eval_kernel<double>), dim3(grid), dim3(block), lds, stream,
+                           make_termk<double>(term), (const double*)frames, batch, n_links,
+                           (const double*)spheres, n_spheres, (double*)out);
     else
-        hipLaunchKernelGGL((field_eval_kernel<float>), dim3(grid), dim3(block), lds, stream, term,
-                           (const float*)frames, batch, n_links, (const float*)spheres, n_spheres,
-                           (float*)out);
+        hipLaunchKernelGGL((field_eval_kernel<float>), dim3(grid), dim3(block), lds, stream,
+                           make_termk<float>(term), (const float*)frames, batch, n_links,
+                           (const float*)spheres, n_spheres, (float*)out);
     return hipGetLastError();
 }

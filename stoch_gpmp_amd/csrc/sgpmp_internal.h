@@ -40,6 +40,7 @@ struct CostTerm {
     int dim0, dim1;
     long long rows_per_goal;   // GOAL_PRIOR: nppg * S
     double inv_cell, off_x, off_y;
+    double selfc;         // SELF: q-independent part of the LxL sum (diagonal, coincident and rigid pairs)
     int n_points;         // links + interpolated points
     int n_interp, interp_lo, interp_hi;
     double alpha[SGPMP_MAX_INTERP];
@@ -58,10 +59,29 @@ struct JointDev {
     int qidx;
 };
 
+// Result of the host-side chain analysis (api.hip: analyse_chain).  Link frames that always
+// coincide are merged into one representative point with a multiplicity, and link pairs whose
+// distance does not depend on q are folded into a constant -- both exact rewrites of the sums in
+// fields.py:79,86,124 that the register-resident FK path of the cost sweep exploits.
+struct FkPlan {
+    int fast;                                   // chain is revolute-first: register path usable
+    int codegen_id;                             // 0 none; 1 = ChainCode_panda (chain_code_generated.h)
+    int n_rep;                                  // distinct link positions
+    float mult[SGPMP_MAX_LINKS];                // multiplicity of link l if representative, else 0
+    float wpair[SGPMP_MAX_LINKS * SGPMP_MAX_LINKS];   // [i*ML+j], i>j: 2 m_i m_j if q-dependent, else 0
+    int n_cpairs;                               // q-independent representative pairs (host use)
+    double cpair_w[SGPMP_MAX_LINKS * SGPMP_MAX_LINKS / 2];
+    double cpair_d2[SGPMP_MAX_LINKS * SGPMP_MAX_LINKS / 2];
+    double diag;                                // sum_l m_l^2  (i == j and coincident terms)
+};
+
 struct ChainDev {
     int n_joints;
     int n_links;          // n_joints + 1
     JointDev j[SGPMP_MAX_JOINTS];
+    float Rf[SGPMP_MAX_JOINTS][9];              // fp32 copies of the joint constants
+    float tf[SGPMP_MAX_JOINTS][3];
+    FkPlan plan;
 };
 
 // ---------------------------------------------------------------------------------- launchers
@@ -74,8 +94,8 @@ hipError_t launch_sample(int dtype, int n, int T, const PriorDev& prior, uint64_
                          const void* eps, int eps_modes, int eps_mode_offset, void* out,
                          hipStream_t stream);
 
-hipError_t launch_cost(int dtype, int n, int T, const CostProgram* d_prog, const CostProgram& h_prog,
-                       const ChainDev* d_chain, int n_links, const void* trajs, long long batch,
+hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const ChainDev* d_chain,
+                       const ChainDev& h_chain, const void* trajs, long long batch,
                        long long batch_offset, const void* spheres, int n_spheres,
                        const void* is_weights, int rows_per_particle, double is_dt, void* costs,
                        double* costs64, hipStream_t stream);

@@ -285,6 +285,44 @@ def test_panda_fk_and_composite_match_reference_fixture(golden, tag, dtype, rtol
         cc.eval(trajs)
 
 
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-10), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("field_type", ["rbf", "sdf", "occupancy"])
+def test_register_fk_path_equals_generic_lds_path_and_oracle(monkeypatch, dtype, rtol, field_type):
+    """The Panda chain takes the register-resident FK path (merged coincident links, rigid pairs
+    folded to constants, native exp2/sin/cos in fp32); SGPMP_FORCE_GENERIC_FK=1 routes the same
+    program through the generic LDS path.  Both must agree with each other and with the oracle."""
+    from tests.hip_builders import hip_panda_cost
+    c = SC.PANDA
+    T, nppg, S = 20, 3, 7
+    g = torch.Generator().manual_seed(5)
+    lo = torch.tensor([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973])
+    hi = torch.tensor([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973])
+    q = lo + (hi - lo) * torch.rand(nppg, S, T, 7, generator=g)
+    trajs = torch.cat([q, torch.randn(nppg, S, T, 7, generator=g)], dim=-1).double()
+    sph = torch.as_tensor(SC.panda_spheres(num=6, seed=2))
+    ta = TA(dtype)
+
+    def collision_only(cost):                       # drop GP / goal terms: they would swamp the fields
+        cost.cost_list = cost.cost_list[2:] if hasattr(cost, "cost_list") else None
+        return cost
+    ora = SC.oracle_panda_cost(c, T, nppg, S, torch.float64, field_type=field_type)
+    ora.terms = ora.terms[2:]
+    ref = ora.eval(trajs, obstacle_spheres=sph)
+    fast = collision_only(hip_panda_cost(c, T, nppg, S, ta, field_type=field_type)).eval(
+        trajs.to(**ta), obstacle_spheres=sph.to(**ta))
+    monkeypatch.setenv("SGPMP_NO_CHAIN_CODEGEN", "1")     # runtime-constant register path
+    mid = collision_only(hip_panda_cost(c, T, nppg, S, ta, field_type=field_type)).eval(
+        trajs.to(**ta), obstacle_spheres=sph.to(**ta))
+    monkeypatch.setenv("SGPMP_FORCE_GENERIC_FK", "1")     # generic LDS path
+    slow = collision_only(hip_panda_cost(c, T, nppg, S, ta, field_type=field_type)).eval(
+        trajs.to(**ta), obstacle_spheres=sph.to(**ta))
+    scale = float(ref.abs().max())
+    close(fast, ref, rtol, atol=rtol * scale * 1e-2)
+    close(mid, ref, rtol, atol=rtol * scale * 1e-2)
+    close(slow, ref, rtol, atol=rtol * scale * 1e-2)
+    close(fast, slow, rtol, atol=rtol * scale * 1e-2)
+
+
 @pytest.mark.parametrize("T", [64, 65, 128, 130])
 def test_cost_sweep_multi_pass_trajectories_match_oracle(T):
     """T > 64 takes several 64-waypoint passes per wave with a carried neighbour waypoint."""
