@@ -29,6 +29,7 @@
 //     waypoint live in LDS (structure-of-arrays, one column per lane: bank-conflict free) because
 //     the loops index them dynamically.
 #include <cstdlib>
+#include <cstring>
 
 #include "chain_code_generated.h"
 #include "sgpmp_internal.h"
@@ -458,189 +459,36 @@ struct CostArgs {
     double* costs64;
 };
 
-// FKMODE: 0 = no link fields; -1 = generic chain; NJ > 0 = register path with exactly NJ joints.
-template <typename real, int N, int FKMODE>
-__global__ void __launch_bounds__(256)
-cost_sweep_kernel(const CostArgs<real> a, const ProgK<real> P) {
-    constexpr int D = 2 * N;
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    real* lds = reinterpret_cast<real*>(lds_raw);
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int waves_per_block = blockDim.x >> 6;
-    const int stride = blockDim.x;
-    real* col = lds + threadIdx.x;
-    const int T = a.T;
-    const int nchunks = (T + 63) >> 6;
+// A cost program with at most one term of each kind, as named fields (see cost_sweep_kernel.inc).
+template <typename real>
+struct FlatProg {
+    int has_gp, has_goal, has_grid, has_self, has_sph, sph_index;
+    TermK<real> gp, goal, grid, self, sph;
+};
 
-    __shared__ double stat[4 * SGPMP_MAX_TERMS];         // per wave: sphere terms of the static links
-    if constexpr (FKMODE >= 1000) {
-        using CC = typename ChainOf<FKMODE>::type;
-        real q0[N], P0[CC::NREP][3];
-#pragma unroll
-        for (int k = 0; k < N; ++k) q0[k] = 0;
-        fk_cg<real, CC>(q0, P0);                         // static links do not depend on q
-        for (int ti = 0; ti < P.n_terms; ++ti) {
-            const TermK<real>& tm = P.t[ti];
-            if (tm.kind != SGPMP_COST_SPHERES) continue;
-            const real init = ((tm.flags & 15) == SGPMP_FIELD_SDF) ? (real)-1e30 : (real)0;
-            const real v = spheres_field_cg<real, CC, true>(tm, P0, a.spheres, a.n_spheres, init);
-            if (lane == 0) stat[wave * SGPMP_MAX_TERMS + ti] = (double)v;
+template <typename real>
+static bool make_flat(const CostProgram& p, FlatProg<real>& f) {
+    std::memset(&f, 0, sizeof(f));
+    for (int i = 0; i < p.n_terms; ++i) {
+        const TermK<real> k = make_termk<real>(p.terms[i]);
+        int* has = nullptr;
+        TermK<real>* slot = nullptr;
+        switch (k.kind) {
+            case SGPMP_COST_GP: has = &f.has_gp; slot = &f.gp; break;
+            case SGPMP_COST_GOAL_PRIOR: has = &f.has_goal; slot = &f.goal; break;
+            case SGPMP_COST_GRID: has = &f.has_grid; slot = &f.grid; break;
+            case SGPMP_COST_SELF: has = &f.has_self; slot = &f.self; break;
+            case SGPMP_COST_SPHERES: has = &f.has_sph; slot = &f.sph; f.sph_index = i; break;
+            default: return false;
         }
-        __syncthreads();
+        if (*has) return false;                      // a second term of this kind: not flat
+        *has = 1;
+        *slot = k;
     }
-
-    for (long long b = (long long)blockIdx.x * waves_per_block + wave; b < a.batch;
-         b += (long long)gridDim.x * waves_per_block) {
-        const real* row = a.trajs + (size_t)b * T * D;
-        const real* isw = a.isw ? a.isw + (size_t)(b / a.rows_per_particle) * (T + 1) * D : nullptr;
-        double acc = 0.;
-        real carry[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) carry[i] = 0;
-
-        for (int c = 0; c < nchunks; ++c) {
-            const int t = (c << 6) + lane;
-            const bool valid = t < T;
-            real x[D], xp[D];
-            if (valid) {
-                // D is even and rows start 2*sizeof(real)-aligned: paired loads
-                typedef real real2 __attribute__((ext_vector_type(2)));
-                const real2* r2 = reinterpret_cast<const real2*>(row + (size_t)t * D);
-#pragma unroll
-                for (int i = 0; i < N; ++i) { const real2 v = r2[i]; x[2 * i] = v.x; x[2 * i + 1] = v.y; }
-            } else {
-#pragma unroll
-                for (int i = 0; i < D; ++i) x[i] = 0;
-            }
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                const real up = shfl_up1(x[i]);
-                xp[i] = (lane == 0) ? carry[i] : up;
-                carry[i] = shfl_idx(x[i], 63);
-            }
-            real part = 0;                                   // this waypoint's cost, in `real`
-            double part64 = 0.;
-
-            for (int ti = 0; ti < P.n_terms; ++ti) {
-                const TermK<real>& tm = P.t[ti];
-                if (tm.kind == SGPMP_COST_GP) {
-                    if (valid && t == 0 && (tm.flags & SGPMP_FLAG_GP_START)) {
-                        const real* st = (const real*)tm.dev_data;
-                        real sq = 0;
-#pragma unroll
-                        for (int i = 0; i < D; ++i) { const real dd = st[i] - x[i]; sq += dd * dd; }
-                        part64 += (double)(sq * tm.K2);
-                    }
-                    if (valid && t >= 1) {           // e_{t-1} = x_t - Phi x_{t-1} (gp_factor.py:54-58)
-                        const real dt = tm.dt;
-                        real pp = 0, pv = 0, vv = 0;
-#pragma unroll
-                        for (int k = 0; k < N; ++k) {
-                            const real ep = x[k] - (xp[k] + dt * xp[N + k]);
-                            const real ev = x[N + k] - xp[N + k];
-                            pp += ep * ep; pv += ep * ev; vv += ev * ev;
-                        }
-                        part64 += (double)(tm.K * (tm.c11 * pp + (real)2 * tm.c12 * pv + tm.c22 * vv));
-                    }
-                } else if (tm.kind == SGPMP_COST_GOAL_PRIOR) {
-                    if (valid && t == T - 1) {
-                        const long long g = (a.batch_offset + b) / tm.rows_per_goal;
-                        const real* gl = (const real*)tm.dev_data + (size_t)g * D;
-                        real sq = 0;
-#pragma unroll
-                        for (int i = 0; i < D; ++i) { const real dd = gl[i] - x[i]; sq += dd * dd; }
-                        part64 += (double)(sq * tm.K);
-                    }
-                } else if (tm.kind == SGPMP_COST_GRID) {
-                    if (valid && t >= 1) part += tm.K * grid_value<real>(tm, x[0], x[N > 1 ? 1 : 0]);
-                }
-            }
-            if constexpr (FKMODE != 0) {
-                if (P.needs_fk) {
-                    // every lane runs FK (uniform control flow); invalid lanes work on zeros
-                    real q[N];
-#pragma unroll
-                    for (int k = 0; k < N; ++k) q[k] = x[k];
-                    if constexpr (FKMODE >= 1000) {
-                        using CC = typename ChainOf<FKMODE>::type;
-                        real Pq[CC::NREP][3];
-                        fk_cg<real, CC>(q, Pq);
-                        for (int ti = 0; ti < P.n_terms; ++ti) {
-                            const TermK<real>& tm = P.t[ti];
-                            real f;
-                            if (tm.kind == SGPMP_COST_SPHERES)
-                                f = spheres_field_cg<real, CC, false>(tm, Pq, a.spheres, a.n_spheres,
-                                                                      (real)stat[wave * SGPMP_MAX_TERMS + ti]);
-                            else if (tm.kind == SGPMP_COST_SELF)
-                                f = self_field_cg<real, CC>(tm, Pq);
-                            else
-                                continue;
-                            if (valid && t >= 1) part += tm.K * f;
-                        }
-                    } else if constexpr (FKMODE > 0) {
-                        real PX[FKMODE + 1], PY[FKMODE + 1], PZ[FKMODE + 1];
-                        ChainC chain = as_const(a.chain);
-                        fk_points_reg<real, N, FKMODE>(chain, q, PX, PY, PZ);
-                        for (int ti = 0; ti < P.n_terms; ++ti) {
-                            const TermK<real>& tm = P.t[ti];
-                            real f;
-                            if (tm.kind == SGPMP_COST_SPHERES)
-                                f = spheres_field_reg<real, FKMODE>(tm, chain, PX, PY, PZ, a.spheres, a.n_spheres);
-                            else if (tm.kind == SGPMP_COST_SELF)
-                                f = self_field_reg<real, FKMODE>(tm, chain, PX, PY, PZ);
-                            else
-                                continue;
-                            if (valid && t >= 1) part += tm.K * f;
-                        }
-                    } else {
-                        fk_points<real, N>(a.chain, q, col, stride);
-                        for (int ti = 0; ti < P.n_terms; ++ti) {
-                            const TermK<real>& tm = P.t[ti];
-                            if (tm.kind != SGPMP_COST_SPHERES && tm.kind != SGPMP_COST_SELF) continue;
-                            if (tm.n_interp > 0) add_interp_points<real>(tm, a.n_links, col, stride);
-                            real f;
-                            if (tm.kind == SGPMP_COST_SPHERES)
-                                f = spheres_field<real>(tm, tm.n_points, col, stride, a.spheres, a.n_spheres);
-                            else
-                                f = self_field<real>(tm, tm.n_points, col, stride);
-                            if (valid && t >= 1) part += tm.K * f;
-                        }
-                    }
-                }
-            }
-            // importance-sampling term with the sampling prior's (A x)_t
-            if (isw && valid) {
-                const real* w = isw + (size_t)t * D;
-                real dot = 0;
-                if (t == 0) {
-#pragma unroll
-                    for (int i = 0; i < D; ++i) dot += x[i] * w[i];
-                } else {
-                    const real dt = a.is_dt;
-#pragma unroll
-                    for (int k = 0; k < N; ++k) {
-                        const real ep = x[k] - (xp[k] + dt * xp[N + k]);
-                        const real ev = x[N + k] - xp[N + k];
-                        dot += ep * w[k] + ev * w[N + k];
-                    }
-                }
-                if (t == T - 1) {
-                    const real* wg = isw + (size_t)T * D;
-#pragma unroll
-                    for (int i = 0; i < D; ++i) dot += x[i] * wg[i];
-                }
-                part64 += (double)dot;
-            }
-            acc += part64 + (double)part;
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            if (a.costs) a.costs[b] = (real)acc;
-            if (a.costs64) a.costs64[b] = acc;
-        }
-    }
+    return true;
 }
+
+#include "cost_sweep_kernel.inc"
 
 template <typename real>
 static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const ChainDev* d_chain,
@@ -649,6 +497,7 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
                                 const real* isw, int rows_per_particle, double is_dt, real* costs,
                                 double* costs64, hipStream_t stream) {
     const int n_links = h_chain.n_links;
+    if (batch + batch_offset >= (1LL << 31)) return hipErrorInvalidValue;   // row indices are 32-bit
     CostArgs<real> a;
     a.T = T; a.chain = d_chain; a.n_links = n_links; a.trajs = trajs;
     a.batch = batch; a.batch_offset = batch_offset; a.spheres = spheres; a.n_spheres = n_spheres;
@@ -675,15 +524,21 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
     const long long cap = 256LL * 32;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
+    FlatProg<real> F;
+    const bool flat = make_flat<real>(h_prog, F) && !getenv("SGPMP_NO_FLAT_PROGRAM");
     if (reg && h_chain.plan.codegen_id == 1 && n == ChainCode_panda::N && !getenv("SGPMP_NO_CHAIN_CODEGEN")) {
-        hipLaunchKernelGGL((cost_sweep_kernel<real, ChainCode_panda::N, 1000>), dim3((unsigned)blocks),
-                           dim3(256), 0, stream, a, P);
+        if (flat)
+            hipLaunchKernelGGL((cost_sweep_kernel<real, ChainCode_panda::N, 1000, true>), dim3((unsigned)blocks),
+                               dim3(256), 0, stream, a, P, F);
+        else
+            hipLaunchKernelGGL((cost_sweep_kernel<real, ChainCode_panda::N, 1000, false>), dim3((unsigned)blocks),
+                               dim3(256), 0, stream, a, P, F);
         return hipGetLastError();
     }
 #define COST_REG(NN, NJJ)                                                                          \
     if (reg && n == NN && nj == NJJ) {                                                             \
-        hipLaunchKernelGGL((cost_sweep_kernel<real, NN, NJJ>), dim3((unsigned)blocks), dim3(256), 0, \
-                           stream, a, P);                      \
+        hipLaunchKernelGGL((cost_sweep_kernel<real, NN, NJJ, false>), dim3((unsigned)blocks), dim3(256), 0, \
+                           stream, a, P, F);                                                       \
         return hipGetLastError();                                                                  \
     }
     COST_REG(7, 10) COST_REG(7, 7) COST_REG(6, 6) COST_REG(3, 3) COST_REG(2, 2)
@@ -698,11 +553,14 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
 #define COST_CASE(NN)                                                                              \
     case NN:                                                                                       \
         if (fk)                                                                                    \
-            hipLaunchKernelGGL((cost_sweep_kernel<real, NN, -1>), dim3((unsigned)blocks),          \
-                               dim3(block), lds, stream, a, P);                                    \
+            hipLaunchKernelGGL((cost_sweep_kernel<real, NN, -1, false>), dim3((unsigned)blocks),   \
+                               dim3(block), lds, stream, a, P, F);                                 \
+        else if (flat)                                                                             \
+            hipLaunchKernelGGL((cost_sweep_kernel<real, NN, 0, true>), dim3((unsigned)blocks),     \
+                               dim3(block), 0, stream, a, P, F);                                   \
         else                                                                                       \
-            hipLaunchKernelGGL((cost_sweep_kernel<real, NN, 0>), dim3((unsigned)blocks),           \
-                               dim3(block), 0, stream, a, P);                                      \
+            hipLaunchKernelGGL((cost_sweep_kernel<real, NN, 0, false>), dim3((unsigned)blocks),    \
+                               dim3(block), 0, stream, a, P, F);                                   \
         break;
     switch (n) {
         COST_CASE(1) COST_CASE(2) COST_CASE(3) COST_CASE(4) COST_CASE(5) COST_CASE(6) COST_CASE(7) COST_CASE(8)

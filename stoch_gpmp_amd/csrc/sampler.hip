@@ -13,34 +13,60 @@
 #include "sgpmp_internal.h"
 #include "rng.h"
 
-template <typename real>
+// Waypoints are produced TC at a time into an LDS tile [samples][TC*d (+pad)] and flushed as whole
+// row segments with VW-wide vector stores (16 B per lane when the row pitch allows), so the wave
+// writes contiguous spans instead of 4-byte fragments 3.5 KB apart.
+#define SGPMP_SAMPLE_TC 16
+
+template <typename real, int VW>
 __global__ void __launch_bounds__(256)
 sample_iso_kernel(int n, int T, int S, int spb, const real* __restrict__ coef /*[T][8]*/,
                   const real* __restrict__ means, const real* __restrict__ eps, int eps_modes,
                   int eps_mode_offset, int mode_offset, uint64_t seed, uint64_t draw,
                   real* __restrict__ out) {
+    typedef real vec __attribute__((ext_vector_type(VW)));
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    real* tile = reinterpret_cast<real*>(lds_raw);
+    constexpr int TC = SGPMP_SAMPLE_TC;
     const int m = blockIdx.y;
     const int sl = threadIdx.x / n, k = threadIdx.x - sl * n;
-    const int s = blockIdx.x * spb + sl;
-    if (sl >= spb || s >= S) return;
+    const int s0 = blockIdx.x * spb;
+    const int s = s0 + sl;
+    const bool active = sl < spb && s < S;
     const int d = 2 * n;
+    const int pitch = TC * d + 4;                        // reals per tile row (padded, VW-aligned)
     const size_t M = (size_t)T * d;
     const real* mu = means + (size_t)m * M;
-    real* row = out + ((size_t)m * S + s) * M;
-    const real* erow = eps ? eps + ((size_t)s * eps_modes + eps_mode_offset + m) * M : nullptr;
+    const real* erow = (eps && active) ? eps + ((size_t)s * eps_modes + eps_mode_offset + m) * M : nullptr;
     NoiseGen<real> gen;
     gen.init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)s, (uint32_t)k);
     real p = 0, v = 0;
-    for (int t = 0; t < T; ++t) {
-        const real* c = coef + t * 8;
-        real e1, e2;
-        if (erow) { e1 = erow[t * d + k]; e2 = erow[t * d + n + k]; }
-        else gen.get(t, e1, e2);
-        const real pn = c[0] * e1 + c[3] * p + c[4] * v;
-        const real vn = c[1] * e1 + c[2] * e2 + c[5] * p + c[6] * v;
-        p = pn; v = vn;
-        row[t * d + k] = mu[t * d + k] + p;
-        row[t * d + n + k] = mu[t * d + n + k] + v;
+    real* trow = tile + (size_t)sl * pitch;
+    const int rows = min(spb, S - s0);
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int tc = min(TC, T - t0);
+        if (active) {
+            for (int tt = 0; tt < tc; ++tt) {
+                const int t = t0 + tt;
+                const real* c = coef + t * 8;
+                real e1, e2;
+                if (erow) { e1 = erow[t * d + k]; e2 = erow[t * d + n + k]; }
+                else gen.get(t, e1, e2);
+                const real pn = c[0] * e1 + c[3] * p + c[4] * v;
+                const real vn = c[1] * e1 + c[2] * e2 + c[5] * p + c[6] * v;
+                p = pn; v = vn;
+                trow[tt * d + k] = mu[t * d + k] + p;
+                trow[tt * d + n + k] = mu[t * d + n + k] + v;
+            }
+        }
+        __syncthreads();
+        const int seg = tc * d / VW;                     // vectors per row segment
+        for (int i = threadIdx.x; i < rows * seg; i += blockDim.x) {
+            const int r = i / seg, j = i - r * seg;
+            const vec val = *reinterpret_cast<const vec*>(tile + (size_t)r * pitch + j * VW);
+            *reinterpret_cast<vec*>(out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d + j * VW) = val;
+        }
+        __syncthreads();
     }
 }
 
@@ -100,11 +126,20 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
     constexpr bool f64 = sizeof(real) == 8;
     if (prior.isotropic) {
         const real* coef = f64 ? (const real*)prior.iso64 : (const real*)prior.iso32;
+        const int d = 2 * n;
         int spb = 256 / n;
         if (spb > S) spb = S;
         dim3 grid((S + spb - 1) / spb, n_modes), block(((spb * n + 63) / 64) * 64);
-        hipLaunchKernelGGL((sample_iso_kernel<real>), grid, block, 0, stream, n, T, S, spb, coef,
-                           means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, out);
+        const size_t lds = (size_t)spb * (SGPMP_SAMPLE_TC * d + 4) * sizeof(real);
+        // widest store that every row segment start is aligned to: rows are T*d reals apart and
+        // tiles start every 16*d reals; d is even
+        const bool v16 = ((size_t)T * d * sizeof(real)) % 16 == 0;
+        if (f64 || !v16)
+            hipLaunchKernelGGL((sample_iso_kernel<real, 2>), grid, block, lds, stream, n, T, S, spb, coef,
+                               means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, out);
+        else
+            hipLaunchKernelGGL((sample_iso_kernel<real, 4>), grid, block, lds, stream, n, T, S, spb, coef,
+                               means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, out);
         return hipGetLastError();
     }
     const real* G = f64 ? (const real*)prior.G : (const real*)prior.G32;

@@ -11,7 +11,9 @@
 // K5 replaces the Sigma_inv @ mu part of StochGPMP._get_costs (planner.py:233-236) in factored form:
 //     x^T Sigma^-1 mu = (A x)^T a,   a = blkdiag(K_s, Q^-1 x (T-1), K_g) (A mu)
 // with A x = (x_0, e_0(x), .., e_{T-2}(x), x_{T-1}) (mp_priors_multi.py:185-198); `a` is computed in
-// fp64 once per particle per iteration and consumed by the cost sweep (K3).
+// fp64 once per particle per iteration and consumed by the cost sweep (K3).  The last block
+// (x_{T-1} . K_g mu_{T-1}) is re-expressed on (x_0, e_0, ..) and folded into the first T blocks, so
+// K3 needs exactly one weight vector per waypoint.
 #include "sgpmp_internal.h"
 
 template <typename T> __device__ __forceinline__ T block_reduce(T v, T* scratch, bool is_min) {
@@ -30,15 +32,19 @@ template <typename T> __device__ __forceinline__ T block_reduce(T v, T* scratch,
     return r;
 }
 
-template <typename real, typename cost_t>
+// VW = elements per thread and load (4 when M % 4 == 0, else 2; M = T * 2n is always even).
+template <typename real, typename cost_t, int VW>
 __global__ void __launch_bounds__(256)
 update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __restrict__ samples,
               real* __restrict__ means, double temperature, double step_size,
               real* __restrict__ weights, real* __restrict__ grad, real* __restrict__ means_prev,
               double* __restrict__ stats) {
+    typedef real vec __attribute__((ext_vector_type(VW)));
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    double* w = reinterpret_cast<double*>(lds_raw);      // [S]
+    double* w = reinterpret_cast<double*>(lds_raw);                  // [S] weights
+    int* idx = reinterpret_cast<int*>(lds_raw + (size_t)S * 8);      // [S] samples with weight != 0
     __shared__ double scratch[8];
+    __shared__ int nnz_s;
     const int p = blockIdx.x;
     const cost_t* c = costs + (size_t)p * S;
 
@@ -76,16 +82,62 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
         if (weights) weights[(size_t)p * S + s] = (real)ws;
     }
     __syncthreads();
+    // Samples whose weight underflowed to exactly 0 contribute exactly 0 to the sum below, so their
+    // rows need not be read at all (with the reference's hyper-parameters the softmax is one-hot
+    // and this turns a pass over [S, M] into a pass over one row).  Order-preserving compaction.
+    if (threadIdx.x < 64) {
+        int base = 0;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + (int)threadIdx.x;
+            const bool nz = s < S && w[s] != 0.;
+            const unsigned long long mask = __ballot(nz);
+            const int pos = base + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
+            if (nz) idx[pos] = s;
+            base += __popcll(mask);
+        }
+        if (threadIdx.x == 0) nnz_s = base;
+    }
+    __syncthreads();
+    const int nnz = nnz_s;
 
     const real* X = samples + (size_t)p * S * M;
     real* mu = means + (size_t)p * M;
-    for (int m = threadIdx.x; m < M; m += blockDim.x) {
-        const real mu_m = mu[m];
-        double acc = 0.;
-        for (int s = 0; s < S; ++s) acc += w[s] * (double)(X[(size_t)s * M + m] - mu_m);
-        if (grad) grad[(size_t)p * M + m] = (real)acc;
-        if (means_prev) means_prev[(size_t)p * M + m] = mu_m;
-        mu[m] = (real)((double)mu_m + step_size * acc);
+    for (int m = threadIdx.x * VW; m < M; m += blockDim.x * VW) {
+        const vec mu_m = *reinterpret_cast<const vec*>(mu + m);
+        double acc[VW];
+#pragma unroll
+        for (int i = 0; i < VW; ++i) acc[i] = 0.;
+        int k = 0;
+        for (; k + 4 <= nnz; k += 4) {                   // four rows in flight per thread
+            vec v[4];
+            double ws[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = idx[k + u];
+                ws[u] = w[s];
+                v[u] = *reinterpret_cast<const vec*>(X + (size_t)s * M + m);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < VW; ++i) acc[i] += ws[u] * (double)(v[u][i] - mu_m[i]);
+        }
+        for (; k < nnz; ++k) {
+            const int s = idx[k];
+            const double ws = w[s];
+            const vec v = *reinterpret_cast<const vec*>(X + (size_t)s * M + m);
+#pragma unroll
+            for (int i = 0; i < VW; ++i) acc[i] += ws * (double)(v[i] - mu_m[i]);
+        }
+        vec g, mn;
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+            g[i] = (real)acc[i];
+            mn[i] = (real)((double)mu_m[i] + step_size * acc[i]);
+        }
+        if (grad) *reinterpret_cast<vec*>(grad + (size_t)p * M + m) = g;
+        if (means_prev) *reinterpret_cast<vec*>(means_prev + (size_t)p * M + m) = mu_m;
+        *reinterpret_cast<vec*>(mu + m) = mn;
     }
 }
 
@@ -94,22 +146,21 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                          void* weights, void* grad, void* means_prev, double* stats,
                          hipStream_t stream) {
     const int M = T * 2 * n;
-    const size_t lds = (size_t)S * sizeof(double);
+    const size_t lds = (size_t)S * (sizeof(double) + sizeof(int));
     if (P <= 0) return hipSuccess;
     dim3 grid(P), block(256);
+#define UPD(REAL, COST, VW)                                                                          \
+    hipLaunchKernelGGL((update_kernel<REAL, COST, VW>), grid, block, lds, stream, M, S,             \
+                       (const COST*)costs, (const REAL*)samples, (REAL*)means, temperature, step_size, \
+                       (REAL*)weights, (REAL*)grad, (REAL*)means_prev, stats)
     if (dtype == SGPMP_F64) {
-        hipLaunchKernelGGL((update_kernel<double, double>), grid, block, lds, stream, M, S,
-                           (const double*)costs, (const double*)samples, (double*)means, temperature,
-                           step_size, (double*)weights, (double*)grad, (double*)means_prev, stats);
+        if (M % 4 == 0) UPD(double, double, 4); else UPD(double, double, 2);
     } else if (costs_dtype == SGPMP_F64) {
-        hipLaunchKernelGGL((update_kernel<float, double>), grid, block, lds, stream, M, S,
-                           (const double*)costs, (const float*)samples, (float*)means, temperature,
-                           step_size, (float*)weights, (float*)grad, (float*)means_prev, stats);
+        if (M % 4 == 0) UPD(float, double, 4); else UPD(float, double, 2);
     } else {
-        hipLaunchKernelGGL((update_kernel<float, float>), grid, block, lds, stream, M, S,
-                           (const float*)costs, (const float*)samples, (float*)means, temperature,
-                           step_size, (float*)weights, (float*)grad, (float*)means_prev, stats);
+        if (M % 4 == 0) UPD(float, float, 4); else UPD(float, float, 2);
     }
+#undef UPD
     return hipGetLastError();
 }
 
@@ -129,10 +180,12 @@ __global__ void is_weights_kernel(int n, int T, int P, const real* __restrict__ 
     const int p = (int)(idx / ((long long)d * (T + 1)));
     const real* mu = means + (size_t)p * T * d;
     double v;
+    if (t == T) {                       // spare block (kept for layout stability): unused by K3
+        out[idx] = (real)0;
+        return;
+    }
     if (t == 0) {
         v = ks * (double)mu[i];
-    } else if (t == T) {
-        v = kg >= 0. ? kg * (double)mu[(size_t)(T - 1) * d + i] : 0.;
     } else {
         const real* a = mu + (size_t)(t - 1) * d;      // mu_{t-1}
         const real* b = mu + (size_t)t * d;            // mu_t
@@ -143,6 +196,13 @@ __global__ void is_weights_kernel(int n, int T, int P, const real* __restrict__ 
             else e = (double)b[j] - (double)a[j];
             v += Qinv[i * d + j] * e;
         }
+    }
+    // goal block b = K_g mu_{T-1} of A x = (x_0, e_0.., x_{T-1}) folded into the per-waypoint weights:
+    // x_{T-1} = sum_j Phi^{T-2-j} e_j + Phi^{T-1} x_0 and (Phi^T)^k (b_p, b_v) = (b_p, k dt b_p + b_v)
+    if (kg >= 0.) {
+        const real* last = mu + (size_t)(T - 1) * d;
+        const double k = (double)(T - 1 - t);
+        v += (i < n) ? kg * (double)last[i] : kg * (k * dt * (double)last[i - n] + (double)last[i]);
     }
     out[idx] = (real)(temperature * v);
 }
