@@ -16,8 +16,10 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
                                                  uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 multiply (v_mad_u64_u32) per product instead of separate lo / hi multiplies
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -71,6 +73,12 @@ template <> struct NoiseGen<float> {
         e_pos = (t & 1) ? z[2] : z[0];
         e_vel = (t & 1) ? z[3] : z[1];
     }
+    // both waypoints of an even-aligned pair: e = (pos_t, vel_t, pos_{t+1}, vel_{t+1}); same stream as get()
+    __device__ __forceinline__ void get4(int t_even, float (&e)[4]) {
+        const Philox4 r = philox4x32_10((uint32_t)(t_even >> 1) | kk, c1, c2, c3, k0, k1);
+        box_muller_f32(r.x, r.y, e[0], e[1]);
+        box_muller_f32(r.z, r.w, e[2], e[3]);
+    }
 };
 
 template <> struct NoiseGen<double> {
@@ -83,5 +91,9 @@ template <> struct NoiseGen<double> {
     __device__ __forceinline__ void get(int t, double& e_pos, double& e_vel) {
         const Philox4 r = philox4x32_10((uint32_t)t | kk, c1, c2, c3 ^ 0x80000000u, k0, k1);
         box_muller_f64(r.x, r.y, r.z, r.w, e_pos, e_vel);
+    }
+    __device__ __forceinline__ void get4(int t_even, double (&e)[4]) {
+        get(t_even, e[0], e[1]);
+        get(t_even + 1, e[2], e[3]);
     }
 };

@@ -13,9 +13,12 @@
 #include "sgpmp_internal.h"
 #include "rng.h"
 
-// Waypoints are produced TC at a time into an LDS tile [samples][TC*d (+pad)] and flushed as whole
-// row segments with VW-wide vector stores (16 B per lane when the row pitch allows), so the wave
-// writes contiguous spans instead of 4-byte fragments 3.5 KB apart.
+// The kernel is VALU-bound (Philox + Box-Muller dominate), so the inner loop is kept lean:
+//   * two waypoints per trip = one Philox4x32 call = four normals (fp32);
+//   * the perturbation y is written to an LDS tile [samples][TC*d (+pad)]; the mean is added while the
+//     tile is flushed, once per VW-wide vector instead of per scalar;
+//   * tiles are flushed as whole row segments with VW-wide stores (16 B per lane when the row pitch
+//     allows), so a wave writes contiguous spans instead of 4-byte fragments 3.5 KB apart.
 #define SGPMP_SAMPLE_TC 16
 
 template <typename real, int VW>
@@ -41,29 +44,50 @@ sample_iso_kernel(int n, int T, int S, int spb, const real* __restrict__ coef /*
     NoiseGen<real> gen;
     gen.init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)s, (uint32_t)k);
     real p = 0, v = 0;
-    real* trow = tile + (size_t)sl * pitch;
+    real* trow = tile + (size_t)sl * pitch + k;
     const int rows = min(spb, S - s0);
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int tc = min(TC, T - t0);
         if (active) {
-            for (int tt = 0; tt < tc; ++tt) {
-                const int t = t0 + tt;
-                const real* c = coef + t * 8;
-                real e1, e2;
-                if (erow) { e1 = erow[t * d + k]; e2 = erow[t * d + n + k]; }
-                else gen.get(t, e1, e2);
-                const real pn = c[0] * e1 + c[3] * p + c[4] * v;
-                const real vn = c[1] * e1 + c[2] * e2 + c[5] * p + c[6] * v;
-                p = pn; v = vn;
-                trow[tt * d + k] = mu[t * d + k] + p;
-                trow[tt * d + n + k] = mu[t * d + n + k] + v;
+            const real* c = coef + (size_t)t0 * 8;
+            real* o = trow;
+            if (erow) {
+                const real* e = erow + (size_t)t0 * d + k;
+                for (int tt = 0; tt < tc; ++tt, c += 8, o += d, e += d) {
+                    const real e1 = e[0], e2 = e[n];
+                    const real pn = c[0] * e1 + c[3] * p + c[4] * v;
+                    const real vn = c[1] * e1 + c[2] * e2 + c[5] * p + c[6] * v;
+                    p = pn; v = vn;
+                    o[0] = p; o[n] = v;
+                }
+            } else {
+                int tt = 0;
+                for (; tt + 2 <= tc; tt += 2, c += 16, o += 2 * d) {     // t0 is even: one RNG block
+                    real e[4];
+                    gen.get4(t0 + tt, e);
+                    real pn = c[0] * e[0] + c[3] * p + c[4] * v;
+                    real vn = c[1] * e[0] + c[2] * e[1] + c[5] * p + c[6] * v;
+                    o[0] = pn; o[n] = vn;
+                    p = c[8] * e[2] + c[11] * pn + c[12] * vn;
+                    v = c[9] * e[2] + c[10] * e[3] + c[13] * pn + c[14] * vn;
+                    o[d] = p; o[d + n] = v;
+                }
+                if (tt < tc) {                                       // odd tail (last waypoint)
+                    real e1, e2;
+                    gen.get(t0 + tt, e1, e2);
+                    const real pn = c[0] * e1 + c[3] * p + c[4] * v;
+                    const real vn = c[1] * e1 + c[2] * e2 + c[5] * p + c[6] * v;
+                    p = pn; v = vn;
+                    o[0] = p; o[n] = v;
+                }
             }
         }
         __syncthreads();
         const int seg = tc * d / VW;                     // vectors per row segment
         for (int i = threadIdx.x; i < rows * seg; i += blockDim.x) {
             const int r = i / seg, j = i - r * seg;
-            const vec val = *reinterpret_cast<const vec*>(tile + (size_t)r * pitch + j * VW);
+            vec val = *reinterpret_cast<const vec*>(tile + (size_t)r * pitch + j * VW);
+            val += *reinterpret_cast<const vec*>(mu + (size_t)t0 * d + j * VW);       // x = mu + y
             *reinterpret_cast<vec*>(out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d + j * VW) = val;
         }
         __syncthreads();

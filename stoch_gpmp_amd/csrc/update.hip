@@ -168,7 +168,7 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
 template <typename real>
 __global__ void is_weights_kernel(int n, int T, int P, const real* __restrict__ means,
                                   const double* __restrict__ Qinv, double ks, double kg, double dt,
-                                  double temperature, real* __restrict__ out,
+                                  double temperature, int isotropic, real* __restrict__ out,
                                   double* __restrict__ zero_stats) {
     const int d = 2 * n;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,11 +190,18 @@ __global__ void is_weights_kernel(int n, int T, int P, const real* __restrict__ 
         const real* a = mu + (size_t)(t - 1) * d;      // mu_{t-1}
         const real* b = mu + (size_t)t * d;            // mu_t
         v = 0.;
-        for (int j = 0; j < d; ++j) {
-            double e;                                   // e_{t-1}(mu)_j = (mu_t - Phi mu_{t-1})_j
-            if (j < n) e = (double)b[j] - ((double)a[j] + dt * (double)a[n + j]);
-            else e = (double)b[j] - (double)a[j];
-            v += Qinv[i * d + j] * e;
+        if (isotropic) {                                // Q^-1 = q (x) I_n: two non-zeros per row
+            const int k = i < n ? i : i - n;
+            const double ep = (double)b[k] - ((double)a[k] + dt * (double)a[n + k]);
+            const double ev = (double)b[n + k] - (double)a[n + k];
+            v = Qinv[i * d + k] * ep + Qinv[i * d + n + k] * ev;
+        } else {
+            for (int j = 0; j < d; ++j) {
+                double e;                               // e_{t-1}(mu)_j = (mu_t - Phi mu_{t-1})_j
+                if (j < n) e = (double)b[j] - ((double)a[j] + dt * (double)a[n + j]);
+                else e = (double)b[j] - (double)a[j];
+                v += Qinv[i * d + j] * e;
+            }
         }
     }
     // goal block b = K_g mu_{T-1} of A x = (x_0, e_0.., x_{T-1}) folded into the per-waypoint weights:
@@ -217,10 +224,10 @@ hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& prior, con
     if (dtype == SGPMP_F64)
         hipLaunchKernelGGL((is_weights_kernel<double>), dim3(grid), dim3(block), 0, stream, n, T,
                            n_particles, (const double*)means, prior.Qinv, prior.ks, prior.kg, prior.dt,
-                           temperature, (double*)out, zero_stats);
+                           temperature, prior.isotropic, (double*)out, zero_stats);
     else
         hipLaunchKernelGGL((is_weights_kernel<float>), dim3(grid), dim3(block), 0, stream, n, T,
                            n_particles, (const float*)means, prior.Qinv, prior.ks, prior.kg, prior.dt,
-                           temperature, (float*)out, zero_stats);
+                           temperature, prior.isotropic, (float*)out, zero_stats);
     return hipGetLastError();
 }
