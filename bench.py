@@ -54,7 +54,8 @@ def build_planner(args, torch, rank, world, dev):
         P_local = args.particles or 1024
         S, T = args.samples or 128, args.traj_len or 64
         pl = W.hip_panda_planner(W.PANDA, T, P_local * world, S, ta, field_type=args.field, seed=0,
-                                 rank=rank, world_size=world)
+                                 rank=rank, world_size=world,
+                                 force_stats_allreduce=os.environ.get("SGPMP_BENCH_FORCE_DIST") == "1")
         obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres()).to(**ta)}
         name = (f"Panda 7-DoF, {P_local * world} particles ({P_local}/GPU) x {S} samples x {T} waypoints, "
                 f"GP + goal-prior + self-collision + 5 sphere obstacles ({args.field}), synthetic")
@@ -152,8 +153,11 @@ def main():
                              f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SGPMP_BENCH_FORCE_DIST") == "1"   # (1-rank RCCL smoke test)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pl, obs, name, P_local, S, T, dtype = build_planner(args, torch, rank, world, dev)
@@ -161,7 +165,7 @@ def main():
     d = pl.d_state_opt
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,7 +177,7 @@ def main():
         pl.optimize(opt_iters=1, **obs)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -229,7 +233,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, torch)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

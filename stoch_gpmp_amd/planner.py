@@ -116,6 +116,7 @@ class StochGPMP:
         self._engine = None
         self._draw = 0
         self._pending_reduce = []
+        self._force_reduce = bool(kwargs.get('force_stats_allreduce', False))   # 1-rank RCCL smoke test
 
         self.reset(start_state, multi_goal_states, initial_particle_means=initial_particle_means)
 
@@ -268,7 +269,7 @@ class StochGPMP:
 
     def _reduce_stats(self, slot):
         # (a shard run stand-alone -- world_size > 1 without a process group -- has no peers to reduce with)
-        if self.world_size > 1 and torch.distributed.is_initialized():
+        if (self.world_size > 1 or self._force_reduce) and torch.distributed.is_initialized():
             self._pending_reduce.append(allreduce_stats_async(self._stats[slot], self.process_group))
             if len(self._pending_reduce) > 1:           # never gate the next iteration's kernels
                 self._pending_reduce.pop(0).wait()
