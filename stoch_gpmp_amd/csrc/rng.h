@@ -31,7 +31,7 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 __device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& z0, float& z1) {
     const float u1 = fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
     const float u2 = (float)b * 2.3283064365386963e-10f;            // revolutions
-    const float r = sqrtf(-2.0f * 0.6931471805599453f * __log2f(u1));
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * 0.6931471805599453f * __log2f(u1));   // raw v_sqrt_f32
     z0 = r * __builtin_amdgcn_cosf(u2);                              // cos(2 pi u2)
     z1 = r * __builtin_amdgcn_sinf(u2);
 }

@@ -25,7 +25,7 @@ template <typename real, int VW>
 __global__ void __launch_bounds__(256)
 sample_iso_kernel(int n, int T, int S, int spb, const real* __restrict__ coef /*[T][8]*/,
                   const real* __restrict__ means, const real* __restrict__ eps, int eps_modes,
-                  int eps_mode_offset, int mode_offset, uint64_t seed, uint64_t draw,
+                  int eps_mode_offset, int mode_offset, uint64_t seed, uint64_t draw, int lpr_shift,
                   real* __restrict__ out) {
     typedef real vec __attribute__((ext_vector_type(VW)));
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -83,12 +83,19 @@ sample_iso_kernel(int n, int T, int S, int spb, const real* __restrict__ coef /*
             }
         }
         __syncthreads();
+        // flush: each group of 2^lpr_shift lanes owns one row at a time (no integer division)
         const int seg = tc * d / VW;                     // vectors per row segment
-        for (int i = threadIdx.x; i < rows * seg; i += blockDim.x) {
-            const int r = i / seg, j = i - r * seg;
-            vec val = *reinterpret_cast<const vec*>(tile + (size_t)r * pitch + j * VW);
-            val += *reinterpret_cast<const vec*>(mu + (size_t)t0 * d + j * VW);       // x = mu + y
-            *reinterpret_cast<vec*>(out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d + j * VW) = val;
+        const int lpr = 1 << lpr_shift;
+        const int groups = blockDim.x >> lpr_shift;
+        const int j0 = threadIdx.x & (lpr - 1);
+        for (int r = threadIdx.x >> lpr_shift; r < rows; r += groups) {
+            const real* trow_r = tile + (size_t)r * pitch;
+            real* orow = out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d;
+            for (int j = j0; j < seg; j += lpr) {
+                vec val = *reinterpret_cast<const vec*>(trow_r + j * VW);
+                val += *reinterpret_cast<const vec*>(mu + (size_t)t0 * d + j * VW);   // x = mu + y
+                *reinterpret_cast<vec*>(orow + j * VW) = val;
+            }
         }
         __syncthreads();
     }
@@ -158,12 +165,15 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
         // widest store that every row segment start is aligned to: rows are T*d reals apart and
         // tiles start every 16*d reals; d is even
         const bool v16 = ((size_t)T * d * sizeof(real)) % 16 == 0;
+        const int vw = (f64 || !v16) ? 2 : 4;
+        int lpr_shift = 0;                               // lanes that share one row while flushing
+        while ((1 << lpr_shift) < SGPMP_SAMPLE_TC * d / vw && lpr_shift < 6) ++lpr_shift;
         if (f64 || !v16)
             hipLaunchKernelGGL((sample_iso_kernel<real, 2>), grid, block, lds, stream, n, T, S, spb, coef,
-                               means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, out);
+                               means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, lpr_shift, out);
         else
             hipLaunchKernelGGL((sample_iso_kernel<real, 4>), grid, block, lds, stream, n, T, S, spb, coef,
-                               means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, out);
+                               means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, lpr_shift, out);
         return hipGetLastError();
     }
     const real* G = f64 ? (const real*)prior.G : (const real*)prior.G32;
