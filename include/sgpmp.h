@@ -59,6 +59,7 @@ enum { SGPMP_FIELD_RBF = 0, SGPMP_FIELD_SDF = 1, SGPMP_FIELD_OCCUPANCY = 2 };
 #define SGPMP_MAX_JOINTS 16
 #define SGPMP_MAX_DOF 8            /* state blocks are handled as one 16x16 MFMA tile        */
 #define SGPMP_MAX_INTERP 8
+#define SGPMP_STAT_SHARDS 64       /* statistics buffers are double[SGPMP_STAT_SHARDS][4]; sum over shards */
 
 typedef struct sgpmp_dims {
     int32_t n_dof;                 /* n;  d = 2n                                                  */
@@ -156,16 +157,18 @@ int sgpmp_is_weights(sgpmp_ctx* ctx, const void* means, int n_particles, double 
  * grad = sum_s w (x - mu), means += step_size * grad.  costs_dtype: SGPMP_F64 or the ctx dtype.
  * weights [P,S] and grad [P,T,d] in ctx dtype (may be NULL). means_prev [P,T,d] (may be NULL)
  * receives the PRE-update means, which is what optimize() returns (planner.py:252-253).
- * stats: DEVICE double[4] accumulated (sum of costs, sum over particles of min cost, particle
- * count, reserved) or NULL. */
+ * stats: DEVICE double[SGPMP_STAT_SHARDS][4] or NULL; each workgroup adds (sum of costs, min cost,
+ * 1, -) of its particle to one shard -- the consumer sums the shards (sharding avoids serialising a
+ * thousand atomics on one address). */
 int sgpmp_update(sgpmp_ctx* ctx, const void* costs, int costs_dtype, const void* samples,
                  void* means, double temperature, double step_size, void* weights, void* grad,
                  void* means_prev, double* stats, void* stream);
 
 /* One body of the loop at planner.py:289-299 for the context's particle shard:
  * K5 -> K2 -> K3 -> K4 on `stream`.  samples [P,S,T,d] is written (state_samples of the iteration);
- * costs [P,S] ctx dtype may be NULL. means updated in place. stats (DEVICE double[4] or NULL) is
- * zeroed at the start of the step and holds this step's sums afterwards. */
+ * costs [P,S] ctx dtype may be NULL. means updated in place. stats (DEVICE
+ * double[SGPMP_STAT_SHARDS][4] or NULL) is zeroed at the start of the step and holds this step's
+ * sharded sums afterwards. */
 int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, int eps_modes,
                int eps_mode_offset, void* means, void* samples, void* costs, void* weights,
                void* grad, void* means_prev, const void* spheres, int n_spheres, double temperature,

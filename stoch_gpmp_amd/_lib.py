@@ -15,6 +15,7 @@ COST_GP, COST_GOAL_PRIOR, COST_GRID, COST_SPHERES, COST_SELF = 1, 2, 3, 4, 5
 FIELD_RBF, FIELD_SDF, FIELD_OCCUPANCY = 0, 1, 2
 FLAG_GP_START, FLAG_SDF_CLAMP = 1, 16
 MAX_TERMS, MAX_JOINTS, MAX_DOF, MAX_INTERP = 8, 16, 8, 8
+STAT_SHARDS = 64
 OK, EINVAL, ENOTPD, EHIP, ESTATE = 0, -1, -2, -3, -4
 
 

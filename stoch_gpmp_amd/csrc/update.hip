@@ -70,9 +70,12 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
         const double tot = block_reduce<double>(csum, scratch, false);
         const double mn = block_reduce<double>(cmin, scratch, true);
         if (threadIdx.x == 0) {
-            atomicAdd(&stats[0], tot);
-            atomicAdd(&stats[1], mn);
-            atomicAdd(&stats[2], 1.0);
+            // 64 shards of 4 doubles: a thousand workgroups adding to one address serialise
+            // at the memory side (~30 us); the consumer sums the shards
+            double* sh = stats + (blockIdx.x & (SGPMP_STAT_SHARDS - 1)) * 4;
+            atomicAdd(&sh[0], tot);
+            atomicAdd(&sh[1], mn);
+            atomicAdd(&sh[2], 1.0);
         }
     }
     const double invZ = 1. / Z;
@@ -172,7 +175,7 @@ __global__ void is_weights_kernel(int n, int T, int P, const real* __restrict__ 
                                   double* __restrict__ zero_stats) {
     const int d = 2 * n;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (zero_stats && idx < 4) zero_stats[idx] = 0.;      // this step's statistics start from zero
+    if (zero_stats && idx < SGPMP_STAT_SHARDS * 4) zero_stats[idx] = 0.;   // this step's statistics start from zero
     const long long total = (long long)P * (T + 1) * d;
     if (idx >= total) return;
     const int i = (int)(idx % d);

@@ -211,7 +211,7 @@ class StochGPMP:
         self._weights_buf = torch.empty(Pl, S, **ta)
         self._grad = torch.empty(Pl, T, d, **ta)
         self._means_prev = torch.empty(Pl, T, d, **ta)
-        self._stats = torch.zeros(2, 4, device=ta['device'], dtype=torch.float64)
+        self._stats = torch.zeros(2, L.STAT_SHARDS, 4, device=ta['device'], dtype=torch.float64)
         self._stats_slot = 0
         self._Sigma_inv = None
         self._obs_cache = (None, None)
@@ -280,7 +280,7 @@ class StochGPMP:
         for w in self._pending_reduce:
             w.wait()
         self._pending_reduce = []
-        s = self._stats[self._stats_slot ^ 1].cpu()
+        s = self._stats[self._stats_slot ^ 1].sum(0).cpu()      # sum the shards
         cnt = max(float(s[2]), 1.0)
         return float(s[0]) / cnt, float(s[1]) / cnt
 
