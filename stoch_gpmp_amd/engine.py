@@ -188,6 +188,26 @@ class Engine:
                                         float(temperature), float(step_size), L.ptr(stats),
                                         L.stream_ptr()))
 
+    def prepare_step(self, seed, means, samples, temperature, step_size, costs=None, weights=None,
+                     grad=None, means_prev=None, spheres=None, stats=None):
+        """Pre-bind every argument of sgpmp_step except the draw counter and the stream (the buffers
+        are persistent, so their device pointers do not change): the returned callable costs one
+        ctypes call per iteration, which matters for the small, launch-bound configurations."""
+        fn, ctx = self.lib.sgpmp_step, self._ctx
+        n_sph = 0 if spheres is None else spheres.shape[0]
+        fixed = (L.ptr(means), L.ptr(samples), L.ptr(costs), L.ptr(weights), L.ptr(grad),
+                 L.ptr(means_prev), L.ptr(spheres), n_sph, float(temperature), float(step_size),
+                 L.ptr(stats))
+        seed = int(seed)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+        def call(draw):
+            if torch.cuda.current_device() != dev_index:
+                torch.cuda.set_device(dev_index)
+            L.check(fn(ctx, seed, draw, None, 0, 0, *fixed,
+                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return call
+
     def fk(self, q):
         self._chk(q, "q")
         B = q.shape[0]

@@ -205,6 +205,7 @@ class StochGPMP:
 
         # persistent buffers of the iteration
         self.state_samples = torch.empty(Pl, S, T, d, **ta)
+        self._samples_buf = self.state_samples          # iteration buffer (pointers are pre-bound)
         self._costs = torch.empty(Pl, S, **ta)
         self._costs64 = torch.empty(Pl, S, device=ta['device'], dtype=torch.float64)
         self._costs64_fresh = False
@@ -213,6 +214,11 @@ class StochGPMP:
         self._means_prev = torch.empty(Pl, T, d, **ta)
         self._stats = torch.zeros(2, L.STAT_SHARDS, 4, device=ta['device'], dtype=torch.float64)
         self._stats_slot = 0
+        self._step_calls = {}
+        # views handed back by optimize(): created once, the buffers are persistent
+        self._weights = self._weights_buf.view(-1, S, 1, 1)
+        self._views = (self._means_prev[..., :n], self._means_prev[..., -n:],
+                       self.state_samples[..., :n], self.state_samples[..., -n:])
         self._Sigma_inv = None
         self._obs_cache = (None, None)
 
@@ -287,19 +293,36 @@ class StochGPMP:
     # ------------------------------------------------------------------------------- the loop
     def step(self, **observation):
         """One body of the loop at planner.py:289-299 on this rank's particle shard."""
+        self.state_samples = self._samples_buf           # (sample_trajectories may have re-pointed it)
         if not self._native_cost:
             return self._step_foreign_cost(**observation)
         slot = self._stats_slot
         if self.num_particles_local > 0:
-            self._engine.step(self.seed, self._draw, self.particle_means, self.state_samples,
-                              self.temperature, self.step_size, costs=self._costs,
-                              weights=self._weights_buf, grad=self._grad, means_prev=self._means_prev,
-                              spheres=self._spheres(observation), eps=self._draw_eps(),
-                              eps_mode_offset=self.p0, stats=self._stats[slot])
+            if self.noise == 'philox':
+                # hot path: all arguments except the draw counter are pre-bound (one ctypes call)
+                sph = observation.get('obstacle_spheres', None)
+                key = (slot, None if sph is None else (id(sph), sph._version), self.temperature,
+                       self.step_size, self.particle_means.data_ptr(), self.state_samples.data_ptr())
+                call = self._step_calls.get(key)
+                if call is None:
+                    if len(self._step_calls) > 8:
+                        self._step_calls.clear()
+                    call = self._engine.prepare_step(
+                        self.seed, self.particle_means, self.state_samples, self.temperature,
+                        self.step_size, costs=self._costs, weights=self._weights_buf, grad=self._grad,
+                        means_prev=self._means_prev, spheres=self._spheres(observation),
+                        stats=self._stats[slot])
+                    self._step_calls[key] = call
+                call(self._draw)
+            else:
+                self._engine.step(self.seed, self._draw, self.particle_means, self.state_samples,
+                                  self.temperature, self.step_size, costs=self._costs,
+                                  weights=self._weights_buf, grad=self._grad, means_prev=self._means_prev,
+                                  spheres=self._spheres(observation), eps=self._draw_eps(),
+                                  eps_mode_offset=self.p0, stats=self._stats[slot])
         self._draw += 1
         self._reduce_stats(slot)
         self._stats_slot ^= 1
-        self._weights = self._weights_buf.view(-1, self.num_samples, 1, 1)
         return self._costs, self._grad
 
     def _step_foreign_cost(self, **observation):
@@ -334,6 +357,7 @@ class StochGPMP:
 
     def sample_and_eval(self, **observation):
         """planner.py:239-261."""
+        self.state_samples = self._samples_buf
         eps = self._draw_eps()
         self._engine.sample(L.PRIOR_SAMPLE, self.seed, self._draw, self.particle_means,
                             self.num_samples, out=self.state_samples, eps=eps,
@@ -353,7 +377,6 @@ class StochGPMP:
         self._engine.update(costs, traj_samples.contiguous(), self.particle_means, self.temperature,
                             self.step_size, weights=self._weights_buf, grad=self._grad,
                             means_prev=self._means_prev)
-        self._weights = self._weights_buf.view(-1, self.num_samples, 1, 1)
         return self._grad
 
     def optimize(self, opt_iters=None, debug=False, **observation):
@@ -369,11 +392,7 @@ class StochGPMP:
             costs, approx_grad = self.step(**observation)
             if debug and opt_step % 50 == 0:
                 print_info(opt_step, opt_iters, start_time_iter, start_time, costs)
-        n = self.n_dof
-        state_trajectories = self.state_samples[..., :n]
-        control_samples = self.state_samples[..., -n:]
-        state_particles = self._means_prev[..., :n]
-        control_particles = self._means_prev[..., -n:]
+        state_particles, control_particles, state_trajectories, control_samples = self._views
         self._recent_control_samples = control_samples
         self._recent_control_particles = control_particles
         self._recent_state_trajectories = state_trajectories
@@ -401,11 +420,13 @@ class StochGPMP:
         if self.noise == 'torch':
             eps = torch.randn(num_samples_per_particle, self.num_particles, T * d,
                               dtype=self.tensor_args['dtype']).to(self.tensor_args['device'])
-        self.state_samples = self._engine.sample(
+        # (a fresh tensor: the iteration buffers keep their size and their pre-bound pointers)
+        fresh = self._engine.sample(
             L.PRIOR_SAMPLE, self.seed, self._draw, self.particle_means, num_samples_per_particle,
             eps=eps, eps_mode_offset=self.p0 if eps is not None else 0, mode_offset=self.p0)
         self._draw += 1
-        return self.state_samples[..., :self.n_dof], self.state_samples[..., -self.n_dof:]
+        self.state_samples = fresh                       # as the reference does (planner.py:341)
+        return fresh[..., :self.n_dof], fresh[..., -self.n_dof:]
 
     def gather_particle_means(self):
         """All ranks' particle means [P,T,d] (RCCL all-gather over xGMI); identity on one GPU."""

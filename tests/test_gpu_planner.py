@@ -109,6 +109,27 @@ def test_panda_small_matches_oracle_fp64(field_type):
         assert rel_err(pl.particle_means, ora.particle_means) < 1e-6
 
 
+def test_panda_multigoal_long_horizon_matches_oracle_fp64():
+    """BASELINE config 5 shape in miniature: Panda, 2 goals, T = 128 (two 64-waypoint passes per
+    wave, goal lookup by particle // nppg), fp64, sdf field, against the oracle on the same noise."""
+    c = SC.PANDA
+    T, nppg, S = 128, 2, 5
+    n = 7
+    goals = [c["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n]
+    sph = torch.as_tensor(SC.panda_spheres(num=7, seed=4)).to(**F64)
+    ora = SC.oracle_panda_planner(c, T, nppg, S, field_type='sdf', seed=8, goals=goals)
+    ora.draw_discarded()
+    pl = hip_panda_planner(c, T, nppg, S, F64, field_type='sdf', seed=8, noise='torch', goals=goals)
+    assert pl.num_particles == 4 and rel_err(pl.particle_means, ora.particle_means) < 1e-6
+    for it in range(3):
+        st = torch.get_rng_state()
+        costs_o, _ = ora.step(obstacle_spheres=sph.cpu())
+        torch.set_rng_state(st)
+        _, _, _, _, costs, _ = pl.optimize(obstacle_spheres=sph)
+        assert rel_err(costs, costs_o) < 1e-8
+        assert rel_err(pl.particle_means, ora.particle_means) < 1e-6
+
+
 # --------------------------------------------------------------------------- fp32 compute path
 def test_planar_fp32_against_fp64_oracle_same_noise(golden):
     """fp32 kernels (prior factored in fp64) fed the oracle's noise, compared with the fp64 oracle:
