@@ -229,6 +229,11 @@ def gen_chain(name, chain):
                + ", ".join(f"{mult[l]}.f" for l in reps) + "}; return t[a]; }")
     out.append(f"    static __host__ __device__ constexpr bool is_static(int a) {{ constexpr bool t[{len(reps)}] = {{"
                + ", ".join("true" if static[l] else "false" for l in reps) + "}; return t[a]; }")
+    dyn = [a for a, l in enumerate(reps) if not static[l]]
+    out.insert(out.index(f"    static constexpr int NPAIR = {len(pairs)};      // q-dependent pairs of distinct links") + 1,
+               f"    static constexpr int NDYN = {len(dyn)};        // distinct links whose position depends on q")
+    out.append(f"    static __host__ __device__ constexpr int dyn_link(int a) {{ constexpr int t[{max(len(dyn), 1)}] = {{"
+               + ", ".join(map(str, dyn or [0])) + "}; return t[a]; }")
     np_ = max(len(pairs), 1)
     pi = [p[0] for p in pairs] or [0]
     pj = [p[1] for p in pairs] or [0]
@@ -255,7 +260,8 @@ def gen_chain(name, chain):
 def main():
     dst = os.path.join(HERE, "..", "chain_code_generated.h")
     out = ["// GENERATED by gen/chain_codegen.py -- do not edit; re-run the generator instead.",
-           "#pragma once", "#include <hip/hip_runtime.h>", ""]
+           "#pragma once", "#include <hip/hip_runtime.h>",
+           "#pragma clang diagnostic ignored \"-Wunused-variable\"", ""]
     for name, chain in REGISTRY.items():
         out += gen_chain(name, chain)
         out.append("")

@@ -29,6 +29,30 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float a, float b
             for (int r = 0; r < 16; ++r) {
                 u0 = u0 * 0xD2511F53u + 1; u1 = __umulhi(u1, 0xCD9E8D57u) + 3; u2 = u2 * 0x9E3779B9u + 5; u3 = __umulhi(u3, 0xBB67AE85u) + 7;
             }
+        } else if (OP == 4) {      // fma with three VGPR operands (no scalar / constant source)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                x0 = fmaf(x0, x4, x5); x1 = fmaf(x1, x5, x6); x2 = fmaf(x2, x6, x7); x3 = fmaf(x3, x7, x4);
+                x4 = fmaf(x4, x0, x1); x5 = fmaf(x5, x1, x2); x6 = fmaf(x6, x2, x3); x7 = fmaf(x7, x3, x0);
+            }
+        } else if (OP == 6) {      // packed fma, all operands VGPR pairs
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p0 = __builtin_elementwise_fma(p0, p1, p2); p1 = __builtin_elementwise_fma(p1, p2, p3);
+                p2 = __builtin_elementwise_fma(p2, p3, p0); p3 = __builtin_elementwise_fma(p3, p0, p1);
+            }
+        } else if (OP == 7) {      // fma with two VGPR sources and one scalar
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                x0 = fmaf(x0, a, x4); x1 = fmaf(x1, a, x5); x2 = fmaf(x2, b, x6); x3 = fmaf(x3, b, x7);
+                x4 = fmaf(x4, a, x0); x5 = fmaf(x5, a, x1); x6 = fmaf(x6, b, x2); x7 = fmaf(x7, b, x3);
+            }
+        } else if (OP == 5) {      // mul / add / sub with two VGPR operands
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                x0 = x0 * x4; x1 = x1 + x5; x2 = x2 - x6; x3 = x3 * x7;
+                x4 = x4 + x0; x5 = x5 * x1; x6 = x6 + x2; x7 = x7 - x3;
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -53,12 +77,12 @@ template <int OP> double run(int blocks_per_cu, int iters, float* d_out) {
 
 int main() {
     float* d_out; hipMalloc(&d_out, sizeof(float) * 256 * 8 * 256);
-    const char* names[4] = {"v_fma_f32", "v_exp_f32", "int mul lo/hi (+add)", "v_pk_fma_f32"};
-    const int per_iter[4] = {64, 64, 64 /*mul*/ , 64};
-    for (int op = 0; op < 4; ++op)
-        for (int bpc = 1; bpc <= 8; bpc *= 2) {
+    const char* names[8] = {"v_fma_f32 (1 vgpr src)", "v_exp_f32", "int mul lo/hi (+add)", "v_pk_fma_f32 (1 vgpr src)", "v_fma_f32 (3 vgpr src)", "v_mul/add (2 vgpr src)", "v_pk_fma_f32 (3 vgpr src)", "v_fma_f32 (2 vgpr + sgpr)"};
+    const int per_iter[8] = {64, 64, 64 /*mul*/ , 64, 64, 64, 64, 64};
+    for (int op = 0; op < 8; ++op)
+        for (int bpc = 2; bpc <= 8; bpc *= 4) {
             const int iters = 20000;
-            double ms = op == 0 ? run<0>(bpc, iters, d_out) : op == 1 ? run<1>(bpc, iters, d_out) : op == 2 ? run<2>(bpc, iters, d_out) : run<3>(bpc, iters, d_out);
+            double ms = op == 0 ? run<0>(bpc, iters, d_out) : op == 1 ? run<1>(bpc, iters, d_out) : op == 2 ? run<2>(bpc, iters, d_out) : op == 3 ? run<3>(bpc, iters, d_out) : op == 4 ? run<4>(bpc, iters, d_out) : op == 5 ? run<5>(bpc, iters, d_out) : op == 6 ? run<6>(bpc, iters, d_out) : run<7>(bpc, iters, d_out);
             // waves per SIMD = bpc (256-thread block = 4 waves = 1 per SIMD)
             const double inst_per_simd = (double)bpc * iters * per_iter[op];
             const double ns_per_inst = ms * 1e6 / inst_per_simd;
