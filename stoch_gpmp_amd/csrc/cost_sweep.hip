@@ -489,6 +489,7 @@ static bool make_flat(const CostProgram& p, FlatProg<real>& f) {
 }
 
 #include "cost_sweep_kernel.inc"
+#include "cost_sweep_dual.inc"
 
 template <typename real>
 static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const ChainDev* d_chain,
@@ -527,6 +528,20 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
     FlatProg<real> F;
     const bool flat = make_flat<real>(h_prog, F) && !getenv("SGPMP_NO_FLAT_PROGRAM");
     if (reg && h_chain.plan.codegen_id == 1 && n == ChainCode_panda::N && !getenv("SGPMP_NO_CHAIN_CODEGEN")) {
+        if constexpr (sizeof(real) == 4) {
+            // two trajectories per wave on packed fp32 math (cost_sweep_dual.inc) when rows pair up
+            const bool pairs_ok = (batch_offset % 2 == 0) && (!isw || a.rows_per_particle % 2 == 0) &&
+                                  (!F.has_goal || F.goal.rows_per_goal % 2 == 0);
+            const bool sph_ok = !F.has_sph || ((F.sph.flags & 15) == SGPMP_FIELD_RBF && n_spheres <= SGPMP_SPH_LDS);
+            if (flat && !F.has_grid && pairs_ok && sph_ok && !getenv("SGPMP_NO_DUAL_SWEEP")) {
+                long long pblocks = ((batch + 1) / 2 + 3) / 4;
+                if (pblocks > cap) pblocks = cap;
+                if (pblocks < 1) pblocks = 1;
+                hipLaunchKernelGGL((cost_sweep_dual_kernel<ChainCode_panda::N, ChainCode_panda>),
+                                   dim3((unsigned)pblocks), dim3(256), 0, stream, a, F);
+                return hipGetLastError();
+            }
+        }
         if (flat)
             hipLaunchKernelGGL((cost_sweep_kernel<real, ChainCode_panda::N, 1000, true>), dim3((unsigned)blocks),
                                dim3(256), 0, stream, a, P, F);
