@@ -23,29 +23,36 @@
 
 template <typename real, int VW>
 __global__ void __launch_bounds__(256)
-sample_iso_kernel(int n, int T, int S, int spb, const real* __restrict__ coef /*[T][8]*/,
+sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*[T][8]*/,
                   const real* __restrict__ means, const real* __restrict__ eps, int eps_modes,
                   int eps_mode_offset, int mode_offset, uint64_t seed, uint64_t draw, int lpr_shift,
                   real* __restrict__ out) {
+    // Each WAVE owns spw = 64 / n samples (one lane per (sample, dof)) and its own rows of the LDS
+    // tile, so producing a tile and flushing it need no workgroup barrier: waves run out of step and
+    // one wave's stores overlap the others' arithmetic.
     typedef real vec __attribute__((ext_vector_type(VW)));
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    real* tile = reinterpret_cast<real*>(lds_raw);
     constexpr int TC = SGPMP_SAMPLE_TC;
     const int m = blockIdx.y;
-    const int sl = threadIdx.x / n, k = threadIdx.x - sl * n;
-    const int s0 = blockIdx.x * spb;
-    const int s = s0 + sl;
-    const bool active = sl < spb && s < S;
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int slw = ln / n, k = ln - slw * n;               // sample within the wave, dof
+    const int s0 = (blockIdx.x * (blockDim.x >> 6) + wv) * spw;   // first sample of this wave
+    const int s = s0 + slw;
+    const bool active = slw < spw && s < S;
     const int d = 2 * n;
     const int pitch = TC * d + 4;                        // reals per tile row (padded, VW-aligned)
+    real* tile = reinterpret_cast<real*>(lds_raw) + (size_t)wv * spw * pitch;     // this wave's rows
     const size_t M = (size_t)T * d;
     const real* mu = means + (size_t)m * M;
     const real* erow = (eps && active) ? eps + ((size_t)s * eps_modes + eps_mode_offset + m) * M : nullptr;
     NoiseGen<real> gen;
     gen.init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)s, (uint32_t)k);
     real p = 0, v = 0;
-    real* trow = tile + (size_t)sl * pitch + k;
-    const int rows = min(spb, S - s0);
+    real* trow = tile + (size_t)slw * pitch + k;
+    const int rows = min(spw, S - s0);                   // rows of this wave that exist (may be <= 0)
+    const int lpr = 1 << lpr_shift;
+    const int groups = 64 >> lpr_shift;
+    const int j0 = ln & (lpr - 1);
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int tc = min(TC, T - t0);
         if (active) {
@@ -82,13 +89,12 @@ sample_iso_kernel(int n, int T, int S, int spb, const real* __restrict__ coef /*
                 }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // tile rows are wave-private
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // flush: each group of 2^lpr_shift lanes owns one row at a time (no integer division)
         const int seg = tc * d / VW;                     // vectors per row segment
-        const int lpr = 1 << lpr_shift;
-        const int groups = blockDim.x >> lpr_shift;
-        const int j0 = threadIdx.x & (lpr - 1);
-        for (int r = threadIdx.x >> lpr_shift; r < rows; r += groups) {
+        for (int r = ln >> lpr_shift; r < rows; r += groups) {
             const real* trow_r = tile + (size_t)r * pitch;
             real* orow = out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d;
             for (int j = j0; j < seg; j += lpr) {
@@ -97,7 +103,9 @@ sample_iso_kernel(int n, int T, int S, int spb, const real* __restrict__ coef /*
                 *reinterpret_cast<vec*>(orow + j * VW) = val;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -158,10 +166,11 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
     if (prior.isotropic) {
         const real* coef = f64 ? (const real*)prior.iso64 : (const real*)prior.iso32;
         const int d = 2 * n;
-        int spb = 256 / n;
-        if (spb > S) spb = S;
-        dim3 grid((S + spb - 1) / spb, n_modes), block(((spb * n + 63) / 64) * 64);
-        const size_t lds = (size_t)spb * (SGPMP_SAMPLE_TC * d + 4) * sizeof(real);
+        const int spw = 64 / n;                          // samples per wave (one lane per (sample, dof))
+        int waves = (S + spw - 1) / spw;                 // waves needed per mode
+        const int wpb = waves < 4 ? waves : 4;
+        dim3 grid((waves + wpb - 1) / wpb, n_modes), block(64 * wpb);
+        const size_t lds = (size_t)wpb * spw * (SGPMP_SAMPLE_TC * d + 4) * sizeof(real);
         // widest store that every row segment start is aligned to: rows are T*d reals apart and
         // tiles start every 16*d reals; d is even
         const bool v16 = ((size_t)T * d * sizeof(real)) % 16 == 0;
@@ -169,10 +178,10 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
         int lpr_shift = 0;                               // lanes that share one row while flushing
         while ((1 << lpr_shift) < SGPMP_SAMPLE_TC * d / vw && lpr_shift < 6) ++lpr_shift;
         if (f64 || !v16)
-            hipLaunchKernelGGL((sample_iso_kernel<real, 2>), grid, block, lds, stream, n, T, S, spb, coef,
+            hipLaunchKernelGGL((sample_iso_kernel<real, 2>), grid, block, lds, stream, n, T, S, spw, coef,
                                means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, lpr_shift, out);
         else
-            hipLaunchKernelGGL((sample_iso_kernel<real, 4>), grid, block, lds, stream, n, T, S, spb, coef,
+            hipLaunchKernelGGL((sample_iso_kernel<real, 4>), grid, block, lds, stream, n, T, S, spw, coef,
                                means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, lpr_shift, out);
         return hipGetLastError();
     }
