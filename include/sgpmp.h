@@ -49,11 +49,14 @@ enum {
     SGPMP_COST_GOAL_PRIOR = 2,  /* CostGoalPrior.eval                    cost_functions.py:376-388         */
     SGPMP_COST_GRID = 3,        /* CostCollision + ObstacleMap           cost_functions.py:247-261, obst_map.py:164-185 */
     SGPMP_COST_SPHERES = 4,     /* CostCollision + LinkDistanceField     fields.py:63-86                   */
-    SGPMP_COST_SELF = 5         /* CostCollision + LinkSelfDistanceField fields.py:114-124                 */
+    SGPMP_COST_SELF = 5,        /* CostCollision + LinkSelfDistanceField fields.py:114-124                 */
+    SGPMP_COST_EE_GOAL = 6      /* CostGoal + EESE3DistanceField         cost_functions.py:282-321, fields.py:130-153
+                                   (SE3_distance itself is third-party and un-vendored: DESIGN.md)      */
 };
 enum { SGPMP_FIELD_RBF = 0, SGPMP_FIELD_SDF = 1, SGPMP_FIELD_OCCUPANCY = 2 };
 #define SGPMP_FLAG_GP_START 1      /* GP term includes the start-state unary factor (CostGP)  */
 #define SGPMP_FLAG_SDF_CLAMP 16    /* LinkDistanceField(clamp_sdf=True)                       */
+#define SGPMP_FLAG_EE_SQUARE 32    /* EESE3DistanceField(square=True)                         */
 
 #define SGPMP_MAX_TERMS 8
 #define SGPMP_MAX_JOINTS 16
@@ -81,7 +84,9 @@ typedef struct sgpmp_cost_desc {
     double sigma2;                 /* GP: sigma_start; SELF: margin                               */
     double dt;                     /* GP: time step                                               */
     const void* data;              /* GP: HOST double[d] start state; GOAL_PRIOR: HOST double[G*d]
-                                      goal states; GRID: DEVICE grid [dim0,dim1] in ctx dtype      */
+                                      goal states; GRID: DEVICE grid [dim0,dim1] in ctx dtype;
+                                      EE_GOAL: HOST double[16] target frame (row-major 4x4), with
+                                      p0 = w_pos, p1 = w_rot                                      */
     int32_t dim0, dim1;            /* GOAL_PRIOR: G, nppg*S of the cost (cost_functions.py:379);
                                       GRID: map.shape[0], map.shape[1]                            */
     double p0, p1, p2;             /* GRID: cell_size, c_offset[0], c_offset[1] (obst_map.py:129-140) */

@@ -235,6 +235,29 @@ def cost_collision_links(x_trajs, field_fn, sigma):
     return (1. / sigma ** 2) * err.sum(1)
 
 
+def se3_distance(H, H_target, w_pos=1., w_rot=1.):
+    """w_pos |p - p*| + w_rot angle(R*^T R).  PARITY UNPINNED: the reference calls
+    torch_robotics' SE3_distance (fields.py:4,143-144), a dependency that is neither vendored nor
+    version-pinned (setup.py) -- this is the definition this build documents."""
+    dp = (H[..., :3, 3] - H_target[..., :3, 3]).norm(dim=-1)
+    Rr = H_target[..., :3, :3].transpose(-1, -2) @ H[..., :3, :3]
+    c = ((Rr.diagonal(dim1=-2, dim2=-1).sum(-1) - 1.) * 0.5).clamp(-1., 1.)
+    return w_pos * dp + w_rot * torch.acos(c)
+
+
+def field_ee_se3(link_tensor, target_H, w_pos=1., w_rot=1., square=True):
+    """EESE3DistanceField.compute_cost -- fields.py:141-149 (last link frame only)."""
+    dist = se3_distance(link_tensor[..., -1, :, :], target_H, w_pos, w_rot)
+    return torch.square(dist) if square else dist
+
+
+def cost_goal_ee(x_trajs, field_fn, sigma):
+    """CostGoal.eval -- cost_functions.py:304-321: the field on the LAST waypoint's frames only."""
+    B, T = x_trajs.shape[:2]
+    err = field_fn(x_trajs[:, T - 1:T]).reshape(B, 1)
+    return (1. / sigma ** 2) * err.sum(1)
+
+
 class CompositeCost:
     """CostComposite.eval -- cost_functions.py:47-58.  `terms` is a list of callables
     term(trajs[B,T,d], x_trajs or None, **obs) -> [B], summed in list order."""

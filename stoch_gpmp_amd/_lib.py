@@ -11,9 +11,9 @@ LIB_PATH = os.path.join(_HERE, "libsgpmp.so")
 
 SGPMP_F32, SGPMP_F64 = 0, 1
 PRIOR_INIT, PRIOR_SAMPLE = 0, 1
-COST_GP, COST_GOAL_PRIOR, COST_GRID, COST_SPHERES, COST_SELF = 1, 2, 3, 4, 5
+COST_GP, COST_GOAL_PRIOR, COST_GRID, COST_SPHERES, COST_SELF, COST_EE_GOAL = 1, 2, 3, 4, 5, 6
 FIELD_RBF, FIELD_SDF, FIELD_OCCUPANCY = 0, 1, 2
-FLAG_GP_START, FLAG_SDF_CLAMP = 1, 16
+FLAG_GP_START, FLAG_SDF_CLAMP, FLAG_EE_SQUARE = 1, 16, 32
 MAX_TERMS, MAX_JOINTS, MAX_DOF, MAX_INTERP = 8, 16, 8, 8
 STAT_SHARDS = 64
 OK, EINVAL, ENOTPD, EHIP, ESTATE = 0, -1, -2, -3, -4

@@ -203,11 +203,21 @@ class CostGoalPrior(Cost):
 
 
 class CostGoal(Cost):
-    """reference cost_functions.py:282-337 (end-effector SE(3) goal).  Depends on the un-vendored
-    torch_robotics SE3_distance; ranked "next" in SURVEY.md 8(f), not built in this round."""
+    """reference cost_functions.py:282-321: K * field(last waypoint), field = EESE3DistanceField."""
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("CostGoal / EESE3DistanceField are not built yet (SURVEY.md 8f)")
+    def __init__(self, n_dof, traj_len, field=None, sigma_goal=None, tensor_args=None):
+        super().__init__(n_dof, traj_len)
+        self.field = field
+        self.sigma_goal = sigma_goal
+        self.tensor_args = tensor_args
+        self.set_cost_factors()
 
-    def descriptors(self):  # pragma: no cover
-        raise NotImplementedError
+    def set_cost_factors(self):
+        self.goal_factor = FieldFactor(self.n_dof, self.sigma_goal, [self.traj_len - 1, self.traj_len])
+
+    def descriptors(self):
+        if self.field is None:
+            return []
+        if not hasattr(self.field, "descriptor"):
+            raise TypeError(f"field {type(self.field).__name__} is not a stoch_gpmp_amd field")
+        return [self.field.descriptor(self.sigma_goal)]

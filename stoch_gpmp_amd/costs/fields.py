@@ -97,16 +97,50 @@ class LinkSelfDistanceField(DistanceField):
         return self._engine(frames.dtype, frames.device).field_eval(0, frames).reshape(shape)
 
 
+def SE3_distance(H1, H2, w_pos=1., w_rot=1.):
+    """The SE(3) distance this build uses:  w_pos |p1 - p2| + w_rot angle(R2^T R1).
+
+    The reference imports `SE3_distance` from the un-vendored, un-versioned `torch_robotics`
+    (reference fields.py:4,143-144); its exact formula cannot be checked here, so this is a documented
+    definition (PARITY UNPINNED), evaluated by the HIP kernels `ee_goal_kernel` /
+    `ee_field_kernel`.  This helper exists for API parity and runs the same kernel."""
+    field = EESE3DistanceField(H2, w_pos=w_pos, w_rot=w_rot, square=False,
+                               tensor_args={"device": H1.device, "dtype": H1.dtype})
+    return field.compute_distance(H1.unsqueeze(-3))
+
+
 class EESE3DistanceField(DistanceField):
-    """reference fields.py:130-153.  Its arithmetic (`SE3_distance`) lives in the un-vendored
-    `torch_robotics`; SURVEY.md 8(f) ranks it "next" -- not built in this round."""
+    """reference fields.py:130-153: distance of the LAST link frame to a target frame."""
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError(
-            "EESE3DistanceField / CostGoal are outside the hot path built so far (SURVEY.md 8f)")
+    def __init__(self, target_H, w_pos=1., w_rot=1., square=True, **kwargs):
+        super().__init__(**kwargs)
+        self.target_H = target_H
+        self.square = square
+        self.w_pos = w_pos
+        self.w_rot = w_rot
 
-    def descriptor(self, sigma):  # pragma: no cover
-        raise NotImplementedError
+    def update_target(self, target_H):
+        self.target_H = target_H
+        self._engines = {}
 
-    def compute_cost(self, *a, **k):  # pragma: no cover
-        raise NotImplementedError
+    def descriptor(self, sigma, square=None):
+        H = torch.as_tensor(self.target_H).detach().cpu().double().reshape(-1, 4, 4)[0]
+        sq = self.square if square is None else square
+        return dict(kind=L.COST_EE_GOAL, flags=L.FLAG_EE_SQUARE if sq else 0, sigma=sigma,
+                    host_data=[float(v) for v in H.flatten()], p0=self.w_pos, p1=self.w_rot)
+
+    def _field(self, link_tensor, square):
+        shape = link_tensor.shape[:-3]
+        frames = link_tensor.contiguous()
+        key = (frames.dtype, str(frames.device), bool(square))
+        if key not in self._engines:
+            eng = Engine(1, 2, 0, 1, tensor_args={"device": frames.device, "dtype": frames.dtype})
+            eng.set_costs([self.descriptor(1.0, square=square)])
+            self._engines[key] = eng
+        return self._engines[key].field_eval(0, frames).reshape(shape)
+
+    def compute_distance(self, link_tensor):
+        return self._field(link_tensor, False)
+
+    def compute_cost(self, link_tensor, **kwargs):
+        return self._field(link_tensor, self.square)

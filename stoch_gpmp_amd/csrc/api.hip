@@ -232,6 +232,12 @@ extern "C" int sgpmp_set_costs(sgpmp_ctx* c, const sgpmp_cost_desc* descs, int n
                 }
                 prog.needs_fk = 1;
                 break;
+            case SGPMP_COST_EE_GOAL:
+                if (!s.data) return fail(SGPMP_EINVAL, "sgpmp_set_costs: EE goal needs a target frame");
+                std::memcpy(t.target, s.data, sizeof(double) * 16);
+                t.w_pos = s.p0; t.w_rot = s.p1;
+                prog.n_ee += 1;
+                break;
             default:
                 return fail(SGPMP_EINVAL, "sgpmp_set_costs: unknown cost kind");
         }
@@ -378,8 +384,8 @@ static int finalize_program(sgpmp_ctx* c) {
     if (!c->have_costs) return fail(SGPMP_ESTATE, "cost program not set (sgpmp_set_costs)");
     if (!c->prog_dirty) return SGPMP_OK;
     CostProgram& p = c->h_prog;
-    if (p.needs_fk && !c->have_chain)
-        return fail(SGPMP_ESTATE, "link-distance cost terms need an FK chain (sgpmp_set_fk)");
+    if ((p.needs_fk || p.n_ee) && !c->have_chain)
+        return fail(SGPMP_ESTATE, "link-distance / end-effector cost terms need an FK chain (sgpmp_set_fk)");
     for (int i = 0; i < p.n_terms; ++i) {
         CostTerm& t = p.terms[i];
         if (t.kind != SGPMP_COST_SPHERES && t.kind != SGPMP_COST_SELF) continue;
@@ -524,7 +530,7 @@ extern "C" int sgpmp_field_eval(sgpmp_ctx* c, int term, const void* frames, int6
     if (!c->have_costs || term < 0 || term >= c->h_prog.n_terms)
         return fail(SGPMP_EINVAL, "sgpmp_field_eval: bad term index");
     CostTerm t = c->h_prog.terms[term];
-    if (t.kind != SGPMP_COST_SPHERES && t.kind != SGPMP_COST_SELF)
+    if (t.kind != SGPMP_COST_SPHERES && t.kind != SGPMP_COST_SELF && t.kind != SGPMP_COST_EE_GOAL)
         return fail(SGPMP_EINVAL, "sgpmp_field_eval: term is not a link field");
     if (t.kind == SGPMP_COST_SPHERES && (!spheres || n_spheres < 1))
         return fail(SGPMP_EINVAL, "LinkDistanceField cost needs obstacle_spheres");

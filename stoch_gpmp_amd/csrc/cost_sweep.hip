@@ -479,6 +479,7 @@ static bool make_flat(const CostProgram& p, FlatProg<real>& f) {
             case SGPMP_COST_GRID: has = &f.has_grid; slot = &f.grid; break;
             case SGPMP_COST_SELF: has = &f.has_self; slot = &f.self; break;
             case SGPMP_COST_SPHERES: has = &f.has_sph; slot = &f.sph; f.sph_index = i; break;
+            case SGPMP_COST_EE_GOAL: continue;      // evaluated by ee_goal_kernel after the sweep
             default: return false;
         }
         if (*has) return false;                      // a second term of this kind: not flat
@@ -590,14 +591,103 @@ hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const
                        long long batch_offset, const void* spheres, int n_spheres,
                        const void* is_weights, int rows_per_particle, double is_dt, void* costs,
                        double* costs64, hipStream_t stream) {
+    hipError_t e;
     if (dtype == SGPMP_F64)
-        return cost_dispatch<double>(n, T, h_prog, d_chain, h_chain, (const double*)trajs, batch,
-                                     batch_offset, (const double*)spheres, n_spheres,
-                                     (const double*)is_weights, rows_per_particle, is_dt, (double*)costs,
-                                     costs64, stream);
-    return cost_dispatch<float>(n, T, h_prog, d_chain, h_chain, (const float*)trajs, batch,
-                                batch_offset, (const float*)spheres, n_spheres, (const float*)is_weights,
-                                rows_per_particle, is_dt, (float*)costs, costs64, stream);
+        e = cost_dispatch<double>(n, T, h_prog, d_chain, h_chain, (const double*)trajs, batch,
+                                  batch_offset, (const double*)spheres, n_spheres,
+                                  (const double*)is_weights, rows_per_particle, is_dt, (double*)costs,
+                                  costs64, stream);
+    else
+        e = cost_dispatch<float>(n, T, h_prog, d_chain, h_chain, (const float*)trajs, batch,
+                                 batch_offset, (const float*)spheres, n_spheres, (const float*)is_weights,
+                                 rows_per_particle, is_dt, (float*)costs, costs64, stream);
+    // end-effector goal terms act on the last waypoint only: one thread per trajectory, added to
+    // the costs the sweep has just written (same stream)
+    for (int i = 0; i < h_prog.n_terms && e == hipSuccess; ++i)
+        if (h_prog.terms[i].kind == SGPMP_COST_EE_GOAL)
+            e = launch_ee_goal(dtype, n, T, h_prog.terms[i], d_chain, trajs, batch, costs, costs64, stream);
+    return e;
+}
+
+// ---------------------------------------------------------------------------------- EE goal term
+// CostGoal + EESE3DistanceField (cost_functions.py:308-321, fields.py:146-150): K * dist^2 on the last
+// waypoint, dist = SE3_distance(H_ee, H_target).  SE3_distance is third-party (torch_robotics) and
+// un-vendored; this build defines it as  w_pos |p - p*| + w_rot angle(R*^T R)  (DESIGN.md).
+template <typename real> struct EeTarget { real R[9], p[3], w_pos, w_rot, K; int square; };
+
+template <typename real>
+__device__ __forceinline__ real se3_distance(const real (&R)[9], const real (&p)[3], const EeTarget<real>& tg) {
+    using O = RealOps<real>;
+    const real dx = p[0] - tg.p[0], dy = p[1] - tg.p[1], dz = p[2] - tg.p[2];
+    const real dpos = O::sqrt_(dx * dx + dy * dy + dz * dz);
+    real tr = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tr += R[i] * tg.R[i];                  // trace(R*^T R)
+    const real c = fmin(fmax((tr - (real)1) * (real)0.5, (real)-1), (real)1);
+    return tg.w_pos * dpos + tg.w_rot * acos(c);
+}
+
+template <typename real>
+__global__ void ee_goal_kernel(int n, int T, const ChainDev* __restrict__ ch, const real* __restrict__ trajs,
+                               long long batch, EeTarget<real> tg, real* __restrict__ costs,
+                               double* __restrict__ costs64) {
+    using O = RealOps<real>;
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const real* q = trajs + ((size_t)b * T + (T - 1)) * 2 * n;
+    real R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    for (int j = 0; j < ch->n_joints; ++j) {
+        const JointDev& J = ch->j[j];
+        real F[9], tt[3], Rn[9];
+        for (int i = 0; i < 9; ++i) F[i] = (real)J.R[i];
+        for (int i = 0; i < 3; ++i) tt[i] = (real)J.t[i];
+        for (int r = 0; r < 3; ++r) p[r] += R[r * 3 + 0] * tt[0] + R[r * 3 + 1] * tt[1] + R[r * 3 + 2] * tt[2];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                Rn[r * 3 + c] = R[r * 3 + 0] * F[c] + R[r * 3 + 1] * F[3 + c] + R[r * 3 + 2] * F[6 + c];
+        if (J.revolute) {
+            real s, c;
+            O::sincos_(q[J.qidx], &s, &c);
+            for (int r = 0; r < 3; ++r) {
+                const real aa = Rn[r * 3 + 0], bb = Rn[r * 3 + 1];
+                Rn[r * 3 + 0] = aa * c + bb * s;
+                Rn[r * 3 + 1] = bb * c - aa * s;
+            }
+        }
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    }
+    real dist = se3_distance<real>(R, p, tg);
+    if (tg.square) dist = dist * dist;
+    const double add = (double)(tg.K * dist);
+    if (costs) costs[b] = (real)((double)costs[b] + add);
+    if (costs64) costs64[b] += add;
+}
+
+template <typename real>
+static EeTarget<real> make_ee_target(const CostTerm& t) {
+    EeTarget<real> g;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) g.R[r * 3 + c] = (real)t.target[r * 4 + c];
+        g.p[r] = (real)t.target[r * 4 + 3];
+    }
+    g.w_pos = (real)t.w_pos; g.w_rot = (real)t.w_rot; g.K = (real)t.K;
+    g.square = (t.flags & SGPMP_FLAG_EE_SQUARE) ? 1 : 0;
+    return g;
+}
+
+hipError_t launch_ee_goal(int dtype, int n, int T, const CostTerm& term, const ChainDev* d_chain,
+                          const void* trajs, long long batch, void* costs, double* costs64,
+                          hipStream_t stream) {
+    const int block = 128;
+    const unsigned grid = (unsigned)((batch + block - 1) / block);
+    if (grid == 0) return hipSuccess;
+    if (dtype == SGPMP_F64)
+        hipLaunchKernelGGL((ee_goal_kernel<double>), dim3(grid), dim3(block), 0, stream, n, T, d_chain,
+                           (const double*)trajs, batch, make_ee_target<double>(term), (double*)costs, costs64);
+    else
+        hipLaunchKernelGGL((ee_goal_kernel<float>), dim3(grid), dim3(block), 0, stream, n, T, d_chain,
+                           (const float*)trajs, batch, make_ee_target<float>(term), (float*)costs, costs64);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------- standalone ops
@@ -699,12 +789,38 @@ __global__ void field_eval_kernel(const TermK<real> tm, const real* __restrict__
     if (b < batch) out[b] = v;
 }
 
+// EESE3DistanceField.compute_cost on explicit frames [B,L,4,4]: distance of the LAST link frame.
+template <typename real>
+__global__ void ee_field_kernel(EeTarget<real> tg, const real* __restrict__ frames, long long batch, int n_links,
+                                real* __restrict__ out) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const real* f = frames + ((size_t)b * n_links + (n_links - 1)) * 16;
+    real R[9], p[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) R[r * 3 + c] = f[r * 4 + c];
+        p[r] = f[r * 4 + 3];
+    }
+    real dist = se3_distance<real>(R, p, tg);
+    if (tg.square) dist = dist * dist;
+    out[b] = dist;
+}
+
 hipError_t launch_field_eval(int dtype, const CostTerm& term, const void* frames, long long batch,
                              int n_links, const void* spheres, int n_spheres, void* out,
                              hipStream_t stream) {
     const int block = 64;
     const unsigned grid = (unsigned)((batch + block - 1) / block);
     if (grid == 0) return hipSuccess;
+    if (term.kind == SGPMP_COST_EE_GOAL) {
+        if (dtype == SGPMP_F64)
+            hipLaunchKernelGGL((ee_field_kernel<double>), dim3(grid), dim3(block), 0, stream,
+                               make_ee_target<double>(term), (const double*)frames, batch, n_links, (double*)out);
+        else
+            hipLaunchKernelGGL((ee_field_kernel<float>), dim3(grid), dim3(block), 0, stream,
+                               make_ee_target<float>(term), (const float*)frames, batch, n_links, (float*)out);
+        return hipGetLastError();
+    }
     const size_t esz = dtype == SGPMP_F64 ? 8 : 4;
     const size_t lds = (size_t)term.n_points * 3 * block * esz;
     if (dtype == SGPMP_F64)

@@ -44,11 +44,14 @@ struct CostTerm {
     int n_points;         // links + interpolated points
     int n_interp, interp_lo, interp_hi;
     double alpha[SGPMP_MAX_INTERP];
+    double target[16];    // EE_GOAL: target end-effector frame
+    double w_pos, w_rot;  // EE_GOAL
 };
 
 struct CostProgram {
     int n_terms;
-    int needs_fk;
+    int needs_fk;         // has link-position fields (SPHERES / SELF) evaluated inside the sweep
+    int n_ee;             // EE_GOAL terms (evaluated by ee_goal_kernel after the sweep)
     CostTerm terms[SGPMP_MAX_TERMS];
 };
 
@@ -109,6 +112,9 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                          void* weights, void* grad, void* means_prev, double* stats,
                          hipStream_t stream);
 
+hipError_t launch_ee_goal(int dtype, int n, int T, const CostTerm& term, const ChainDev* d_chain,
+                          const void* trajs, long long batch, void* costs, double* costs64,
+                          hipStream_t stream);
 hipError_t launch_fk(int dtype, int n, const ChainDev* d_chain, int n_links, const void* q,
                      long long batch, void* frames, hipStream_t stream);
 hipError_t launch_grid_lookup(int dtype, const CostTerm& term, const void* xy, long long batch,

@@ -139,10 +139,15 @@ def test_cost_descriptors_follow_the_reference_constructors():
         CostComposite(n, T, [gp], FK=lambda q: q)       # arbitrary FK callables cannot run in HIP
     with pytest.raises(NotImplementedError):
         gp.get_linear_system(None)                      # GPMP-only, out of scope
-    with pytest.raises(NotImplementedError):
-        CostGoal(n, T)
-    with pytest.raises(NotImplementedError):
-        EESE3DistanceField(None)
+    H = torch.eye(4, dtype=torch.float64)
+    H[:3, 3] = torch.tensor([0.4, 0.1, 0.5])
+    ee = CostGoal(n, T, field=EESE3DistanceField(H, w_pos=2., w_rot=0.5, tensor_args=CPU),
+                  sigma_goal=7e-3, tensor_args=CPU)
+    de = ee.descriptors()[0]
+    assert de["kind"] == L.COST_EE_GOAL and de["flags"] == L.FLAG_EE_SQUARE and de["sigma"] == 7e-3
+    assert (de["p0"], de["p1"]) == (2., 0.5) and de["host_data"] == [float(v) for v in H.flatten()]
+    assert ee.goal_factor.K == 1. / 7e-3 ** 2
+    assert CostGoal(n, T, sigma_goal=1.).descriptors() == []    # cost_functions.py:306: no field -> 0
 
 
 def test_rasteriser_and_synthetic_scene(golden):

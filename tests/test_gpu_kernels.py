@@ -323,6 +323,86 @@ def test_register_fk_path_equals_generic_lds_path_and_oracle(monkeypatch, dtype,
     close(fast, slow, rtol, atol=rtol * scale * 1e-2)
 
 
+def _ee_target():
+    H = fk_all_links(torch.tensor([[0.3, -0.5, 0.2, -1.9, 0.1, 1.6, 0.4]], dtype=torch.float64))[0, -1]
+    return H.clone()
+
+
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("square", [True, False])
+def test_ee_se3_field_on_frames_matches_oracle(dtype, rtol, square):
+    """EESE3DistanceField.compute_cost on explicit frames (reference fields.py:141-149); the SE(3)
+    distance itself is this build's documented definition (oracle.ref_equiv.se3_distance)."""
+    from stoch_gpmp_amd.costs.fields import EESE3DistanceField
+    g = torch.Generator().manual_seed(3)
+    q = torch.rand(5, 9, 7, generator=g, dtype=torch.float64) * 2 - 1
+    frames = fk_all_links(q.reshape(-1, 7)).reshape(5, 9, -1, 4, 4)
+    H = _ee_target()
+    ref = R.field_ee_se3(frames, H, w_pos=1.5, w_rot=0.25, square=square)
+    f = EESE3DistanceField(H, w_pos=1.5, w_rot=0.25, square=square, tensor_args=TA(dtype))
+    close(f.compute_cost(frames.to(**TA(dtype))), ref, rtol, atol=rtol)
+    close(f.compute_distance(frames.to(**TA(dtype))),
+          R.field_ee_se3(frames, H, w_pos=1.5, w_rot=0.25, square=False), rtol, atol=rtol)
+    # identical frame: distance exactly 0 (acos argument clamps at 1)
+    same = H.expand(1, 1, 1, 4, 4).to(**TA(dtype)).contiguous()
+    assert float(f.compute_distance(same).abs().max()) <= (0. if dtype == torch.float64 else 1e-3)
+
+
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-10), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("T", [16, 70])
+def test_cost_goal_ee_in_composite_matches_oracle(dtype, rtol, T):
+    """CostGoal (reference cost_functions.py:282-321) inside the composite: K * field on the frames
+    of the LAST waypoint, added to the sweep's costs; alone, and together with the other Panda terms."""
+    from stoch_gpmp_amd.costs.cost_functions import CostComposite, CostGoal
+    from stoch_gpmp_amd.costs.fields import EESE3DistanceField
+    from stoch_gpmp_amd.robots.panda import DifferentiableFrankaPanda
+    from tests.hip_builders import hip_panda_cost
+    c = SC.PANDA
+    nppg, S, n = 3, 5, 7
+    ta = TA(dtype)
+    g = torch.Generator().manual_seed(T)
+    trajs = torch.cat([torch.rand(nppg, S, T, n, generator=g) * 3 - 1.5,
+                       torch.randn(nppg, S, T, n, generator=g)], dim=-1).double()
+    sph = torch.as_tensor(SC.panda_spheres(num=4, seed=1))
+    H = _ee_target()
+    sigma = 0.05
+    ee_ref = lambda tr, xt, **o: R.cost_goal_ee(                                      # noqa: E731
+        xt, lambda fr: R.field_ee_se3(fr, H, w_pos=1., w_rot=0.5, square=True), sigma)
+    ee_hip = CostGoal(n, T, field=EESE3DistanceField(H, w_pos=1., w_rot=0.5, tensor_args=ta),
+                      sigma_goal=sigma, tensor_args=ta)
+    fk = DifferentiableFrankaPanda(gripper=False, device=DEV)
+    # alone
+    ref = R.CompositeCost(n, T, [ee_ref], FK=fk_all_links).eval(trajs)
+    out = CostComposite(n, T, [ee_hip], FK=fk.compute_forward_kinematics_all_links,
+                        tensor_args=ta).eval(trajs.to(**ta))
+    close(out, ref, rtol, atol=rtol * float(ref.abs().max()) * 1e-2)
+    # with the collision fields (GP / goal-prior terms dropped: they would swamp the EE term)
+    ora = SC.oracle_panda_cost(c, T, nppg, S, torch.float64)
+    ora.terms = ora.terms[2:] + [ee_ref]
+    ref = ora.eval(trajs, obstacle_spheres=sph)
+    hip = hip_panda_cost(c, T, nppg, S, ta)
+    hip.cost_list = hip.cost_list[2:] + [ee_hip]
+    out = hip.eval(trajs.to(**ta), obstacle_spheres=sph.to(**ta))
+    close(out, ref, rtol, atol=rtol * float(ref.abs().max()) * 1e-2)
+    # full composite in fp64 only (fp32 resolution is set by the 1e8-scale GP term)
+    if dtype == torch.float64:
+        ora = SC.oracle_panda_cost(c, T, nppg, S, torch.float64)
+        ora.terms = ora.terms + [ee_ref]
+        hip = hip_panda_cost(c, T, nppg, S, ta)
+        hip.cost_list = hip.cost_list + [ee_hip]
+        close(hip.eval(trajs.to(**ta), obstacle_spheres=sph.to(**ta)),
+              ora.eval(trajs, obstacle_spheres=sph), 1e-10)
+
+
+def test_cost_goal_ee_requires_a_chain():
+    from stoch_gpmp_amd.costs.cost_functions import CostComposite, CostGoal
+    from stoch_gpmp_amd.costs.fields import EESE3DistanceField
+    ee = CostGoal(7, 8, field=EESE3DistanceField(torch.eye(4), tensor_args=F64), sigma_goal=1.,
+                  tensor_args=F64)
+    with pytest.raises((ValueError, RuntimeError)):
+        CostComposite(7, 8, [ee], FK=None, tensor_args=F64).eval(torch.zeros(2, 8, 14, **F64))
+
+
 @pytest.mark.parametrize("T", [64, 65, 128, 130])
 def test_cost_sweep_multi_pass_trajectories_match_oracle(T):
     """T > 64 takes several 64-waypoint passes per wave with a carried neighbour waypoint."""
