@@ -204,9 +204,14 @@ def main():
         # the figure comes from the committed rocprofv3 --pmc passes of this same command (per launch,
         # FETCH_SIZE doubled per the gfx950 correction); null when the workload is not the profiled one
         traffic = None
+        # which K3 the dispatcher (csrc/cost_sweep.hip: cost_dispatch) picks for this workload
+        dual = (args.workload == "panda" and args.dtype == "f32" and args.field == "rbf"
+                and S % 2 == 0 and not os.environ.get("SGPMP_NO_DUAL_SWEEP"))
+        sweep_kernel = "cost_sweep_dual_kernel" if dual else "cost_sweep_kernel"
         tf = os.path.join(ROOT, "profiles", "r01", "traffic.json")
         if os.path.exists(tf) and args.workload == "panda" and (P_local, S, T, args.dtype, args.field) == (1024, 128, 64, "f32", "rbf"):
-            traffic = json.load(open(tf))["kernels"]["cost_sweep_kernel"]["bytes"]
+            kk = json.load(open(tf))["kernels"]
+            traffic = kk.get(sweep_kernel, kk.get("cost_sweep_kernel", {})).get("bytes")
         out = {
             "metric": "planner iterations/sec (and ms/iter) at fixed particles x samples x T",
             # whole-job aggregate: every rank advances its 1024-particle shard by one iteration per
@@ -224,7 +229,7 @@ def main():
                        "samples": S, "traj_len": T, "state_dim": d,
                        "parallelism": f"particle-sharded x{world}" if world > 1 else "single GPU",
                        "noise": "philox (in-kernel)", "prior_factor_dtype": "f64"},
-            "roofline": {"bound": "hbm", "kernel": "cost_sweep_kernel (K3)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": sweep_kernel + " (K3)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": sweep_bytes,
                          "avg_launch_ms": sweep_ms},

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collect the profiles that bench.py's roofline block and DESIGN.md cite.  Run ON the GPU box:
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh v3'
+# Outputs under gpurun_out/prof_<tag>/ ; copy the summaries into profiles/rNN/ afterwards
+# (tools/summarise_prof.py does the reduction).  PMC passes are separate runs with --kernel-trace only
+# (never combined with sys/hip/hsa traces), one counter group per pass, as MI355X_MICROARCH.md says.
+set -u
+TAG=${1:-v3}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline"
+
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
+for grp in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
+           "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"; do
+    name=$(echo "$grp" | cut -d' ' -f1)
+    rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o pmc -- $BENCH > /dev/null 2> "$OUT/pmc_$name.log"
+done
+cd "$ROOT"
+python3 bench.py --steps 200 --warmup 20 > "$OUT/bench_with_cpu_baseline.json" 2> "$OUT/bench.log"
+python3 tools/summarise_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+tail -40 "$OUT/summary.txt"

@@ -1,0 +1,58 @@
+"""Reduce the rocprofv3 outputs of tools/profile_round.sh to the summaries kept under profiles/rNN/:
+   kernel_stats.csv  (copy of the --stats table), pmc_summary.txt (per-kernel average of every counter)
+   and traffic.json  (HBM bytes per launch = FETCH_SIZE KiB * 1024 * 2 + WRITE_SIZE KiB * 1024, the
+   gfx950 correction from MI355X_MICROARCH.md).   usage: summarise_prof.py <prof_dir>"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    return name.replace("void ", "").split("(")[0][:60]
+
+
+def base(name):
+    return name.replace("void ", "").split("<")[0].split("(")[0].strip()
+
+
+def main(d):
+    stats = glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(d, "kernel_stats.csv"))
+        print("== kernel stats ==")
+        for row in csv.DictReader(open(stats[0])):
+            print({k: row[k] for k in row if k in ("Name", "Calls", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+    per = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            per[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    lines = []
+    avg = {}
+    for k in sorted(per):
+        avg[k] = {c: sum(v) / len(v) for c, v in per[k].items()}
+        n = max(len(v) for v in per[k].values())
+        lines.append(f"{short(k)}  launches={n}")
+        for c in sorted(avg[k]):
+            lines.append(f"    {c:28s} {avg[k][c]:.6g}")
+    open(os.path.join(d, "pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    kernels = {}
+    for k, a in avg.items():
+        if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
+            kernels[base(k)] = {"full_name": short(k), "fetch_size_kib": a["FETCH_SIZE"],
+                                "write_size_kib": a["WRITE_SIZE"],
+                                "bytes": int(a["FETCH_SIZE"] * 1024 * 2 + a["WRITE_SIZE"] * 1024)}
+    json.dump({"note": "HBM traffic per launch from rocprofv3 --pmc passes on MI355X (separate passes: "
+                       "FETCH_SIZE, WRITE_SIZE; KiB as reported). gfx950 correction per MI355X_MICROARCH.md: "
+                       "bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024.",
+               "workload": "panda P=1024 S=128 T=64 f32 rbf", "kernels": kernels},
+              open(os.path.join(d, "traffic.json"), "w"), indent=1)
+    print(json.dumps(kernels, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
