@@ -540,8 +540,12 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
                 if (const char* e = getenv("SGPMP_K3_BLOCKS")) pcap = atoll(e);
                 if (pblocks > pcap) pblocks = pcap;
                 if (pblocks < 1) pblocks = 1;
-                hipLaunchKernelGGL((cost_sweep_dual_kernel<ChainCode_panda::N, ChainCode_panda>),
-                                   dim3((unsigned)pblocks), dim3(256), 0, stream, a, F);
+                if (T <= 64 && !getenv("SGPMP_K3_NO_ONE"))
+                    hipLaunchKernelGGL((cost_sweep_dual_kernel<ChainCode_panda::N, ChainCode_panda, true>),
+                                       dim3((unsigned)pblocks), dim3(256), 0, stream, a, F);
+                else
+                    hipLaunchKernelGGL((cost_sweep_dual_kernel<ChainCode_panda::N, ChainCode_panda, false>),
+                                       dim3((unsigned)pblocks), dim3(256), 0, stream, a, F);
                 return hipGetLastError();
             }
         }
