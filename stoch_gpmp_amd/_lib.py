@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsgpmp.so")
+# SGPMP_LIB_PATH: development override (A/B of two builds on one GPU box, tools/ab.sh); still a HIP build
+LIB_PATH = os.environ.get("SGPMP_LIB_PATH") or os.path.join(_HERE, "libsgpmp.so")
 
 SGPMP_F32, SGPMP_F64 = 0, 1
 PRIOR_INIT, PRIOR_SAMPLE = 0, 1

@@ -540,9 +540,14 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
                 if (const char* e = getenv("SGPMP_K3_BLOCKS")) pcap = atoll(e);
                 if (pblocks > pcap) pblocks = pcap;
                 if (pblocks < 1) pblocks = 1;
-                if (T <= 64 && !getenv("SGPMP_K3_NO_ONE"))
+                size_t pad = 0;                               // experiment: occupancy limiter
+                if (const char* e = getenv("SGPMP_K3_LDS_PAD")) pad = (size_t)atoll(e);
+                if (T <= 64 && T % 2 == 0 && !getenv("SGPMP_K3_NO_ONE") && !getenv("SGPMP_K3_NO_LDS_PREFETCH"))
+                    hipLaunchKernelGGL((cost_sweep_dual_pf_kernel<ChainCode_panda::N, ChainCode_panda>),
+                                       dim3((unsigned)pblocks), dim3(256), pad, stream, a, F);
+                else if (T <= 64 && !getenv("SGPMP_K3_NO_ONE"))
                     hipLaunchKernelGGL((cost_sweep_dual_kernel<ChainCode_panda::N, ChainCode_panda, true>),
-                                       dim3((unsigned)pblocks), dim3(256), 0, stream, a, F);
+                                       dim3((unsigned)pblocks), dim3(256), pad, stream, a, F);
                 else
                     hipLaunchKernelGGL((cost_sweep_dual_kernel<ChainCode_panda::N, ChainCode_panda, false>),
                                        dim3((unsigned)pblocks), dim3(256), 0, stream, a, F);
