@@ -207,7 +207,8 @@ def main():
         # which K3 the dispatcher (csrc/cost_sweep.hip: cost_dispatch) picks for this workload
         dual = (args.workload == "panda" and args.dtype == "f32" and args.field == "rbf"
                 and S % 2 == 0 and not os.environ.get("SGPMP_NO_DUAL_SWEEP"))
-        sweep_kernel = "cost_sweep_dual_kernel" if dual else "cost_sweep_kernel"
+        pf = dual and T <= 64 and T % 2 == 0 and not os.environ.get("SGPMP_K3_NO_LDS_PREFETCH")
+        sweep_kernel = ("cost_sweep_dual_pf_kernel" if pf else "cost_sweep_dual_kernel") if dual else "cost_sweep_kernel"
         tf = os.path.join(ROOT, "profiles", "r01", "traffic.json")
         if os.path.exists(tf) and args.workload == "panda" and (P_local, S, T, args.dtype, args.field) == (1024, 128, 64, "f32", "rbf"):
             kk = json.load(open(tf))["kernels"]

@@ -55,6 +55,13 @@ sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*
     const int j0 = ln & (lpr - 1);
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int tc = min(TC, T - t0);
+        // the means of this chunk, fetched BEFORE the arithmetic so that the flush below issues stores
+        // only: on gfx9 stores count in vmcnt, and a load + s_waitcnt vmcnt(0) inside the flush loop would
+        // make every row wait for the previous row's HBM write to be acknowledged
+        const int seg = tc * d / VW;                     // vectors per row segment
+        const bool one_j = seg <= lpr;                   // each lane owns at most one vector of a row
+        vec mu0 = {};
+        if (one_j && j0 < seg) mu0 = *reinterpret_cast<const vec*>(mu + (size_t)t0 * d + j0 * VW);
         if (active) {
             const real* c = coef + (size_t)t0 * 8;
             real* o = trow;
@@ -93,14 +100,22 @@ sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // flush: each group of 2^lpr_shift lanes owns one row at a time (no integer division)
-        const int seg = tc * d / VW;                     // vectors per row segment
-        for (int r = ln >> lpr_shift; r < rows; r += groups) {
-            const real* trow_r = tile + (size_t)r * pitch;
-            real* orow = out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d;
-            for (int j = j0; j < seg; j += lpr) {
-                vec val = *reinterpret_cast<const vec*>(trow_r + j * VW);
-                val += *reinterpret_cast<const vec*>(mu + (size_t)t0 * d + j * VW);   // x = mu + y
-                *reinterpret_cast<vec*>(orow + j * VW) = val;
+        if (one_j) {
+            if (j0 < seg)
+                for (int r = ln >> lpr_shift; r < rows; r += groups) {
+                    vec val = *reinterpret_cast<const vec*>(tile + (size_t)r * pitch + j0 * VW);
+                    val += mu0;                                                          // x = mu + y
+                    *reinterpret_cast<vec*>(out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d + j0 * VW) = val;
+                }
+        } else {
+            for (int r = ln >> lpr_shift; r < rows; r += groups) {
+                const real* trow_r = tile + (size_t)r * pitch;
+                real* orow = out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d;
+                for (int j = j0; j < seg; j += lpr) {
+                    vec val = *reinterpret_cast<const vec*>(trow_r + j * VW);
+                    val += *reinterpret_cast<const vec*>(mu + (size_t)t0 * d + j * VW);
+                    *reinterpret_cast<vec*>(orow + j * VW) = val;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -1,0 +1,41 @@
+// Cost of the K2 noise source in isolation, at K2's launch geometry for config 3
+// (1024 x 128 samples x 7 dofs = 917504 lanes, 32 Philox4x32-10 calls each).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "../stoch_gpmp_amd/csrc/rng.h"
+template <int MODE>
+__global__ void __launch_bounds__(256) k(float* out, int calls, uint64_t seed) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    NoiseGen<float> gen;
+    gen.init(seed, 1, g >> 10, g & 1023, g % 7);
+    float acc = 0.f; uint32_t xacc = 0;
+    for (int i = 0; i < calls; ++i) {
+        if (MODE == 0) {
+            const Philox4 r = philox4x32_10((uint32_t)i | gen.kk, gen.c1, gen.c2, gen.c3, gen.k0, gen.k1);
+            xacc ^= r.x ^ r.y ^ r.z ^ r.w;
+        } else {
+            float e[4];
+            gen.get4(2 * i, e);
+            acc += e[0] + e[1] + e[2] + e[3];
+        }
+    }
+    if (acc == 1.2345f || xacc == 0x12345u) out[g] = acc + (float)xacc;
+}
+int main() {
+    float* d; (void)hipMalloc(&d, 4 << 20);
+    const int blocks = 917504 / 256;
+    for (int mode = 0; mode < 2; ++mode) {
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(e0);
+            if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, d, 32, 7ull);
+            else hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, d, 32, 7ull);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep == 2) printf("%s: %.1f us for %d lanes x 32 calls (%.2f ns per wave-call per SIMD)\n",
+                                 mode ? "philox + box-muller" : "philox only", ms * 1e3, blocks * 256,
+                                 ms * 1e6 / (blocks * 4.0 * 32 / 1024));
+        }
+    }
+    return 0;
+}
