@@ -1,0 +1,86 @@
+"""CPU restatement (numpy) of the NATIVE noise source of the HIP sampler -- TEST INFRASTRUCTURE ONLY.
+
+The reference draws eps = randn(S, P, M) from torch's sequential global generator (planner.py:48-49,
+torch multivariate_normal.py:250-253); the HIP sampler's default mode replaces that by a counter-based
+stream (csrc/rng.h): Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3",
+SC'11 -- the generator behind curand / torch.cuda) + Box-Muller, keyed on
+(seed, draw, global particle, sample, waypoint pair, dof).  This file restates that stream so that the
+native mode has a deterministic checker too: `native_eps(...)` returns the noise in torch's
+`randn(S, P, M)` layout, ready for `oracle.ref_equiv.TrajPrior.sample(eps=...)`.
+
+Pinned by the Random123 known-answer vectors for philox4x32-10 (tests/test_oracle_golden.py).
+"""
+import numpy as np
+
+M0 = np.uint64(0xD2511F53)
+M1 = np.uint64(0xCD9E8D57)
+W0 = 0x9E3779B9
+W1 = 0xBB67AE85
+MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10: counters are uint32 arrays (broadcastable), keys Python ints."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & MASK for c in (c0, c1, c2, c3))
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 &= 0xFFFFFFFF
+    k1 &= 0xFFFFFFFF
+    for _ in range(10):
+        p0 = M0 * c0                                   # < 2^64: exact in uint64
+        p1 = M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & MASK
+        hi1, lo1 = p1 >> np.uint64(32), p1 & MASK
+        c0, c1, c2, c3 = hi1 ^ c1 ^ np.uint64(k0), lo1, hi0 ^ c3 ^ np.uint64(k1), lo0
+        k0 = (k0 + W0) & 0xFFFFFFFF
+        k1 = (k1 + W1) & 0xFFFFFFFF
+    return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def box_muller_f32(a, b):
+    """csrc/rng.h box_muller_f32: u1 = a*2^-32 + 2^-33 in (0,1], angle = b*2^-32 revolutions."""
+    a = a.astype(np.float32)
+    b = b.astype(np.float32)
+    u1 = a * np.float32(2.3283064365386963e-10) + np.float32(1.1641532182693481e-10)
+    u2 = b * np.float32(2.3283064365386963e-10)
+    r = np.sqrt(np.float32(-2.0 * 0.6931471805599453) * np.log2(u1.astype(np.float64)).astype(np.float32))
+    ang = (2.0 * np.pi) * u2.astype(np.float64)
+    return (r * np.cos(ang)).astype(np.float32), (r * np.sin(ang)).astype(np.float32)
+
+
+def box_muller_f64(a, b, c, d):
+    """csrc/rng.h box_muller_f64: 53-bit uniforms from two words each."""
+    m1 = ((a.astype(np.uint64) << np.uint64(32)) | b.astype(np.uint64)) >> np.uint64(11)
+    m2 = ((c.astype(np.uint64) << np.uint64(32)) | d.astype(np.uint64)) >> np.uint64(11)
+    u1 = (m1.astype(np.float64) + 0.5) * 1.1102230246251565e-16
+    u2 = m2.astype(np.float64) * 1.1102230246251565e-16
+    r = np.sqrt(-2.0 * np.log(u1))
+    return r * np.cos(2.0 * np.pi * u2), r * np.sin(2.0 * np.pi * u2)
+
+
+def native_eps(seed, draw, particles, S, T, n, dtype="float32"):
+    """Noise of the HIP sampler for global particle indices `particles` -> [S, len(particles), T*2n]
+    (torch.randn(S, P, M) layout: element t*d + k is the position noise of dof k at waypoint t,
+    t*d + n + k the velocity noise)."""
+    particles = np.asarray(particles, dtype=np.uint64)
+    P, d = len(particles), 2 * n
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    s_idx = np.arange(S, dtype=np.uint64).reshape(S, 1, 1, 1)
+    m_idx = particles.reshape(1, P, 1, 1)
+    k_idx = np.arange(n, dtype=np.uint64).reshape(1, 1, 1, n)
+    c3 = np.uint64(draw & 0xFFFFFFFF)
+    out = np.zeros((S, P, T, d), dtype=np.float64 if dtype == "float64" else np.float32)
+    if dtype == "float64":
+        t_idx = np.arange(T, dtype=np.uint64).reshape(1, 1, T, 1)
+        x, y, z, w = philox4x32_10(t_idx | (k_idx << np.uint64(20)), s_idx, m_idx,
+                                   c3 ^ np.uint64(0x80000000), k0, k1)
+        z0, z1 = box_muller_f64(x, y, z, w)
+        out[..., :n], out[..., n:] = z0, z1
+    else:
+        nb = (T + 1) // 2
+        b_idx = np.arange(nb, dtype=np.uint64).reshape(1, 1, nb, 1)
+        x, y, z, w = philox4x32_10(b_idx | (k_idx << np.uint64(20)), s_idx, m_idx, c3, k0, k1)
+        e0, e1 = box_muller_f32(x, y)                  # waypoint 2b:   (pos, vel)
+        e2, e3 = box_muller_f32(z, w)                  # waypoint 2b+1: (pos, vel)
+        out[:, :, 0::2, :n], out[:, :, 0::2, n:] = e0[:, :, :(T + 1) // 2], e1[:, :, :(T + 1) // 2]
+        out[:, :, 1::2, :n], out[:, :, 1::2, n:] = e2[:, :, :T // 2], e3[:, :, :T // 2]
+    return out.reshape(S, P, T * d)

@@ -182,6 +182,35 @@ def test_native_noise_statistics_and_sharding_invariance(dtype):
     assert torch.equal(xs.cpu().double().reshape(2, S, M), x[2:])
 
 
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("n,T,dense", [(2, 9, False), (7, 64, False), (3, 12, True)])
+def test_native_noise_samples_match_the_restated_stream(n, T, dense, dtype, rtol):
+    """The in-kernel Philox4x32-10 + Box-Muller stream, restated on the CPU (oracle/native_noise.py,
+    pinned by the Random123 known-answer vectors), fed through the oracle's dense sampler must give
+    the samples the HIP sampler produces from (seed, draw, global particle index) alone."""
+    from oracle.native_noise import native_eps
+    from stoch_gpmp_amd import _lib as L
+    dt, ss, sg, sgoal, modes, S, off = 0.1, 0.3, 1.0, 0.4, 3, 11, 5
+    d = 2 * n
+    seed, draw = 0x1234567887654321, 77
+    g = torch.Generator().manual_seed(4)
+    means = torch.randn(modes, T, d, generator=g, dtype=torch.float64)
+    pr = R.TrajPrior(T, n, dt, R.unary_K(d, ss, torch.float64), R.q_inv_matrix(n, dt, sg, torch.float64),
+                     torch.zeros(d, dtype=torch.float64), means=means, K_g=R.unary_K(d, sgoal, torch.float64),
+                     goals=torch.zeros(modes, d, dtype=torch.float64))
+    eps = torch.from_numpy(native_eps(seed, draw, range(off, off + modes), S, T, n,
+                                      "float64" if dtype == torch.float64 else "float32")).double()
+    ref = pr.sample(S, eps=eps)
+    eng = engine(n, T, modes, S, dtype)
+    if dense:
+        eng.set_prior(L.PRIOR_SAMPLE, dt, ss, None, sgoal, Q_c_inv=torch.eye(n, dtype=torch.float64) / sg ** 2)
+    else:
+        eng.set_prior(L.PRIOR_SAMPLE, dt, ss, sg, sgoal)
+    out = eng.sample(L.PRIOR_SAMPLE, seed, draw, means.to(**TA(dtype)), S, mode_offset=off)
+    scale = float((ref - means.unsqueeze(1)).abs().max())
+    close(out, ref, rtol, atol=rtol * scale)
+
+
 # ------------------------------------------------------------------------------------------- K3
 @pytest.mark.parametrize("tag,dtype,rtol", [("f64", torch.float64, 1e-11), ("f32", torch.float32, 3e-6)])
 def test_planar_cost_terms_match_reference_fixture(golden, tag, dtype, rtol):

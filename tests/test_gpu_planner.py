@@ -109,6 +109,26 @@ def test_panda_small_matches_oracle_fp64(field_type):
         assert rel_err(pl.particle_means, ora.particle_means) < 1e-6
 
 
+def test_panda_default_native_noise_matches_oracle_on_the_restated_stream():
+    """The DEFAULT mode (noise='philox', nothing fed from the host): the oracle planner driven by the
+    CPU restatement of the in-kernel stream (oracle/native_noise.py, pinned by the Random123 vectors)
+    must follow the HIP planner -- initial particle means, costs and means over the iterations."""
+    from oracle.native_noise import native_eps
+    c = SC.PANDA
+    T, nppg, S, iters, n, seed = 16, 4, 6, 4, 7, 11
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F64)
+    eps0 = torch.from_numpy(native_eps(seed, 0, range(1), nppg, T, n, "float64"))      # [nppg, G, M]
+    ora = SC.oracle_panda_planner(c, T, nppg, S, seed=seed, eps_init=eps0)
+    pl = hip_panda_planner(c, T, nppg, S, F64, seed=seed)                              # noise='philox'
+    assert rel_err(pl.particle_means, ora.particle_means) < 1e-7
+    for it in range(iters):
+        eps = torch.from_numpy(native_eps(seed, 2 + it, range(nppg), S, T, n, "float64"))   # draw 1 is discarded
+        costs_o, grad_o = ora.step(eps=eps, obstacle_spheres=sph.cpu())
+        _, _, _, _, costs, grad = pl.optimize(obstacle_spheres=sph)
+        assert rel_err(costs, costs_o) < 1e-7
+        assert rel_err(pl.particle_means, ora.particle_means) < 1e-6
+
+
 def test_panda_multigoal_long_horizon_matches_oracle_fp64():
     """BASELINE config 5 shape in miniature: Panda, 2 goals, T = 128 (two 64-waypoint passes per
     wave, goal lookup by particle // nppg), fp64, sdf field, against the oracle on the same noise."""
