@@ -47,6 +47,18 @@ sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*
     const real* erow = (eps && active) ? eps + ((size_t)s * eps_modes + eps_mode_offset + m) * M : nullptr;
     NoiseGen<real> gen;
     gen.init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)s, (uint32_t)k);
+    // Warm the scalar cache: touch every 64-B line of the coefficient table once with all loads in
+    // flight together.  The recurrence reads 32 B of coefficients per waypoint through s_load; a cold
+    // line costs ~1 us, which a launch with few waves (configs 1 and 2) cannot hide behind other waves
+    // (config 2: 41.6 -> 33.7 us).
+    {
+        const int nlines = (int)(((size_t)T * 8 * sizeof(real) + 63) >> 6);
+        for (int i = 0; i < nlines; ++i) {
+            uint32_t sink;
+            asm volatile("s_load_dword %0, %1, %2" : "=s"(sink) : "s"(coef), "s"(i << 6) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     real p = 0, v = 0;
     real* trow = tile + (size_t)slw * pitch + k;
     const int rows = min(spw, S - s0);                   // rows of this wave that exist (may be <= 0)
