@@ -190,6 +190,14 @@ int sgpmp_grid_lookup(sgpmp_ctx* ctx, int term, const void* xy, int64_t batch, v
 int sgpmp_field_eval(sgpmp_ctx* ctx, int term, const void* frames, int64_t batch, int n_links,
                      const void* spheres, int n_spheres, void* out, void* stream);
 
+/* FieldFactor.get_error(calc_jacobian=True) (factors/field_factor.py:28-38): value [B] (may be NULL) and
+ * gradient d value / d q [B,n] of link-field term `term` at joint configurations q [B,n], with the
+ * context's FK chain -- the analytic form of the reference's torch.autograd.grad through FK and the
+ * field (the reference's H is MINUS this gradient).  Smooth fields only: SPHERES with the rbf type
+ * and SELF; sdf / occupancy / EE_GOAL -> SGPMP_EINVAL.   */
+int sgpmp_field_grad(sgpmp_ctx* ctx, int term, const void* q, int64_t batch, const void* spheres,
+                     int n_spheres, void* value, void* grad, void* stream);
+
 /* Kernel timing helper for bench.py: elapsed ms between two events recorded on `stream`
  * (HIP events on the stream the kernels run on). */
 int sgpmp_event_create(void** ev);

@@ -258,6 +258,30 @@ def cost_goal_ee(x_trajs, field_fn, sigma):
     return (1. / sigma ** 2) * err.sum(1)
 
 
+def field_error_and_jacobian(q_trajs, n, traj_range, FK, field_fn):
+    """FieldFactor.get_error(calc_jacobian=True) -- field_factor.py:28-38: error [B,len] and
+    H = -d(error.sum())/d q restricted to the waypoint range and the position columns, by autograd
+    through the FK callable exactly as the reference does."""
+    a, b = traj_range
+    q_trajs = q_trajs.detach().clone().requires_grad_(True)
+    B, T, d = q_trajs.shape
+    x_trajs = FK(q_trajs.reshape(-1, d)[:, :n]).reshape(B, T, -1, 4, 4)
+    error = field_fn(x_trajs[:, a:b]).reshape(B, b - a)
+    H = -torch.autograd.grad(error.sum(), q_trajs)[0][:, a:b, :n]
+    return error.detach(), H
+
+
+def collision_linear_system(q_trajs, n, FK, field_fn, sigma):
+    """CostCollision.get_linear_system -- cost_functions.py:263-279."""
+    B, T, d = q_trajs.shape
+    err, H = field_error_and_jacobian(q_trajs, n, (1, T), FK, field_fn)
+    A = torch.zeros(B, T - 1, d * T, dtype=q_trajs.dtype)
+    for i in range(T - 1):
+        A[:, i, (i + 1) * d:(i + 1) * d + n] = H[:, i]
+    K = (1. / sigma ** 2) * torch.eye(T - 1, dtype=q_trajs.dtype).repeat(B, 1, 1)
+    return A, err.unsqueeze(-1), K
+
+
 class CompositeCost:
     """CostComposite.eval -- cost_functions.py:47-58.  `terms` is a list of callables
     term(trajs[B,T,d], x_trajs or None, **obs) -> [B], summed in list order."""

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sgpmp_fk": (_I, [_P, _P, _I64, _P, _P]),
     "sgpmp_grid_lookup": (_I, [_P, _I, _P, _I64, _P, _P]),
     "sgpmp_field_eval": (_I, [_P, _I, _P, _I64, _I, _P, _I, _P, _P]),
+    "sgpmp_field_grad": (_I, [_P, _I, _P, _I64, _P, _I, _P, _P, _P]),
     "sgpmp_event_create": (_I, [C.POINTER(_P)]),
     "sgpmp_event_record": (_I, [_P, _P]),
     "sgpmp_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),

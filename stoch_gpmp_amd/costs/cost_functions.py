@@ -62,6 +62,10 @@ class CostComposite(Cost):
         self.tensor_args = tensor_args
         self._engines = {}
         self.chain = self._resolve_chain(FK)
+        for cost in cost_list:                          # children evaluate stand-alone through the same chain
+            if getattr(cost, "_fk", None) is None:
+                cost._fk = FK
+                cost._chain = self.chain
 
     @staticmethod
     def _resolve_chain(FK):
@@ -174,6 +178,24 @@ class CostCollision(Cost):
         if not hasattr(self.field, "descriptor"):
             raise TypeError(f"field {type(self.field).__name__} is not a stoch_gpmp_amd field")
         return [self.field.descriptor(self.sigma_coll)]
+
+    def get_linear_system(self, trajs, x_trajs=None, **observation):
+        """cost_functions.py:263-279: A [B,T-1,T*d] holds the field Jacobian H_i = -d field / d q of
+        waypoint i+1 in the columns of that waypoint's positions, b = field values, K = I / sigma^2.
+        The Jacobian comes from `field_grad_kernel` (analytic) instead of autograd."""
+        if self.field is None:
+            return None, None, None
+        chain = getattr(self, "_chain", None)
+        trajs = trajs.reshape(-1, self.traj_len, self.dim)
+        B, T = trajs.shape[0], self.traj_len
+        err, H = self.obst_factor.get_error(trajs, self.field, calc_jacobian=True, fk_chain=chain,
+                                            obstacle_spheres=observation.get('obstacle_spheres', None))
+        A = torch.zeros(B, T - 1, self.dim * T, device=trajs.device, dtype=trajs.dtype)
+        rows = torch.arange(T - 1, device=trajs.device)
+        cols = ((rows + 1) * self.dim).unsqueeze(1) + torch.arange(self.n_dof, device=trajs.device)
+        A[:, rows.unsqueeze(1), cols] = H
+        K = self.obst_factor.K * torch.eye(T - 1, device=trajs.device, dtype=trajs.dtype).repeat(B, 1, 1)
+        return A, err.unsqueeze(-1), K
 
 
 class CostGoalPrior(Cost):

@@ -9,11 +9,20 @@ class FieldFactor:
         self.length = traj_range[1] - traj_range[0]
         self.K = 1. / (sigma ** 2)                      # field_factor.py:16
 
-    def get_error(self, q_trajs, field, x_trajs=None, calc_jacobian=False, **observations):
-        if calc_jacobian:
-            raise NotImplementedError("Jacobians belong to the GPMP planner (out of scope, SURVEY.md 8f)")
+    def get_error(self, q_trajs, field, x_trajs=None, calc_jacobian=False, fk_chain=None, **observations):
+        """field_factor.py:18-40.  With calc_jacobian the reference differentiates the field through the
+        FK callable with autograd; here the Jacobian is analytic and needs the URDF chain itself
+        (`fk_chain`, e.g. CostComposite.chain) -- link frames `x_trajs` are then not used."""
         batch = q_trajs.shape[0]
         a, b = self.traj_range
+        if calc_jacobian:
+            if fk_chain is None:
+                raise ValueError("calc_jacobian=True needs fk_chain (the URDF chain of the composite's FK)")
+            if not hasattr(field, "compute_cost_and_grad"):
+                raise NotImplementedError(f"{type(field).__name__} has no analytic Jacobian")
+            q = q_trajs[:, a:b, :self.n_dof].reshape(-1, self.n_dof)
+            err, grad = field.compute_cost_and_grad(q, fk_chain, **observations)
+            return err.reshape(batch, self.length), -grad.reshape(batch, self.length, self.n_dof)
         if x_trajs is not None:
             states = x_trajs[:, a:b]
         else:

@@ -547,6 +547,28 @@ extern "C" int sgpmp_field_eval(sgpmp_ctx* c, int term, const void* frames, int6
     return SGPMP_OK;
 }
 
+extern "C" int sgpmp_field_grad(sgpmp_ctx* c, int term, const void* q, int64_t batch, const void* spheres,
+                                int n_spheres, void* value, void* grad, void* stream) {
+    if (!c || !q || !grad || batch < 0) return fail(SGPMP_EINVAL, "sgpmp_field_grad: bad argument");
+    if (!c->have_costs || term < 0 || term >= c->h_prog.n_terms)
+        return fail(SGPMP_EINVAL, "sgpmp_field_grad: bad term index");
+    if (!c->have_chain) return fail(SGPMP_EINVAL, "sgpmp_field_grad: no FK chain (sgpmp_set_fk)");
+    int rc;
+    if ((rc = finalize_program(c)) != SGPMP_OK) return rc;
+    CostTerm t = c->h_prog.terms[term];
+    if (t.kind == SGPMP_COST_SPHERES) {
+        if ((t.flags & 15) != SGPMP_FIELD_RBF)
+            return fail(SGPMP_EINVAL, "sgpmp_field_grad: only the rbf sphere field is differentiable here");
+        if (!spheres || n_spheres < 1) return fail(SGPMP_EINVAL, "LinkDistanceField cost needs obstacle_spheres");
+    } else if (t.kind != SGPMP_COST_SELF) {
+        return fail(SGPMP_EINVAL, "sgpmp_field_grad: term is not a smooth link field");
+    }
+    if (t.n_points > SGPMP_MAX_POINTS) return fail(SGPMP_EINVAL, "too many link points (max 32)");
+    HIPCHK(launch_field_grad(c->dims.dtype, c->dims.n_dof, t, c->d_chain, q, batch, spheres, n_spheres,
+                             value, grad, (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
 // ---------------------------------------------------------------------------------- timing helpers
 extern "C" int sgpmp_event_create(void** ev) {
     hipEvent_t e;

@@ -817,6 +817,127 @@ __global__ void ee_field_kernel(EeTarget<real> tg, const real* __restrict__ fram
     out[b] = dist;
 }
 
+// ---------------------------------------------------------------------------------- field Jacobians
+// FieldFactor.get_error(calc_jacobian=True) (field_factor.py:28-38): the field value at a batch of
+// joint configurations q [B,n] and its gradient with respect to q, analytically instead of through
+// autograd.  The field is a function of the link positions p_l(q); with g_l = df/dp_l,
+//   df/dq_j = z_j . sum_{l after joint j} (p_l - o_j) x g_l = z_j . (M_j - o_j x F_j),
+// F_j = sum g_l, M_j = sum p_l x g_l over the links behind revolute joint j (axis z_j through o_j),
+// accumulated from the end effector backwards.  Interpolated link points (fields.py:68-74) hand their
+// gradient to the two links they lie between.  One thread per configuration; any joint order.
+template <typename real>
+__global__ void __launch_bounds__(64)
+field_grad_kernel(const ChainDev* __restrict__ ch, TermK<real> tm, int n, const real* __restrict__ q,
+                  long long batch, const real* __restrict__ spheres, int n_spheres,
+                  real* __restrict__ value, real* __restrict__ grad) {
+    using O = RealOps<real>;
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const real* qb = q + (size_t)b * n;
+    const int nj = ch->n_joints;
+    real P[SGPMP_MAX_POINTS][3], G[SGPMP_MAX_POINTS][3];
+    real Z[SGPMP_MAX_JOINTS][3], Oj[SGPMP_MAX_JOINTS][3];
+    real R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    P[0][0] = P[0][1] = P[0][2] = 0;
+    for (int j = 0; j < nj; ++j) {
+        const JointDev& J = ch->j[j];
+        real F[9], tt[3], Rn[9];
+        for (int i = 0; i < 9; ++i) F[i] = (real)J.R[i];
+        for (int i = 0; i < 3; ++i) tt[i] = (real)J.t[i];
+        for (int r = 0; r < 3; ++r) p[r] += R[r * 3 + 0] * tt[0] + R[r * 3 + 1] * tt[1] + R[r * 3 + 2] * tt[2];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                Rn[r * 3 + c] = R[r * 3 + 0] * F[c] + R[r * 3 + 1] * F[3 + c] + R[r * 3 + 2] * F[6 + c];
+        for (int r = 0; r < 3; ++r) { Z[j][r] = Rn[r * 3 + 2]; Oj[j][r] = p[r]; }     // joint axis and origin
+        if (J.revolute) {
+            real sn, cs;
+            O::sincos_(qb[J.qidx], &sn, &cs);
+            for (int r = 0; r < 3; ++r) {
+                const real aa = Rn[r * 3 + 0], bb = Rn[r * 3 + 1];
+                Rn[r * 3 + 0] = aa * cs + bb * sn;
+                Rn[r * 3 + 1] = bb * cs - aa * sn;
+            }
+        }
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+        for (int r = 0; r < 3; ++r) P[j + 1][r] = p[r];
+    }
+    const int n_links = nj + 1;
+    int npts = n_links;
+    if (tm.n_interp > 0)
+        for (int i = tm.interp_lo; i < tm.interp_hi; ++i)
+            for (int a = 0; a < tm.n_interp; ++a, ++npts)
+                for (int r = 0; r < 3; ++r) P[npts][r] = P[i][r] + (P[i + 1][r] - P[i][r]) * tm.alpha[a];
+    for (int l = 0; l < npts; ++l) G[l][0] = G[l][1] = G[l][2] = 0;
+    real val = 0;
+    if (tm.kind == SGPMP_COST_SPHERES) {                     // rbf only (checked by the host)
+        for (int o = 0; o < n_spheres; ++o) {
+            const real cx = spheres[o * 4], cy = spheres[o * 4 + 1], cz = spheres[o * 4 + 2], rr = spheres[o * 4 + 3];
+            const real ir2 = (real)1 / (rr * rr);
+            for (int l = 0; l < npts; ++l) {
+                const real dx = P[l][0] - cx, dy = P[l][1] - cy, dz = P[l][2] - cz;
+                const real e = O::exp_((real)-0.5 * (dx * dx + dy * dy + dz * dz) * ir2);
+                val += e;
+                const real w = -e * ir2;
+                G[l][0] += w * dx; G[l][1] += w * dy; G[l][2] += w * dz;
+            }
+        }
+    } else {                                                 // SELF: full L x L sum, both triangles
+        for (int i = 0; i < npts; ++i)
+            for (int j = 0; j < npts; ++j) {
+                const real dx = P[i][0] - P[j][0], dy = P[i][1] - P[j][1], dz = P[i][2] - P[j][2];
+                const real e = O::exp_((dx * dx + dy * dy + dz * dz) * tm.K2);
+                val += e;
+                const real w = (real)2 * tm.K2 * e;
+                G[i][0] += w * dx; G[i][1] += w * dy; G[i][2] += w * dz;
+                G[j][0] -= w * dx; G[j][1] -= w * dy; G[j][2] -= w * dz;
+            }
+    }
+    if (tm.n_interp > 0) {                                   // interpolated points -> their two links
+        int m = n_links;
+        for (int i = tm.interp_lo; i < tm.interp_hi; ++i)
+            for (int a = 0; a < tm.n_interp; ++a, ++m)
+                for (int r = 0; r < 3; ++r) {
+                    G[i][r] += ((real)1 - tm.alpha[a]) * G[m][r];
+                    G[i + 1][r] += tm.alpha[a] * G[m][r];
+                }
+    }
+    if (value) value[b] = val;
+    real Fs[3] = {0, 0, 0}, Ms[3] = {0, 0, 0};
+    real* gb = grad + (size_t)b * n;
+    for (int k = 0; k < n; ++k) gb[k] = 0;
+    for (int j = nj - 1; j >= 0; --j) {
+        const int l = j + 1;
+        Fs[0] += G[l][0]; Fs[1] += G[l][1]; Fs[2] += G[l][2];
+        Ms[0] += P[l][1] * G[l][2] - P[l][2] * G[l][1];
+        Ms[1] += P[l][2] * G[l][0] - P[l][0] * G[l][2];
+        Ms[2] += P[l][0] * G[l][1] - P[l][1] * G[l][0];
+        if (ch->j[j].revolute) {
+            const real ox = Oj[j][0], oy = Oj[j][1], oz = Oj[j][2];
+            const real tx = Ms[0] - (oy * Fs[2] - oz * Fs[1]);
+            const real ty = Ms[1] - (oz * Fs[0] - ox * Fs[2]);
+            const real tz = Ms[2] - (ox * Fs[1] - oy * Fs[0]);
+            gb[ch->j[j].qidx] += Z[j][0] * tx + Z[j][1] * ty + Z[j][2] * tz;
+        }
+    }
+}
+
+hipError_t launch_field_grad(int dtype, int n, const CostTerm& term, const ChainDev* d_chain, const void* q,
+                             long long batch, const void* spheres, int n_spheres, void* value, void* grad,
+                             hipStream_t stream) {
+    const int block = 64;
+    const unsigned grid = (unsigned)((batch + block - 1) / block);
+    if (grid == 0) return hipSuccess;
+    if (dtype == SGPMP_F64)
+        hipLaunchKernelGGL((field_grad_kernel<double>), dim3(grid), dim3(block), 0, stream, d_chain,
+                           make_termk<double>(term), n, (const double*)q, batch, (const double*)spheres,
+                           n_spheres, (double*)value, (double*)grad);
+    else
+        hipLaunchKernelGGL((field_grad_kernel<float>), dim3(grid), dim3(block), 0, stream, d_chain,
+                           make_termk<float>(term), n, (const float*)q, batch, (const float*)spheres,
+                           n_spheres, (float*)value, (float*)grad);
+    return hipGetLastError();
+}
+
 hipError_t launch_field_eval(int dtype, const CostTerm& term, const void* frames, long long batch,
                              int n_links, const void* spheres, int n_spheres, void* out,
                              hipStream_t stream) {

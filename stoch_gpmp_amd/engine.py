@@ -240,6 +240,24 @@ class Engine:
                                               L.ptr(spheres), n_sph, L.ptr(out), L.stream_ptr()))
         return out
 
+    def field_grad(self, term, q, spheres=None):
+        """Value [B] and gradient [B,n] of link-field term `term` at joint configurations q [B,n]
+        (analytic FK Jacobians in `field_grad_kernel`)."""
+        self._chk(q, "q")
+        assert q.shape[-1] == self.n
+        B = q.numel() // self.n
+        value = torch.empty(B, **self.tensor_args)
+        grad = torch.empty(B, self.n, **self.tensor_args)
+        n_sph = 0
+        if spheres is not None:
+            spheres = spheres.reshape(-1, 4)
+            self._chk(spheres, "obstacle_spheres")
+            n_sph = spheres.shape[0]
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_field_grad(self._ctx, term, L.ptr(q), B, L.ptr(spheres), n_sph,
+                                              L.ptr(value), L.ptr(grad), L.stream_ptr()))
+        return value, grad
+
     # ------------------------------------------------------------------ profiling
     def profile_enable(self, on=True):
         L.check(self.lib.sgpmp_profile_enable(self._ctx, 1 if on else 0))
