@@ -564,8 +564,8 @@ extern "C" int sgpmp_field_grad(sgpmp_ctx* c, int term, const void* q, int64_t b
         return fail(SGPMP_EINVAL, "sgpmp_field_grad: term is not a smooth link field");
     }
     if (t.n_points > SGPMP_MAX_POINTS) return fail(SGPMP_EINVAL, "too many link points (max 32)");
-    HIPCHK(launch_field_grad(c->dims.dtype, c->dims.n_dof, t, c->d_chain, q, batch, spheres, n_spheres,
-                             value, grad, (hipStream_t)stream));
+    HIPCHK(launch_field_grad(c->dims.dtype, c->dims.n_dof, t, c->d_chain, c->h_chain.n_joints, q, batch,
+                             spheres, n_spheres, value, grad, (hipStream_t)stream));
     return SGPMP_OK;
 }
 

@@ -825,7 +825,9 @@ __global__ void ee_field_kernel(EeTarget<real> tg, const real* __restrict__ fram
 // F_j = sum g_l, M_j = sum p_l x g_l over the links behind revolute joint j (axis z_j through o_j),
 // accumulated from the end effector backwards.  Interpolated link points (fields.py:68-74) hand their
 // gradient to the two links they lie between.  One thread per configuration; any joint order.
-template <typename real>
+// NJ > 0: chain length known at compile time and no interpolated points -- every loop unrolls and the
+// per-thread arrays live in registers (NJ = 0 is the generic form, whose arrays go to scratch).
+template <typename real, int NJ>
 __global__ void __launch_bounds__(64)
 field_grad_kernel(const ChainDev* __restrict__ ch, TermK<real> tm, int n, const real* __restrict__ q,
                   long long batch, const real* __restrict__ spheres, int n_spheres,
@@ -834,11 +836,14 @@ field_grad_kernel(const ChainDev* __restrict__ ch, TermK<real> tm, int n, const 
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     const real* qb = q + (size_t)b * n;
-    const int nj = ch->n_joints;
-    real P[SGPMP_MAX_POINTS][3], G[SGPMP_MAX_POINTS][3];
-    real Z[SGPMP_MAX_JOINTS][3], Oj[SGPMP_MAX_JOINTS][3];
+    const int nj = NJ > 0 ? NJ : ch->n_joints;
+    constexpr int MP = NJ > 0 ? NJ + 1 : SGPMP_MAX_POINTS;
+    constexpr int MJ = NJ > 0 ? NJ : SGPMP_MAX_JOINTS;
+    real P[MP][3], G[MP][3];
+    real Z[MJ][3], Oj[MJ][3];
     real R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
     P[0][0] = P[0][1] = P[0][2] = 0;
+#pragma unroll
     for (int j = 0; j < nj; ++j) {
         const JointDev& J = ch->j[j];
         real F[9], tt[3], Rn[9];
@@ -863,16 +868,18 @@ field_grad_kernel(const ChainDev* __restrict__ ch, TermK<real> tm, int n, const 
     }
     const int n_links = nj + 1;
     int npts = n_links;
-    if (tm.n_interp > 0)
+    if (NJ == 0 && tm.n_interp > 0)
         for (int i = tm.interp_lo; i < tm.interp_hi; ++i)
             for (int a = 0; a < tm.n_interp; ++a, ++npts)
                 for (int r = 0; r < 3; ++r) P[npts][r] = P[i][r] + (P[i + 1][r] - P[i][r]) * tm.alpha[a];
+#pragma unroll
     for (int l = 0; l < npts; ++l) G[l][0] = G[l][1] = G[l][2] = 0;
     real val = 0;
     if (tm.kind == SGPMP_COST_SPHERES) {                     // rbf only (checked by the host)
         for (int o = 0; o < n_spheres; ++o) {
             const real cx = spheres[o * 4], cy = spheres[o * 4 + 1], cz = spheres[o * 4 + 2], rr = spheres[o * 4 + 3];
             const real ir2 = (real)1 / (rr * rr);
+#pragma unroll
             for (int l = 0; l < npts; ++l) {
                 const real dx = P[l][0] - cx, dy = P[l][1] - cy, dz = P[l][2] - cz;
                 const real e = O::exp_((real)-0.5 * (dx * dx + dy * dy + dz * dz) * ir2);
@@ -881,18 +888,22 @@ field_grad_kernel(const ChainDev* __restrict__ ch, TermK<real> tm, int n, const 
                 G[l][0] += w * dx; G[l][1] += w * dy; G[l][2] += w * dz;
             }
         }
-    } else {                                                 // SELF: full L x L sum, both triangles
-        for (int i = 0; i < npts; ++i)
-            for (int j = 0; j < npts; ++j) {
+    } else {                                                 // SELF: the full L x L sum of fields.py:124
+        // = diagonal (value 1 each, no gradient) + twice the strict lower triangle
+        val = (real)npts;
+#pragma unroll
+        for (int i = 1; i < npts; ++i)
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
                 const real dx = P[i][0] - P[j][0], dy = P[i][1] - P[j][1], dz = P[i][2] - P[j][2];
                 const real e = O::exp_((dx * dx + dy * dy + dz * dz) * tm.K2);
-                val += e;
-                const real w = (real)2 * tm.K2 * e;
+                val += (real)2 * e;
+                const real w = (real)4 * tm.K2 * e;
                 G[i][0] += w * dx; G[i][1] += w * dy; G[i][2] += w * dz;
                 G[j][0] -= w * dx; G[j][1] -= w * dy; G[j][2] -= w * dz;
             }
     }
-    if (tm.n_interp > 0) {                                   // interpolated points -> their two links
+    if (NJ == 0 && tm.n_interp > 0) {                                   // interpolated points -> their two links
         int m = n_links;
         for (int i = tm.interp_lo; i < tm.interp_hi; ++i)
             for (int a = 0; a < tm.n_interp; ++a, ++m)
@@ -905,6 +916,7 @@ field_grad_kernel(const ChainDev* __restrict__ ch, TermK<real> tm, int n, const 
     real Fs[3] = {0, 0, 0}, Ms[3] = {0, 0, 0};
     real* gb = grad + (size_t)b * n;
     for (int k = 0; k < n; ++k) gb[k] = 0;
+#pragma unroll
     for (int j = nj - 1; j >= 0; --j) {
         const int l = j + 1;
         Fs[0] += G[l][0]; Fs[1] += G[l][1]; Fs[2] += G[l][2];
@@ -921,20 +933,23 @@ field_grad_kernel(const ChainDev* __restrict__ ch, TermK<real> tm, int n, const 
     }
 }
 
-hipError_t launch_field_grad(int dtype, int n, const CostTerm& term, const ChainDev* d_chain, const void* q,
-                             long long batch, const void* spheres, int n_spheres, void* value, void* grad,
-                             hipStream_t stream) {
+hipError_t launch_field_grad(int dtype, int n, const CostTerm& term, const ChainDev* d_chain, int n_joints,
+                             const void* q, long long batch, const void* spheres, int n_spheres, void* value,
+                             void* grad, hipStream_t stream) {
     const int block = 64;
     const unsigned grid = (unsigned)((batch + block - 1) / block);
     if (grid == 0) return hipSuccess;
-    if (dtype == SGPMP_F64)
-        hipLaunchKernelGGL((field_grad_kernel<double>), dim3(grid), dim3(block), 0, stream, d_chain,
-                           make_termk<double>(term), n, (const double*)q, batch, (const double*)spheres,
-                           n_spheres, (double*)value, (double*)grad);
-    else
-        hipLaunchKernelGGL((field_grad_kernel<float>), dim3(grid), dim3(block), 0, stream, d_chain,
-                           make_termk<float>(term), n, (const float*)q, batch, (const float*)spheres,
-                           n_spheres, (float*)value, (float*)grad);
+#define FG_LAUNCH(REAL, NJ)                                                                         \
+    hipLaunchKernelGGL((field_grad_kernel<REAL, NJ>), dim3(grid), dim3(block), 0, stream, d_chain,  \
+                       make_termk<REAL>(term), n, (const REAL*)q, batch, (const REAL*)spheres,      \
+                       n_spheres, (REAL*)value, (REAL*)grad)
+    const int nj = term.n_interp > 0 ? 0 : n_joints;       // specialised chain lengths: 10 (Panda), 7
+    if (dtype == SGPMP_F64) {
+        if (nj == 10) FG_LAUNCH(double, 10); else if (nj == 7) FG_LAUNCH(double, 7); else FG_LAUNCH(double, 0);
+    } else {
+        if (nj == 10) FG_LAUNCH(float, 10); else if (nj == 7) FG_LAUNCH(float, 7); else FG_LAUNCH(float, 0);
+    }
+#undef FG_LAUNCH
     return hipGetLastError();
 }
 

@@ -115,9 +115,9 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
 hipError_t launch_ee_goal(int dtype, int n, int T, const CostTerm& term, const ChainDev* d_chain,
                           const void* trajs, long long batch, void* costs, double* costs64,
                           hipStream_t stream);
-hipError_t launch_field_grad(int dtype, int n, const CostTerm& term, const ChainDev* d_chain, const void* q,
-                             long long batch, const void* spheres, int n_spheres, void* value, void* grad,
-                             hipStream_t stream);
+hipError_t launch_field_grad(int dtype, int n, const CostTerm& term, const ChainDev* d_chain, int n_joints,
+                             const void* q, long long batch, const void* spheres, int n_spheres, void* value,
+                             void* grad, hipStream_t stream);
 hipError_t launch_fk(int dtype, int n, const ChainDev* d_chain, int n_links, const void* q,
                      long long batch, void* frames, hipStream_t stream);
 hipError_t launch_grid_lookup(int dtype, const CostTerm& term, const void* xy, long long batch,
