@@ -360,13 +360,44 @@ def gen_update_and_is():
     np.savez_compressed(os.path.join(OUT, "g5_update_is.npz"), **out)
 
 
+# ------------------------------------------------------------------------------ G6
+def gen_scene_tooling():
+    """Setup-side scene generators: the reference's `generate_obstacle_map` with
+    fixed + random obstacles on a coarse grid, and `random_init_static_sphere` (envs/panda.py:42-66,
+    imported with empty stand-in modules for the PyBullet imports of that file -- the function itself
+    is pure numpy) with the example's parameters (examples/panda_environment.py:124-133)."""
+    from stoch_gpmp.envs.obst_map import ObstacleCircle, ObstacleRectangle
+    for name in ("pybullet", "pybullet_data", "pybullet_utils", "pybullet_utils.bullet_client"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["pybullet_utils"].bullet_client = sys.modules["pybullet_utils.bullet_client"]
+    from stoch_gpmp.envs.panda import random_init_static_sphere
+    out = {}
+    for seed in (0, 7):
+        random.seed(seed)
+        np.random.seed(seed)
+        om, obs = generate_obstacle_map(map_dim=[10, 12], obst_list=[ObstacleRectangle(0, 0, 2, 3),
+                                                                     ObstacleCircle(-3, 2, 1.)],
+                                        cell_size=0.25, random_gen=True, num_obst=7,
+                                        rand_limits=[[-4, 4], [-5, 5]], rand_rect_shape=[1, 2],
+                                        rand_circle_radius=0.75, tensor_args=F64)
+        out[f"map/{seed}/grid"] = om.map.astype(np.uint8)
+        out[f"map/{seed}/n_obst"] = np.array(len(obs))
+        np.random.seed(seed)
+        sph = np.zeros((5, 4))
+        for i in range(5):
+            r, pos = random_init_static_sphere(0.1, 0.2, np.array([0.6, -0.2, 0.6]),
+                                               np.array([1., 0.2, 1]), 0.01)
+            sph[i, :3], sph[i, 3] = pos, r
+        out[f"spheres/{seed}"] = sph
+    np.savez_compressed(os.path.join(OUT, "g6_scene_tooling.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
-    gen_prior()
-    gen_planar_e2e()
-    gen_cost_terms()
-    gen_panda_fields()
-    gen_update_and_is()
+    gens = {"g1": gen_prior, "g2": gen_planar_e2e, "g3": gen_cost_terms, "g4": gen_panda_fields,
+            "g5": gen_update_and_is, "g6": gen_scene_tooling}
+    for key in (sys.argv[1:] or sorted(gens)):          # `python oracle/gen_golden.py g6` regenerates one
+        gens[key]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -172,6 +172,41 @@ def test_rasteriser_and_synthetic_scene(golden):
     assert ref.map_torch.shape == (200, 200)
 
 
+def test_scene_generators_reproduce_the_reference_scenes(golden):
+    """generate_obstacle_map (map_generator.py:9-92) and random_init_static_sphere (envs/panda.py:42-66)
+    consume the global `random` / `np.random` streams exactly like the reference: same seeds, same
+    scene -- the example's 200x200 grid (g2) and the fixed+random coarse maps / sphere sets of g6."""
+    import random
+    from stoch_gpmp_amd.envs.map_generator import generate_obstacle_map
+    from stoch_gpmp_amd.envs.obst_map import ObstacleCircle, ObstacleRectangle
+    from stoch_gpmp_amd.envs.spheres import random_init_static_sphere, spawn_obstacle_spheres
+    random.seed(0)
+    np.random.seed(0)
+    om, obs = generate_obstacle_map(map_dim=[20, 20], obst_list=[], cell_size=0.1, random_gen=True, num_obst=15,
+                                    rand_limits=[[-7.5, 7.5], [-7.5, 7.5]], rand_rect_shape=[2, 2], tensor_args=CPU)
+    assert len(obs) == 15 and np.array_equal(om.map, golden("g2_planar_e2e.npz")["grid"].astype(np.float64))
+    g = golden("g6_scene_tooling.npz")
+    for seed in (0, 7):
+        random.seed(seed)
+        np.random.seed(seed)
+        om, obs = generate_obstacle_map(map_dim=[10, 12], obst_list=[ObstacleRectangle(0, 0, 2, 3),
+                                                                     ObstacleCircle(-3, 2, 1.)],
+                                        cell_size=0.25, random_gen=True, num_obst=7,
+                                        rand_limits=[[-4, 4], [-5, 5]], rand_rect_shape=[1, 2],
+                                        rand_circle_radius=0.75, tensor_args=CPU)
+        assert len(obs) == int(g[f"map/{seed}/n_obst"])
+        assert np.array_equal(om.map, g[f"map/{seed}/grid"].astype(np.float64))
+        np.random.seed(seed)
+        sph = spawn_obstacle_spheres(5)
+        assert sph.shape == (1, 5, 4) and np.array_equal(sph[0].numpy(), g[f"spheres/{seed}"])
+    np.random.seed(0)
+    r, pos = random_init_static_sphere(0.1, 0.2, np.array([0.6, -0.2, 0.6]), np.array([1., 0.2, 1]), 0.01)
+    assert r == g["spheres/0"][0, 3] and np.array_equal(pos, g["spheres/0"][0, :3])
+    with pytest.raises(AssertionError):
+        generate_obstacle_map(map_dim=[10, 10], obst_list=[ObstacleRectangle(0, 0, 1, 1)] * 3, random_gen=True,
+                              num_obst=2, rand_limits=[[-1, 1], [-1, 1]], tensor_args=CPU)
+
+
 def test_factor_mirrors_expose_the_reference_quantities():
     from oracle import ref_equiv as R
     from stoch_gpmp_amd.costs.factors.field_factor import FieldFactor
