@@ -457,6 +457,7 @@ struct CostArgs {
     real is_dt;                 // time step of the sampling prior (Phi of the IS term)
     real* costs;
     double* costs64;
+    int rpp_shift, rpg_shift;   // log2 of rows_per_particle / rows_per_goal when a power of two, else -1
 };
 
 // A cost program with at most one term of each kind, as named fields (see cost_sweep_kernel.inc).
@@ -528,6 +529,9 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
     if (blocks < 1) blocks = 1;
     FlatProg<real> F;
     const bool flat = make_flat<real>(h_prog, F) && !getenv("SGPMP_NO_FLAT_PROGRAM");
+    auto log2_exact = [](long long v) { int s = 0; while ((1LL << s) < v && s < 62) ++s; return (1LL << s) == v ? s : -1; };
+    a.rpp_shift = log2_exact(a.rows_per_particle);
+    a.rpg_shift = (flat && F.has_goal) ? log2_exact(F.goal.rows_per_goal) : -1;
     if (reg && h_chain.plan.codegen_id == 1 && n == ChainCode_panda::N && !getenv("SGPMP_NO_CHAIN_CODEGEN")) {
         if constexpr (sizeof(real) == 4) {
             // two trajectories per wave on packed fp32 math (cost_sweep_dual.inc) when rows pair up
