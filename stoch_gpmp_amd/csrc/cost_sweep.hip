@@ -537,24 +537,30 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
             // two trajectories per wave on packed fp32 math (cost_sweep_dual.inc) when rows pair up
             const bool pairs_ok = (batch_offset % 2 == 0) && (!isw || a.rows_per_particle % 2 == 0) &&
                                   (!F.has_goal || F.goal.rows_per_goal % 2 == 0);
-            const bool sph_ok = !F.has_sph || ((F.sph.flags & 15) == SGPMP_FIELD_RBF && n_spheres <= SGPMP_SPH_LDS);
+            const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
+            const bool sph_ok = !F.has_sph || n_spheres <= SGPMP_SPH_LDS;
             if (flat && !F.has_grid && pairs_ok && sph_ok && !getenv("SGPMP_NO_DUAL_SWEEP")) {
                 long long pblocks = ((batch + 1) / 2 + 3) / 4;
                 long long pcap = 256LL * 12;          // 12 workgroups per CU: measured optimum (tools/k3_grid_sweep.sh)
                 if (const char* e = getenv("SGPMP_K3_BLOCKS")) pcap = atoll(e);
                 if (pblocks > pcap) pblocks = pcap;
                 if (pblocks < 1) pblocks = 1;
-                size_t pad = 0;                               // experiment: occupancy limiter
-                if (const char* e = getenv("SGPMP_K3_LDS_PAD")) pad = (size_t)atoll(e);
-                if (T <= 64 && T % 2 == 0 && !getenv("SGPMP_K3_NO_ONE") && !getenv("SGPMP_K3_NO_LDS_PREFETCH"))
-                    hipLaunchKernelGGL((cost_sweep_dual_pf_kernel<ChainCode_panda::N, ChainCode_panda>),
-                                       dim3((unsigned)pblocks), dim3(256), pad, stream, a, F);
-                else if (T <= 64 && !getenv("SGPMP_K3_NO_ONE"))
-                    hipLaunchKernelGGL((cost_sweep_dual_kernel<ChainCode_panda::N, ChainCode_panda, true>),
-                                       dim3((unsigned)pblocks), dim3(256), pad, stream, a, F);
-                else
-                    hipLaunchKernelGGL((cost_sweep_dual_kernel<ChainCode_panda::N, ChainCode_panda, false>),
-                                       dim3((unsigned)pblocks), dim3(256), 0, stream, a, F);
+                const bool pf = T <= 64 && T % 2 == 0 && !getenv("SGPMP_K3_NO_ONE") && !getenv("SGPMP_K3_NO_LDS_PREFETCH");
+                const bool one = T <= 64 && !getenv("SGPMP_K3_NO_ONE");
+#define DUAL_LAUNCH(FT)                                                                                    \
+                if (pf)                                                                                    \
+                    hipLaunchKernelGGL((cost_sweep_dual_pf_kernel<ChainCode_panda::N, ChainCode_panda, FT>),          \
+                                       dim3((unsigned)pblocks), dim3(256), 0, stream, a, F);               \
+                else if (one && FT == SGPMP_FIELD_RBF)                                                     \
+                    hipLaunchKernelGGL((cost_sweep_dual_kernel<ChainCode_panda::N, ChainCode_panda, true, SGPMP_FIELD_RBF>), \
+                                       dim3((unsigned)pblocks), dim3(256), 0, stream, a, F);               \
+                else                                                                                       \
+                    hipLaunchKernelGGL((cost_sweep_dual_kernel<ChainCode_panda::N, ChainCode_panda, false, FT>),      \
+                                       dim3((unsigned)pblocks), dim3(256), 0, stream, a, F)
+                if (ft == SGPMP_FIELD_RBF) { DUAL_LAUNCH(SGPMP_FIELD_RBF); }
+                else if (ft == SGPMP_FIELD_SDF) { DUAL_LAUNCH(SGPMP_FIELD_SDF); }
+                else { DUAL_LAUNCH(SGPMP_FIELD_OCCUPANCY); }
+#undef DUAL_LAUNCH
                 return hipGetLastError();
             }
         }
