@@ -9,7 +9,7 @@ synthetic data.  Workload at N = 1: BASELINE.json configs[2] -- Panda 7-DoF (14-
 particles x 128 samples x 64 waypoints, 5 synthetic sphere obstacles (rbf field) + self-collision,
 fp32 compute with the prior factored in fp64.  At N > 1 every rank holds 1024 particles of a
 (1024 N)-particle problem (configs[3] at N = 8: weak scaling, particles sharded, no data-path
-collective; a 4-double statistics all-reduce over RCCL per iteration).
+collective; a [64,4]-double statistics all-reduce over RCCL per iteration).
 
 Prints one JSON line (rank 0).  `roofline` prices the dominant kernel (the cost sweep) against the
 HBM peak using its algorithmic bytes N*w + P*S*8 and its average duration measured
@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--traj-len", type=int, default=None)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--field", default="rbf", choices=["rbf", "sdf", "occupancy"])
+    ap.add_argument("--spheres", type=int, default=5, help="number of sphere obstacles (panda; 64 = stress variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -56,9 +57,9 @@ def build_planner(args, torch, rank, world, dev):
         pl = W.hip_panda_planner(W.PANDA, T, P_local * world, S, ta, field_type=args.field, seed=0,
                                  rank=rank, world_size=world,
                                  force_stats_allreduce=os.environ.get("SGPMP_BENCH_FORCE_DIST") == "1")
-        obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres()).to(**ta)}
+        obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres(num=args.spheres)).to(**ta)}
         name = (f"Panda 7-DoF, {P_local * world} particles ({P_local}/GPU) x {S} samples x {T} waypoints, "
-                f"GP + goal-prior + self-collision + 5 sphere obstacles ({args.field}), synthetic")
+                f"GP + goal-prior + self-collision + {args.spheres} sphere obstacles ({args.field}), synthetic")
     else:
         from stoch_gpmp_amd.envs.obst_map import synthetic_obstacle_map
         P_local = args.particles or 256
@@ -98,7 +99,7 @@ def cpu_baseline(args, torch):
             # README.md:35); the reference must then be run in fp64, and so is its stand-in
             dtype = torch.float64
             ora = SC.oracle_panda_planner(W.PANDA, T, Pc, S, dtype=dtype, field_type=args.field, seed=0)
-        obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres()).to(dtype)}
+        obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres(num=args.spheres)).to(dtype)}
     else:
         from stoch_gpmp_amd.envs.obst_map import synthetic_obstacle_map
         S, T = args.samples or 64, args.traj_len or 128
@@ -210,7 +211,7 @@ def main():
         pf = dual and T <= 64 and T % 2 == 0 and not os.environ.get("SGPMP_K3_NO_LDS_PREFETCH")
         sweep_kernel = ("cost_sweep_dual_pf_kernel" if pf else "cost_sweep_dual_kernel") if dual else "cost_sweep_kernel"
         tf = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-        if os.path.exists(tf) and args.workload == "panda" and (P_local, S, T, args.dtype, args.field) == (1024, 128, 64, "f32", "rbf"):
+        if os.path.exists(tf) and args.workload == "panda" and (P_local, S, T, args.dtype, args.field, args.spheres) == (1024, 128, 64, "f32", "rbf", 5):
             kk = json.load(open(tf))["kernels"]
             traffic = kk.get(sweep_kernel, kk.get("cost_sweep_kernel", {})).get("bytes")
         out = {

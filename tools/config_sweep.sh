@@ -6,3 +6,6 @@ run --workload planar --particles 4 --samples 16 --traj-len 64 --dtype f64 --ste
 run --workload panda --particles 512 --samples 256 --traj-len 128 --steps 60 --warmup 10             # config 5 share
 run --workload panda --field sdf --steps 100 --warmup 10                        # config 3, sphere-SDF
 run --workload panda --dtype f64 --steps 30 --warmup 5                          # config 3 in fp64
+run --workload panda --field occupancy --steps 100 --warmup 10                  # config 3, occupancy count
+run --workload panda --spheres 64 --steps 60 --warmup 10                        # config 3, O = 64 stress variant
+run --workload panda --spheres 64 --field sdf --steps 60 --warmup 10
