@@ -272,3 +272,26 @@ def test_full_size_planar_fused_step_equals_separate_calls(golden):
     # goal-directedness: every particle's last waypoint stays near its own goal (sigma_goal 1e-3)
     end = a.particle_means[:, -1, :2].reshape(4, 64, 2).cpu()
     assert float((end - torch.tensor(goals)[:, None, :2]).abs().max()) < 0.05
+
+
+# --------------------------------------------------------------------------- example scripts
+def test_example_scripts_run_and_make_progress():
+    """examples/*.py are this package's versions of the reference's two example scripts; a short run
+    must lower the mean cost (planar) and bring the end effector towards the target (Panda)."""
+    import importlib.util
+    import os
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "examples")
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    planar = load("planar_environment")
+    pl0, c0 = planar.main(opt_iters=0, seed=3, num_samples=32, verbose=False)
+    pl1, c1 = planar.main(opt_iters=60, seed=3, num_samples=32, verbose=False)
+    assert c1.shape == c0.shape == (15, 32) and float(c1.mean()) < 0.5 * float(c0.mean())
+    panda = load("panda_environment")
+    p0, k0 = panda.main(opt_iters=0, seed=3, verbose=False)
+    p1, k1 = panda.main(opt_iters=80, seed=3, verbose=False)
+    assert k1.shape == (5, 32) and float(k1.min(1)[0].mean()) < float(k0.min(1)[0].mean())
