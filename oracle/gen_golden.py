@@ -392,11 +392,48 @@ def gen_scene_tooling():
     np.savez_compressed(os.path.join(OUT, "g6_scene_tooling.npz"), **out)
 
 
+# ------------------------------------------------------------------------------ G7
+def gen_gpmp():
+    """The reference's Gauss-Newton planner GPMP (planner.py:352-661) on a small Panda problem with
+    oracle.fk as the FK callable: particle means before / after each of 3 steps, the costs it reports,
+    for both damping modes."""
+    from stoch_gpmp.planner import GPMP
+    from tests import scenarios as SC
+    c, n, T, nppg = SC.PANDA, 7, 8, 3
+    start = torch.tensor(c["start_q"] + [0.] * n, **F64)
+    goals = torch.tensor([c["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n], **F64)
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F64)
+    out = {"dims": np.array([T, nppg]), "goals": npy(goals), "spheres": npy(sph)}
+    for tag, solver in (("tr", dict(delta=1e-2, trust_region=True, method='cholesky')),
+                        ("lm", dict(delta=5.0, trust_region=False, method='inverse'))):
+        cost = CostComposite(n, T, [
+            CostGP(n, T, start, c["dt"], dict(sigma_start=c["cost_sigma_start"], sigma_gp=c["cost_sigma_gp"]), F64),
+            CostGoalPrior(n, T, multi_goal_states=goals, num_particles_per_goal=nppg, num_samples=1,
+                          sigma_goal_prior=c["sigma_goal_prior"], tensor_args=F64),
+            CostCollision(n, T, field=LinkSelfDistanceField(margin=c["self_margin"], tensor_args=F64),
+                          sigma_coll=c["sigma_self"], tensor_args=F64),
+            CostCollision(n, T, field=LinkDistanceField(tensor_args=F64), sigma_coll=c["sigma_coll"],
+                          tensor_args=F64),
+        ], FK=fk_all_links, tensor_args=F64)
+        pl = GPMP(num_particles_per_goal=nppg, traj_len=T, opt_iters=1, dt=c["dt"], n_dof=n, step_size=0.5,
+                  temperature=1., start_state=start, multi_goal_states=goals, cost=cost,
+                  sigma_start_init=c["sigma_start_init"], sigma_start_sample=c["sigma_start_sample"],
+                  sigma_goal_init=c["sigma_goal_init"], sigma_goal_sample=c["sigma_goal_sample"],
+                  sigma_gp_init=c["sigma_gp_init"], sigma_gp_sample=c["sigma_gp_sample"], seed=0,
+                  solver_params=solver, tensor_args=F64)
+        out[f"{tag}/means0"] = npy(pl.particle_means)
+        for it in range(3):
+            vel, pos, costs = pl.optimize(obstacle_spheres=sph)
+            out[f"{tag}/means{it + 1}"] = npy(pl.particle_means)
+            out[f"{tag}/costs{it + 1}"] = npy(costs)
+    np.savez_compressed(os.path.join(OUT, "g7_gpmp.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
     gens = {"g1": gen_prior, "g2": gen_planar_e2e, "g3": gen_cost_terms, "g4": gen_panda_fields,
-            "g5": gen_update_and_is, "g6": gen_scene_tooling}
+            "g5": gen_update_and_is, "g6": gen_scene_tooling, "g7": gen_gpmp}
     for key in (sys.argv[1:] or sorted(gens)):          # `python oracle/gen_golden.py g6` regenerates one
         gens[key]()
     for f in sorted(os.listdir(OUT)):
