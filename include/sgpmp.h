@@ -198,6 +198,23 @@ int sgpmp_field_eval(sgpmp_ctx* ctx, int term, const void* frames, int64_t batch
 int sgpmp_field_grad(sgpmp_ctx* ctx, int term, const void* q, int64_t batch, const void* spheres,
                      int n_spheres, void* value, void* grad, void* stream);
 
+/* ---- GPMP: the reference's Gauss-Newton planner (planner.py:352-661) ------- */
+/* First half of GPMP._step (planner.py:580-581, cost.get_linear_system): evaluates every smooth link
+ * field of the cost list and its Jacobian at waypoints 1..T-1 of the particle means [P,T,d] (kept in
+ * the context), and -- when `diag_sum` [T*d] is given -- the sum over THIS context's particles of the
+ * field part of diag(A^T K A), which the trust-region damping averages over all particles
+ * (planner.py:618-622; all-reduce it across ranks before sgpmp_gpmp_solve when particles are sharded).
+ * The cost list may hold one CostGP, one CostGoalPrior and up to 4 rbf-sphere / self-distance fields. */
+int sgpmp_gpmp_linearize(sgpmp_ctx* ctx, const void* means, const void* spheres, int n_spheres,
+                         double* diag_sum, void* stream);
+/* Second half (planner.py:583-603): per particle, assemble the block-tridiagonal normal equations
+ * (A^T K A + damping) d_theta = A^T K b, solve them by block Cholesky, means += step_size * d_theta.
+ * diag_sum NULL: damping delta * I (trust_region=False); else delta * diag(mean_p A^T K A).
+ * d_theta [P,T,d] and costs [P] (= b^T K b at the linearisation point, planner.py:642-644) may be NULL.
+ * Synchronous; SGPMP_ENOTPD if a pivot is not positive (torch raises from cholesky in the reference). */
+int sgpmp_gpmp_solve(sgpmp_ctx* ctx, void* means, const double* diag_sum, double delta, double step_size,
+                     void* d_theta, void* costs, void* stream);
+
 /* Kernel timing helper for bench.py: elapsed ms between two events recorded on `stream`
  * (HIP events on the stream the kernels run on). */
 int sgpmp_event_create(void** ev);

@@ -62,6 +62,8 @@ SIGNATURES = {
     "sgpmp_grid_lookup": (_I, [_P, _I, _P, _I64, _P, _P]),
     "sgpmp_field_eval": (_I, [_P, _I, _P, _I64, _I, _P, _I, _P, _P]),
     "sgpmp_field_grad": (_I, [_P, _I, _P, _I64, _P, _I, _P, _P, _P]),
+    "sgpmp_gpmp_linearize": (_I, [_P, _P, _P, _I, _P, _P]),
+    "sgpmp_gpmp_solve": (_I, [_P, _P, _P, C.c_double, C.c_double, _P, _P, _P]),
     "sgpmp_event_create": (_I, [C.POINTER(_P)]),
     "sgpmp_event_record": (_I, [_P, _P]),
     "sgpmp_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),

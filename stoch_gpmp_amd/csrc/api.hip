@@ -40,6 +40,12 @@ struct sgpmp_ctx {
     bool have_chain;
     std::vector<void*> owned;     // device buffers holding term data (start / goal states)
     void* d_isw;                  // [P, T+1, d] importance-sampling weights (K5 output)
+    // GPMP (Gauss-Newton planner) scratch, allocated on first use
+    void* d_fval[4];              // per link-field term: [P, T-1] values
+    void* d_fgrad[4];             // [P, T-1, n] gradients
+    double* d_gscratch;           // [P][T][2][256] block factors
+    double* d_diag;               // [T*d] field part of sum_p diag(A^T K A)
+    int* d_gstatus;
     double* d_costs64;            // [P, S]
     bool profiling;
     std::vector<StepEvents> events;
@@ -89,6 +95,8 @@ extern "C" int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out) {
     c->esz = dims->dtype == SGPMP_F64 ? 8 : 4;
     c->d_qc = nullptr; c->d_prog = nullptr; c->d_chain = nullptr; c->d_isw = nullptr;
     c->d_costs64 = nullptr;
+    for (int i = 0; i < 4; ++i) { c->d_fval[i] = nullptr; c->d_fgrad[i] = nullptr; }
+    c->d_gscratch = nullptr; c->d_diag = nullptr; c->d_gstatus = nullptr;
     c->have_costs = false; c->prog_dirty = false; c->have_chain = false; c->profiling = false;
     std::memset(&c->h_prog, 0, sizeof(c->h_prog));
     std::memset(&c->h_chain, 0, sizeof(c->h_chain));
@@ -111,6 +119,8 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     free_prior(c->prior[1]);
     hipFree(c->d_qc); hipFree(c->d_prog); hipFree(c->d_chain); hipFree(c->d_isw);
     hipFree(c->d_costs64);
+    for (int i = 0; i < 4; ++i) { hipFree(c->d_fval[i]); hipFree(c->d_fgrad[i]); }
+    hipFree(c->d_gscratch); hipFree(c->d_diag); hipFree(c->d_gstatus);
     for (void* p : c->owned) hipFree(p);
     for (auto& se : c->events)
         for (auto& e : se.ev) hipEventDestroy(e);
@@ -564,8 +574,110 @@ extern "C" int sgpmp_field_grad(sgpmp_ctx* c, int term, const void* q, int64_t b
         return fail(SGPMP_EINVAL, "sgpmp_field_grad: term is not a smooth link field");
     }
     if (t.n_points > SGPMP_MAX_POINTS) return fail(SGPMP_EINVAL, "too many link points (max 32)");
-    HIPCHK(launch_field_grad(c->dims.dtype, c->dims.n_dof, t, c->d_chain, c->h_chain.n_joints, q, batch,
+    HIPCHK(launch_field_grad(c->dims.dtype, c->dims.n_dof, t, c->d_chain, c->h_chain.n_joints, q, batch, 0,
                              spheres, n_spheres, value, grad, (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
+// ---------------------------------------------------------------------------------- GPMP (Gauss-Newton)
+// Fill the kernel arguments from the cost program: GP term (+ start factor), goal prior, smooth link
+// fields.  Anything else in the cost list has no linear system here.
+static int gpmp_args(sgpmp_ctx* c, GpmpArgs& a, int* field_terms) {
+    const sgpmp_dims& D = c->dims;
+    std::memset(&a, 0, sizeof(a));
+    a.n = D.n_dof; a.T = D.traj_len; a.P = D.num_particles; a.p_offset = D.particle_offset;
+    bool have_gp = false;
+    for (int i = 0; i < c->h_prog.n_terms; ++i) {
+        const CostTerm& t = c->h_prog.terms[i];
+        switch (t.kind) {
+            case SGPMP_COST_GP:
+                if (have_gp) return fail(SGPMP_EINVAL, "GPMP: more than one GP term");
+                have_gp = true;
+                a.dt = t.dt; a.Kgp = t.K; a.c11 = t.c11; a.c12 = t.c12; a.c22 = t.c22;
+                if (t.flags & SGPMP_FLAG_GP_START) { a.Ks = t.K2; a.start = t.dev_data; }
+                break;
+            case SGPMP_COST_GOAL_PRIOR:
+                if (a.Kg > 0.) return fail(SGPMP_EINVAL, "GPMP: more than one goal prior");
+                a.Kg = t.K; a.goals = t.dev_data; a.rows_per_goal = D.num_particles_per_goal > 0 ? D.num_particles_per_goal : 1;
+                break;
+            case SGPMP_COST_SPHERES:
+                if ((t.flags & 15) != SGPMP_FIELD_RBF)
+                    return fail(SGPMP_EINVAL, "GPMP: only the rbf sphere field has a Jacobian");
+                /* fall through */
+            case SGPMP_COST_SELF:
+                if (a.n_fields == 4) return fail(SGPMP_EINVAL, "GPMP: more than 4 link-field terms");
+                field_terms[a.n_fields] = i;
+                a.f[a.n_fields].K = t.K;
+                a.n_fields += 1;
+                break;
+            default:
+                return fail(SGPMP_EINVAL, "GPMP: cost term without a linear system (grid / end-effector goal)");
+        }
+    }
+    if (!have_gp) return fail(SGPMP_EINVAL, "GPMP: the cost list needs a CostGP term");
+    if (a.T < 2 || a.T > SGPMP_MAX_T_GPMP) return fail(SGPMP_EINVAL, "GPMP: traj_len must be in [2, 128]");
+    return SGPMP_OK;
+}
+
+static int gpmp_alloc(sgpmp_ctx* c, const GpmpArgs& a) {
+    const size_t PT = (size_t)a.P * (a.T - 1);
+    for (int k = 0; k < a.n_fields; ++k) {
+        if (!c->d_fval[k]) HIPCHK(hipMalloc(&c->d_fval[k], PT * c->esz));
+        if (!c->d_fgrad[k]) HIPCHK(hipMalloc(&c->d_fgrad[k], PT * a.n * c->esz));
+    }
+    if (!c->d_gscratch) HIPCHK(hipMalloc(&c->d_gscratch, (size_t)a.P * a.T * 2 * 256 * sizeof(double)));
+    if (!c->d_diag) HIPCHK(hipMalloc(&c->d_diag, (size_t)a.T * 2 * a.n * sizeof(double)));
+    if (!c->d_gstatus) { HIPCHK(hipMalloc(&c->d_gstatus, sizeof(int))); HIPCHK(hipMemset(c->d_gstatus, 0, sizeof(int))); }
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_gpmp_linearize(sgpmp_ctx* c, const void* means, const void* spheres, int n_spheres,
+                                    double* diag_sum, void* stream) {
+    if (!c || !means) return fail(SGPMP_EINVAL, "sgpmp_gpmp_linearize: bad argument");
+    int rc;
+    if ((rc = finalize_program(c)) != SGPMP_OK) return rc;
+    GpmpArgs a;
+    int ft[4];
+    if ((rc = gpmp_args(c, a, ft)) != SGPMP_OK) return rc;
+    if (a.n_fields > 0 && !c->have_chain) return fail(SGPMP_ESTATE, "GPMP: link fields need an FK chain");
+    if ((rc = gpmp_alloc(c, a)) != SGPMP_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const long long B = (long long)a.P * (a.T - 1);
+    for (int k = 0; k < a.n_fields; ++k) {
+        const CostTerm& t = c->h_prog.terms[ft[k]];
+        if (t.kind == SGPMP_COST_SPHERES && (!spheres || n_spheres < 1))
+            return fail(SGPMP_EINVAL, "LinkDistanceField cost needs obstacle_spheres");
+        HIPCHK(launch_field_grad(c->dims.dtype, a.n, t, c->d_chain, c->h_chain.n_joints, means, B, a.T, spheres,
+                                 n_spheres, c->d_fval[k], c->d_fgrad[k], st));
+        a.f[k].val = c->d_fval[k];
+        a.f[k].grad = c->d_fgrad[k];
+    }
+    if (diag_sum) HIPCHK(launch_gpmp_diag(c->dims.dtype, a, diag_sum, st));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_gpmp_solve(sgpmp_ctx* c, void* means, const double* diag_sum, double delta,
+                                double step_size, void* d_theta, void* costs, void* stream) {
+    if (!c || !means || !(delta >= 0.)) return fail(SGPMP_EINVAL, "sgpmp_gpmp_solve: bad argument");
+    int rc;
+    if ((rc = finalize_program(c)) != SGPMP_OK) return rc;
+    GpmpArgs a;
+    int ft[4];
+    if ((rc = gpmp_args(c, a, ft)) != SGPMP_OK) return rc;
+    if (!c->d_gscratch) return fail(SGPMP_ESTATE, "sgpmp_gpmp_solve: call sgpmp_gpmp_linearize first");
+    for (int k = 0; k < a.n_fields; ++k) { a.f[k].val = c->d_fval[k]; a.f[k].grad = c->d_fgrad[k]; }
+    a.delta = delta; a.diag_sum = diag_sum; a.step_size = step_size; a.scratch = c->d_gscratch;
+    a.status = c->d_gstatus;
+    a.inv_particles = 1.0 / (double)(c->dims.num_particles_global > 0 ? c->dims.num_particles_global : a.P);
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(launch_gpmp_solve(c->dims.dtype, a, means, d_theta, costs, st));
+    int status = 0;                                   // synchronous, like sgpmp_set_prior: GPMP is not the hot path
+    HIPCHK(hipMemcpyAsync(&status, c->d_gstatus, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (status) {
+        HIPCHK(hipMemsetAsync(c->d_gstatus, 0, sizeof(int), st));
+        return fail(SGPMP_ENOTPD, "GPMP: normal matrix not positive definite");
+    }
     return SGPMP_OK;
 }
 

@@ -840,12 +840,15 @@ __global__ void ee_field_kernel(EeTarget<real> tg, const real* __restrict__ fram
 template <typename real, int NJ>
 __global__ void __launch_bounds__(64)
 field_grad_kernel(const ChainDev* __restrict__ ch, TermK<real> tm, int n, const real* __restrict__ q,
-                  long long batch, const real* __restrict__ spheres, int n_spheres,
+                  long long batch, int traj_T, const real* __restrict__ spheres, int n_spheres,
                   real* __restrict__ value, real* __restrict__ grad) {
     using O = RealOps<real>;
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    const real* qb = q + (size_t)b * n;
+    // traj_T = 0: q is [B, n].  traj_T = T: q is a trajectory batch [P, T, 2n] and configuration b is
+    // waypoint 1 + b % (T-1) of trajectory b / (T-1) (the waypoint range of CostCollision)
+    const real* qb = traj_T > 0 ? q + ((size_t)(b / (traj_T - 1)) * traj_T + 1 + b % (traj_T - 1)) * 2 * n
+                                : q + (size_t)b * n;
     const int nj = NJ > 0 ? NJ : ch->n_joints;
     constexpr int MP = NJ > 0 ? NJ + 1 : SGPMP_MAX_POINTS;
     constexpr int MJ = NJ > 0 ? NJ : SGPMP_MAX_JOINTS;
@@ -944,14 +947,14 @@ field_grad_kernel(const ChainDev* __restrict__ ch, TermK<real> tm, int n, const 
 }
 
 hipError_t launch_field_grad(int dtype, int n, const CostTerm& term, const ChainDev* d_chain, int n_joints,
-                             const void* q, long long batch, const void* spheres, int n_spheres, void* value,
-                             void* grad, hipStream_t stream) {
+                             const void* q, long long batch, int traj_T, const void* spheres, int n_spheres,
+                             void* value, void* grad, hipStream_t stream) {
     const int block = 64;
     const unsigned grid = (unsigned)((batch + block - 1) / block);
     if (grid == 0) return hipSuccess;
 #define FG_LAUNCH(REAL, NJ)                                                                         \
     hipLaunchKernelGGL((field_grad_kernel<REAL, NJ>), dim3(grid), dim3(block), 0, stream, d_chain,  \
-                       make_termk<REAL>(term), n, (const REAL*)q, batch, (const REAL*)spheres,      \
+                       make_termk<REAL>(term), n, (const REAL*)q, batch, traj_T, (const REAL*)spheres, \
                        n_spheres, (REAL*)value, (REAL*)grad)
     const int nj = term.n_interp > 0 ? 0 : n_joints;       // specialised chain lengths: 10 (Panda), 7
     if (dtype == SGPMP_F64) {

@@ -1,0 +1,273 @@
+// Gauss-Newton step of the reference's `GPMP` planner (planner.py:580-640), fused.
+//
+// The reference stacks every factor of the cost list into dense A [P, rows, N], b, K (N = T d), forms
+// J^T J = A^T K A + damping [P, N, N] and solves it densely (planner.py:607-640).  The normal matrix is
+// block-TRIDIAGONAL in d x d waypoint blocks:
+//   * start prior (cost_functions.py:154-158): K_s on block (0,0), rhs K_s (s - x_0);
+//   * GP factor i (cost_functions.py:160-166; H1 = Phi, H2 = -I): blocks (i,i) += Phi^T Q^-1 Phi,
+//     (i+1,i+1) += Q^-1, (i+1,i) = -Q^-1 Phi; rhs_i += Phi^T Q^-1 e_i, rhs_{i+1} -= Q^-1 e_i,
+//     e_i = x_{i+1} - Phi x_i;
+//   * goal prior (cost_functions.py:390-405): K_g on the last block, rhs K_g (goal - x_{T-1});
+//   * link field k at waypoint t >= 1 (cost_functions.py:263-279; A row = H = -grad f): the position
+//     block gets the rank-1 term K_k h h^T, rhs K_k h f;
+//   * damping (planner.py:613-622): delta I, or delta * diag(mean over ALL particles of A^T K A).
+// One wave per particle runs a forward block Cholesky over the waypoints (d x d tiles padded to 16 x 16
+// in LDS; products on the fp64 matrix cores, v_mfma_f64_16x16x4_f64) and a backward substitution;
+// L_t^-1 and W_t = E L_{t-1}^-T are parked in a context scratch buffer between the two sweeps.
+#include "sgpmp_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define TS SGPMP_TILE
+
+// C = alpha * op(A) * op(B) + beta * Cin on 16x16 row-major LDS tiles, one wave (operand maps as in
+// prior_factor.hip: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[row = (l>>4) + 4r][col = l&15]).
+__device__ __forceinline__ void gp_mm16(double* C, const double* A, const double* B, bool tA, bool tB,
+                                        double alpha, const double* Cin, double beta) {
+    const int l = threadIdx.x;
+    const int i = l & 15, kq = l >> 4;
+    d4 acc = {0., 0., 0., 0.};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int k = 4 * kb + kq;
+        const double a = tA ? A[k * TS + i] : A[i * TS + k];
+        const double b = tB ? B[i * TS + k] : B[k * TS + i];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    double cin[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cin[r] = Cin ? Cin[(kq + 4 * r) * TS + i] : 0.;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[(kq + 4 * r) * TS + i] = alpha * acc[r] + beta * cin[r];
+    __syncthreads();
+}
+
+template <typename real>
+__device__ __forceinline__ double ld(const void* p, size_t i) { return (double)((const real*)p)[i]; }
+
+// constant part of block (t,t) of A^T K A, element (r,c)
+__device__ __forceinline__ double gp_diag_const(const GpmpArgs& a, int t, int r, int c) {
+    const int n = a.n;
+    if ((r % n) != (c % n)) return 0.;
+    const bool rp = r < n, cp = c < n;
+    const double q = a.Kgp * (rp ? (cp ? a.c11 : a.c12) : (cp ? a.c12 : a.c22));
+    const double m = a.c11 * a.dt + a.c12;
+    const double pqp = a.Kgp * (rp ? (cp ? a.c11 : m) : (cp ? m : a.c11 * a.dt * a.dt + 2. * a.c12 * a.dt + a.c22));
+    double v = 0.;
+    if (t >= 1) v += q;                                  // Q^-1 of factor t-1
+    if (t <= a.T - 2) v += pqp;                          // Phi^T Q^-1 Phi of factor t
+    if (r == c) {
+        if (t == 0) v += a.Ks;
+        if (t == a.T - 1) v += a.Kg;
+    }
+    return v;
+}
+
+// sum over this rank's particles of the field part of diag(A^T K A): one thread per (t >= 1, joint j)
+template <typename real>
+__global__ void gpmp_diag_kernel(GpmpArgs a, double* __restrict__ diag_sum) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = 2 * a.n;
+    if (idx >= a.T * d) return;
+    const int t = idx / d, j = idx % d;
+    double s = 0.;
+    if (t >= 1 && j < a.n)
+        for (int k = 0; k < a.n_fields; ++k)
+            for (int p = 0; p < a.P; ++p) {
+                const double h = ld<real>(a.f[k].grad, ((size_t)p * (a.T - 1) + (t - 1)) * a.n + j);
+                s += a.f[k].K * h * h;
+            }
+    diag_sum[idx] = s;
+}
+
+template <typename real>
+__global__ void __launch_bounds__(64)
+gpmp_solve_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_theta, real* __restrict__ costs) {
+    __shared__ double S[TS * TS], L[TS * TS], Li[TS * TS], Lp[TS * TS], W[TS * TS], E[TS * TS];
+    __shared__ double mu[SGPMP_MAX_T_GPMP * TS], y[SGPMP_MAX_T_GPMP * TS], g[TS], r[TS], tmp[TS];
+    __shared__ double csum[64];
+    const int l = threadIdx.x, p = blockIdx.x;
+    const int n = a.n, d = 2 * n, T = a.T;
+    real* mp = means + (size_t)p * T * d;
+    double* scr = a.scratch + (size_t)p * T * 2 * TS * TS;
+    for (int e = l; e < T * TS; e += 64) {
+        const int t = e / TS, i = e % TS;
+        mu[e] = i < d ? (double)mp[t * d + i] : 0.;
+    }
+    for (int e = l; e < TS * TS; e += 64) {              // E = block (t, t-1) = -Q^-1 Phi, constant
+        const int rr = e / TS, c = e % TS;
+        double v = 0.;
+        if (rr < d && c < d && (rr % n) == (c % n)) {
+            const bool rp = rr < n, cp = c < n;
+            const double q1 = rp ? a.c11 : a.c12, q2 = rp ? a.c12 : a.c22;     // row of Q^-1: (pos col, vel col)
+            v = -a.Kgp * (cp ? q1 : q1 * a.dt + q2);                          // (Q^-1 Phi)[r][c]
+        }
+        E[e] = v;
+        Lp[e] = 0.; L[e] = 0.; Li[e] = 0.; W[e] = 0.;
+    }
+    __syncthreads();
+    const long long gi = a.Kg > 0. ? (a.p_offset + p) / a.rows_per_goal : 0;
+    double cost = 0.;                                    // b^T K b, accumulated by lane (i = l < d)
+
+    for (int t = 0; t < T; ++t) {
+        // ---- right-hand side g_t and the cost terms living at waypoint t
+        if (l < TS) {
+            double v = 0.;
+            if (l < d) {
+                const int k = l % n;
+                const bool pos = l < n;
+                if (t == 0 && a.Ks > 0.) {
+                    const double e0 = ld<real>(a.start, l) - mu[l];
+                    v += a.Ks * e0;
+                    cost += a.Ks * e0 * e0;
+                }
+                if (t == T - 1 && a.Kg > 0.) {
+                    const double eg = ld<real>(a.goals, (size_t)gi * d + l) - mu[t * TS + l];
+                    v += a.Kg * eg;
+                    cost += a.Kg * eg * eg;
+                }
+                if (t <= T - 2) {                         // factor t: e = x_{t+1} - Phi x_t ; rhs_t += Phi^T Q^-1 e
+                    const double ep = mu[(t + 1) * TS + k] - (mu[t * TS + k] + a.dt * mu[t * TS + n + k]);
+                    const double ev = mu[(t + 1) * TS + n + k] - mu[t * TS + n + k];
+                    const double qp = a.Kgp * (a.c11 * ep + a.c12 * ev), qv = a.Kgp * (a.c12 * ep + a.c22 * ev);
+                    v += pos ? qp : a.dt * qp + qv;
+                    cost += pos ? ep * qp : ev * qv;      // e^T Q^-1 e, split over the lanes of dof k
+                }
+                if (t >= 1) {                             // factor t-1: rhs_t -= Q^-1 e
+                    const double ep = mu[t * TS + k] - (mu[(t - 1) * TS + k] + a.dt * mu[(t - 1) * TS + n + k]);
+                    const double ev = mu[t * TS + n + k] - mu[(t - 1) * TS + n + k];
+                    v -= a.Kgp * (pos ? a.c11 * ep + a.c12 * ev : a.c12 * ep + a.c22 * ev);
+                    if (pos)
+                        for (int f = 0; f < a.n_fields; ++f) {
+                            const size_t o = (size_t)p * (T - 1) + (t - 1);
+                            const double fv = ld<real>(a.f[f].val, o);
+                            v += a.f[f].K * (-ld<real>(a.f[f].grad, o * n + l)) * fv;     // A row = -grad f
+                            if (l == 0) cost += a.f[f].K * fv * fv;
+                        }
+                }
+            }
+            g[l] = v;
+        }
+        // ---- S = D_t + damping - W W^T
+        for (int e = l; e < TS * TS; e += 64) {
+            const int rr = e / TS, c = e % TS;
+            double v = 0.;
+            if (rr < d && c < d) {
+                v = gp_diag_const(a, t, rr, c);
+                double fpart = 0.;
+                if (t >= 1 && rr < n && c < n)
+                    for (int f = 0; f < a.n_fields; ++f) {
+                        const size_t o = ((size_t)p * (T - 1) + (t - 1)) * n;
+                        fpart += a.f[f].K * ld<real>(a.f[f].grad, o + rr) * ld<real>(a.f[f].grad, o + c);
+                    }
+                v += fpart;
+                if (rr == c)
+                    v += a.diag_sum ? a.delta * (gp_diag_const(a, t, rr, rr) + a.diag_sum[t * d + rr] * a.inv_particles)
+                                    : a.delta;
+            } else if (rr == c) {
+                v = 1.;                                   // padding keeps the tile positive definite
+            }
+            S[e] = v;
+        }
+        __syncthreads();
+        if (t >= 1) {
+            gp_mm16(W, E, Lp, false, true, 1., nullptr, 0.);         // W = E L_{t-1}^-T
+            gp_mm16(S, W, W, false, true, -1., S, 1.);               // S -= W W^T
+            if (l < TS) {                                            // r = g - W y_{t-1}
+                double v = g[l];
+                for (int c = 0; c < d; ++c) v -= W[l * TS + c] * y[(t - 1) * TS + c];
+                r[l] = v;
+            }
+        } else if (l < TS) {
+            r[l] = g[l];
+        }
+        __syncthreads();
+        // ---- L L^T = S (lower), one column per step, lanes over rows
+        for (int j = 0; j < TS; ++j) {
+            if (l >= j && l < TS) {
+                double v = S[l * TS + j];
+                for (int k = 0; k < j; ++k) v -= L[l * TS + k] * L[j * TS + k];
+                tmp[l] = v;
+            }
+            __syncthreads();
+            const double piv = tmp[j];
+            if (!(piv > 0.) || !(piv < 1e300)) { if (l == 0) *a.status = 1; }
+            const double rt = sqrt(piv > 0. ? piv : 1.);
+            if (l < TS) L[l * TS + j] = l > j ? tmp[l] / rt : (l == j ? rt : 0.);
+            __syncthreads();
+        }
+        // ---- Li = L^-1 (forward substitution, lanes over columns)
+        for (int i = 0; i < TS; ++i) {
+            if (l < TS) {
+                double v = (i == l) ? 1. : 0.;
+                for (int k = 0; k < i; ++k) v -= L[i * TS + k] * Li[k * TS + l];
+                Li[i * TS + l] = v / L[i * TS + i];
+            }
+            __syncthreads();
+        }
+        if (l < TS) {                                               // y_t = L^-1 r
+            double v = 0.;
+            for (int c = 0; c <= l; ++c) v += Li[l * TS + c] * r[c];
+            y[t * TS + l] = v;
+        }
+        for (int e = l; e < TS * TS; e += 64) {                     // park L^-1 and W for the back sweep
+            scr[(size_t)(2 * t) * TS * TS + e] = Li[e];
+            scr[(size_t)(2 * t + 1) * TS * TS + e] = W[e];
+            Lp[e] = Li[e];
+        }
+        __syncthreads();
+    }
+    // ---- cost of the linearisation point (GPMP._get_costs, planner.py:642-644)
+    csum[l] = l < d ? cost : 0.;
+    __syncthreads();
+    if (l == 0) {
+        double c = 0.;
+        for (int i = 0; i < d; ++i) c += csum[i];
+        if (costs) costs[p] = (real)c;
+    }
+    // ---- backward: x_t = L_t^-T (y_t - W_{t+1}^T x_{t+1}), written into y in place
+    for (int t = T - 1; t >= 0; --t) {
+        for (int e = l; e < TS * TS; e += 64) Li[e] = scr[(size_t)(2 * t) * TS * TS + e];
+        __syncthreads();
+        if (l < TS) {
+            double v = y[t * TS + l];
+            if (t < T - 1)
+                for (int c = 0; c < d; ++c) v -= W[c * TS + l] * y[(t + 1) * TS + c];   // W currently = W_{t+1}
+            r[l] = v;
+        }
+        __syncthreads();
+        if (l < TS) {
+            double v = 0.;
+            for (int c = l; c < TS; ++c) v += Li[c * TS + l] * r[c];
+            y[t * TS + l] = v;
+        }
+        for (int e = l; e < TS * TS; e += 64) W[e] = scr[(size_t)(2 * t + 1) * TS * TS + e];   // W_t for step t-1
+        __syncthreads();
+    }
+    for (int e = l; e < T * d; e += 64) {
+        const int t = e / d, i = e % d;
+        const double x = y[t * TS + i];
+        if (d_theta) d_theta[(size_t)p * T * d + e] = (real)x;
+        mp[e] = (real)(mu[t * TS + i] + a.step_size * x);
+    }
+}
+
+hipError_t launch_gpmp_diag(int dtype, const GpmpArgs& a, double* diag_sum, hipStream_t stream) {
+    const int total = a.T * 2 * a.n;
+    const unsigned grid = (unsigned)((total + 63) / 64);
+    if (dtype == SGPMP_F64) hipLaunchKernelGGL((gpmp_diag_kernel<double>), dim3(grid), dim3(64), 0, stream, a, diag_sum);
+    else hipLaunchKernelGGL((gpmp_diag_kernel<float>), dim3(grid), dim3(64), 0, stream, a, diag_sum);
+    return hipGetLastError();
+}
+
+hipError_t launch_gpmp_solve(int dtype, const GpmpArgs& a, void* means, void* d_theta, void* costs,
+                             hipStream_t stream) {
+    if (a.P <= 0) return hipSuccess;
+    if (dtype == SGPMP_F64)
+        hipLaunchKernelGGL((gpmp_solve_kernel<double>), dim3(a.P), dim3(64), 0, stream, a, (double*)means,
+                           (double*)d_theta, (double*)costs);
+    else
+        hipLaunchKernelGGL((gpmp_solve_kernel<float>), dim3(a.P), dim3(64), 0, stream, a, (float*)means,
+                           (float*)d_theta, (float*)costs);
+    return hipGetLastError();
+}

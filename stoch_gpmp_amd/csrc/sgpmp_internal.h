@@ -116,8 +116,38 @@ hipError_t launch_ee_goal(int dtype, int n, int T, const CostTerm& term, const C
                           const void* trajs, long long batch, void* costs, double* costs64,
                           hipStream_t stream);
 hipError_t launch_field_grad(int dtype, int n, const CostTerm& term, const ChainDev* d_chain, int n_joints,
-                             const void* q, long long batch, const void* spheres, int n_spheres, void* value,
-                             void* grad, hipStream_t stream);
+                             const void* q, long long batch, int traj_T, const void* spheres, int n_spheres,
+                             void* value, void* grad, hipStream_t stream);
+// GPMP (gpmp.hip)
+#define SGPMP_MAX_T_GPMP 128
+struct GpmpFieldK {               // one link-field term of the cost list
+    double K;                     // 1 / sigma^2
+    const void* val;              // [P, T-1]   field values        (context dtype)
+    const void* grad;             // [P, T-1, n] d field / d q       (context dtype)
+};
+
+struct GpmpArgs {
+    int n, T, P;
+    long long p_offset;           // global index of particle 0 (goal lookup)
+    double dt, Kgp, c11, c12, c22;   // cost GP term: Q^-1 = Kgp [[c11, c12], [c12, c22]] (x) I_n
+    double Ks;                    // start prior weight (0: no start factor)
+    const void* start;            // [d] context dtype
+    double Kg;                    // goal prior weight (0: none)
+    const void* goals;            // [G, d]
+    long long rows_per_goal;      // particles per goal
+    int n_fields;
+    GpmpFieldK f[4];
+    double delta;
+    const double* diag_sum;       // [T*d] sum over all particles of the FIELD part of diag(A^T K A), or null
+    double inv_particles;         // 1 / (global particle count)
+    double step_size;
+    double* scratch;              // [P][T][2][256]
+    int* status;                  // set to 1 when a pivot is not positive
+};
+
+hipError_t launch_gpmp_diag(int dtype, const GpmpArgs& a, double* diag_sum, hipStream_t stream);
+hipError_t launch_gpmp_solve(int dtype, const GpmpArgs& a, void* means, void* d_theta, void* costs,
+                             hipStream_t stream);
 hipError_t launch_fk(int dtype, int n, const ChainDev* d_chain, int n_links, const void* q,
                      long long batch, void* frames, hipStream_t stream);
 hipError_t launch_grid_lookup(int dtype, const CostTerm& term, const void* xy, long long batch,

@@ -258,6 +258,32 @@ class Engine:
                                               L.ptr(value), L.ptr(grad), L.stream_ptr()))
         return value, grad
 
+    # ------------------------------------------------------------------ GPMP (Gauss-Newton planner)
+    def gpmp_linearize(self, means, spheres=None, diag_sum=None):
+        """Fields + Jacobians of the cost list at the particle means; optionally the local sum of the
+        field part of diag(A^T K A) into `diag_sum` [T*d] (fp64) for the trust-region damping."""
+        self._chk(means, "means")
+        n_sph = 0
+        if spheres is not None:
+            spheres = spheres.reshape(-1, 4)
+            self._chk(spheres, "obstacle_spheres")
+            n_sph = spheres.shape[0]
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_gpmp_linearize(self._ctx, L.ptr(means), L.ptr(spheres), n_sph,
+                                                  L.ptr(diag_sum), L.stream_ptr()))
+
+    def gpmp_solve(self, means, delta, step_size, diag_sum=None, d_theta=None, costs=None):
+        """Block-tridiagonal Gauss-Newton solve + in-place update of `means`; -> (d_theta, costs)."""
+        self._chk(means, "means")
+        if d_theta is None:
+            d_theta = torch.empty_like(means)
+        if costs is None:
+            costs = torch.empty(means.shape[0], **self.tensor_args)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_gpmp_solve(self._ctx, L.ptr(means), L.ptr(diag_sum), float(delta),
+                                              float(step_size), L.ptr(d_theta), L.ptr(costs), L.stream_ptr()))
+        return d_theta, costs
+
     # ------------------------------------------------------------------ profiling
     def profile_enable(self, on=True):
         L.check(self.lib.sgpmp_profile_enable(self._ctx, 1 if on else 0))

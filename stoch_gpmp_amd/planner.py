@@ -31,6 +31,7 @@ from .engine import Engine
 
 
 class StochGPMP:
+    _discard_draw_at_reset = True
 
     def __init__(
             self,
@@ -230,6 +231,8 @@ class StochGPMP:
         else:
             eng.set_costs([])
 
+        if not self._discard_draw_at_reset:              # GPMP.reset (planner.py:508-545) draws nothing more
+            return
         # the reference draws one throw-away batch here (planner.py:227); keep the stream aligned
         eps = None
         if self.noise == 'torch':
@@ -444,3 +447,6 @@ def print_info(opt_step, opt_iters, start_time_iter, start_time, costs):
               ' Total Time: %.3f ' % (now - start_time),
               ' Cost: %.6f' % float(costs.sum(-1).mean())]
     print('|'.join(fields))
+
+
+from .gpmp import GPMP  # noqa: E402,F401  (reference planner.py defines both planners in one module)

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from tests import scenarios as SC
-from tests.hip_builders import hip_panda_planner, hip_planar_planner
+from tests.hip_builders import hip_panda_planner, hip_planar_planner, hip_panda_cost
 
 pytestmark = pytest.mark.gpu
 
@@ -295,3 +295,66 @@ def test_example_scripts_run_and_make_progress():
     p0, k0 = panda.main(opt_iters=0, seed=3, verbose=False)
     p1, k1 = panda.main(opt_iters=80, seed=3, verbose=False)
     assert k1.shape == (5, 32) and float(k1.min(1)[0].mean()) < float(k0.min(1)[0].mean())
+
+
+# --------------------------------------------------------------------------- GPMP (Gauss-Newton)
+def _hip_gpmp(g, tag, ta, delta, trust, method="cholesky", **kw):
+    from stoch_gpmp_amd.planner import GPMP
+    c = SC.PANDA
+    T, nppg = [int(v) for v in g["dims"]]
+    n = 7
+    goals = torch.from_numpy(g["goals"]).to(**ta)
+    G = goals.shape[0]
+    cost = hip_panda_cost(c, T, nppg, 1, ta, goals=goals)
+    init = torch.from_numpy(g[f"{tag}/means0"]).to(**ta).reshape(G, nppg, T, 2 * n)
+    return GPMP(num_particles_per_goal=nppg, traj_len=T, opt_iters=1, dt=c["dt"], n_dof=n, step_size=0.5,
+                temperature=1., start_state=torch.tensor(c["start_q"] + [0.] * n, **ta), multi_goal_states=goals,
+                initial_particle_means=init, cost=cost,
+                sigma_start_init=c["sigma_start_init"], sigma_start_sample=c["sigma_start_sample"],
+                sigma_goal_init=c["sigma_goal_init"], sigma_goal_sample=c["sigma_goal_sample"],
+                sigma_gp_init=c["sigma_gp_init"], sigma_gp_sample=c["sigma_gp_sample"], seed=0,
+                solver_params=dict(delta=delta, trust_region=trust, method=method), tensor_args=ta, **kw)
+
+
+@pytest.mark.parametrize("tag,delta,trust", [("lm", 5.0, False), ("tr", 1e-2, True)])
+def test_gpmp_matches_reference_run_and_oracle(golden, tag, delta, trust):
+    """The Gauss-Newton planner: block-tridiagonal HIP solve against (a) the reference's own run for the
+    Levenberg mode with its correct 'inverse' solver (g7 fixture), (b) the dense oracle (proper solve)
+    step by step in both damping modes -- d_theta, costs and means."""
+    from oracle import gpmp_equiv as GP
+    from oracle.fk import fk_all_links
+    g = golden("g7_gpmp.npz")
+    T, nppg = [int(v) for v in g["dims"]]
+    goals, sph = torch.from_numpy(g["goals"]), torch.from_numpy(g["spheres"])
+    pl = _hip_gpmp(g, tag, F64, delta, trust)
+    ora = GP.OracleGPMP(torch.from_numpy(g[f"{tag}/means0"]),
+                        GP.panda_systems_fn(SC.PANDA, T, nppg, goals, fk_all_links), 0.5, delta, trust, "inverse")
+    for it in range(3):
+        d_o, c_o = ora.step(obstacle_spheres=sph)
+        vel, pos, costs = pl.optimize(obstacle_spheres=sph.to(**F64))
+        assert rel_err(pl._d_theta, d_o) < 1e-7
+        assert rel_err(costs, c_o) < 1e-9
+        assert rel_err(pl.particle_means, ora.particle_means) < 1e-8
+        assert torch.equal(pos, pl.particle_means[..., :7]) and torch.equal(vel, pl.particle_means[..., 7:])
+        if tag == "lm":                                   # the reference itself (its 'inverse' branch)
+            assert rel_err(pl.particle_means, torch.from_numpy(g[f"lm/means{it + 1}"])) < 1e-8
+            assert rel_err(costs, torch.from_numpy(g[f"lm/costs{it + 1}"])) < 1e-9
+
+
+def test_gpmp_fp32_and_errors(golden):
+    from oracle import gpmp_equiv as GP
+    from oracle.fk import fk_all_links
+    from stoch_gpmp_amd.planner import GPMP
+    g = golden("g7_gpmp.npz")
+    T, nppg = [int(v) for v in g["dims"]]
+    goals, sph = torch.from_numpy(g["goals"]), torch.from_numpy(g["spheres"])
+    pl = _hip_gpmp(g, "lm", F32, 5.0, False, method="inverse")
+    ora = GP.OracleGPMP(torch.from_numpy(g["lm/means0"]),
+                        GP.panda_systems_fn(SC.PANDA, T, nppg, goals, fk_all_links), 0.5, 5.0, False, "inverse")
+    d_o, c_o = ora.step(obstacle_spheres=sph)
+    _, _, costs = pl.optimize(obstacle_spheres=sph.to(**F32))
+    assert rel_err(costs, c_o) < 1e-4 and rel_err(pl.particle_means, ora.particle_means) < 1e-4
+    with pytest.raises(NotImplementedError):
+        _hip_gpmp(g, "lm", F64, 1.0, False, method="lu")
+    with pytest.raises(TypeError):
+        GPMP(num_particles_per_goal=1, traj_len=4, opt_iters=1, dt=0.1, n_dof=2, cost=None, tensor_args=F64)
