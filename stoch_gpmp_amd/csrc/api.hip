@@ -444,7 +444,7 @@ static int check_spheres(sgpmp_ctx* c, const void* spheres, int n_spheres) {
 extern "C" int sgpmp_cost_eval(sgpmp_ctx* c, const void* trajs, int64_t batch, int64_t batch_offset,
                                const void* spheres, int n_spheres, const void* is_weights,
                                int rows_per_particle, void* costs, double* costs64, void* stream) {
-    if (!c || !trajs || batch < 0) return fail(SGPMP_EINVAL, "sgpmp_cost_eval: bad argument");
+    if (!c || batch < 0 || (!trajs && batch > 0)) return fail(SGPMP_EINVAL, "sgpmp_cost_eval: bad argument");
     int rc;
     if ((rc = finalize_program(c)) != SGPMP_OK) return rc;
     if ((rc = check_spheres(c, spheres, n_spheres)) != SGPMP_OK) return rc;

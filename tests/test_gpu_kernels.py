@@ -547,3 +547,49 @@ def test_update_with_fp32_costs_tensor():
     close(wts, w, 1e-6)
     close(gr, grad, 1e-5, atol=1e-7)
     close(m_dev, means.double() + 0.25 * grad, 1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------- edge cases of K3
+@pytest.mark.parametrize("S,T,n_sph,field_type", [
+    (7, 20, 6, "rbf"),          # odd rows per particle -> single-trajectory sweep with IS weights
+    (6, 21, 6, "rbf"),          # odd T <= 64 -> two-trajectory sweep without the LDS prefetch
+    (6, 2, 3, "sdf"),           # shortest trajectory (one GP factor)
+    (4, 64, 1, "occupancy"),    # exactly one full pass, one sphere
+    (4, 66, 130, "rbf"),        # more spheres than the LDS staging holds -> falls back; T just over a pass
+    (5, 64, 40, "sdf"),         # odd batch tail (5 rows: last pair has one row)
+])
+def test_cost_sweep_dispatch_corners_match_oracle_fp32(S, T, n_sph, field_type):
+    """Every dispatch corner of the Panda cost sweep in fp32 -- pairing rules, pass counts, sphere
+    staging limit, odd tails -- against the fp64 oracle, with and without the importance-sampling term."""
+    from tests.hip_builders import hip_panda_cost
+    c, n, nppg = SC.PANDA, 7, 1
+    g = torch.Generator().manual_seed(S * 100 + T)
+    trajs = torch.cat([torch.rand(nppg, S, T, n, generator=g) * 3 - 1.5,
+                       torch.randn(nppg, S, T, n, generator=g) * 0.1], dim=-1).double()
+    sph = torch.as_tensor(SC.panda_spheres(num=n_sph, seed=5))
+    ora = SC.oracle_panda_cost(c, T, nppg, S, torch.float64, field_type=field_type)
+    ora.terms = ora.terms[2:]                                  # collision fields only (GP would swamp them)
+    ref = ora.eval(trajs, obstacle_spheres=sph)
+    hip = hip_panda_cost(c, T, nppg, S, F32, field_type=field_type)
+    hip.cost_list = hip.cost_list[2:]
+    out = hip.eval(trajs.to(**F32), obstacle_spheres=sph.to(**F32))
+    close(out, ref, 3e-4, atol=3e-6 * float(ref.abs().max()))
+    # full composite through the engine with IS weights: compare against the fp64 engine path
+    full32 = hip_panda_cost(c, T, nppg, S, F32, field_type=field_type)
+    full64 = hip_panda_cost(c, T, nppg, S, F64, field_type=field_type)
+    e32, e64 = full32._engine(torch.float32, DEV), full64._engine(torch.float64, DEV)
+    w = torch.randn(nppg, T + 1, 2 * n, generator=g).double()
+    o32 = e32.cost_eval(trajs.to(**F32).contiguous(), spheres=sph.to(**F32).reshape(-1, 4).contiguous(),
+                        is_weights=w.to(**F32).contiguous(), rows_per_particle=S)
+    o64 = e64.cost_eval(trajs.to(**F64).contiguous(), spheres=sph.to(**F64).reshape(-1, 4).contiguous(),
+                        is_weights=w.to(**F64).contiguous(), rows_per_particle=S)
+    close(o32, o64, 2e-4)
+
+
+def test_zero_sized_batches_are_no_ops():
+    from tests.hip_builders import hip_planar_cost
+    from stoch_gpmp_amd.envs.obst_map import synthetic_obstacle_map
+    om = synthetic_obstacle_map(seed=1, tensor_args=F64)
+    cost = hip_planar_cost(SC.PLANAR, 8, [[9., 6., 0., 0.]], 1, 4, om, F64)
+    out = cost.eval(torch.zeros(0, 8, 4, **F64))
+    assert out.shape == (0,)
