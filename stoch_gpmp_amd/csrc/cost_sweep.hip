@@ -541,7 +541,7 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
             const bool sph_ok = !F.has_sph || n_spheres <= SGPMP_SPH_LDS;
             if (flat && !F.has_grid && pairs_ok && sph_ok && !getenv("SGPMP_NO_DUAL_SWEEP")) {
                 long long pblocks = ((batch + 1) / 2 + 3) / 4;
-                long long pcap = 256LL * 12;          // 12 workgroups per CU: measured optimum (tools/k3_grid_sweep.sh)
+                long long pcap = 256LL * 20;          // 20 workgroups per CU (4 resident): measured optimum (tools/k3_grid_sweep.sh)
                 if (const char* e = getenv("SGPMP_K3_BLOCKS")) pcap = atoll(e);
                 if (pblocks > pcap) pblocks = pcap;
                 if (pblocks < 1) pblocks = 1;
