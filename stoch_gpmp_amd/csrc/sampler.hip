@@ -10,6 +10,7 @@
 // G_t = g_t (x) I_n and H_t = h_t (x) I_n with 2x2 g_t, h_t): one thread per (sample, dof) runs a
 // 7-FMA recurrence on (position_k, velocity_k); coefficients are wave-uniform scalar loads.
 // Dense path (user-supplied Q_c_inv): one thread per sample carries the full d-vector.
+#include <cstdlib>
 #include "sgpmp_internal.h"
 #include "rng.h"
 
@@ -136,6 +137,90 @@ sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*
     }
 }
 
+// Few-wave launches (BASELINE config 1: 4 waves on 1024 SIMDs).  In the kernel above a
+// wave walks its chains through all T waypoints, one Philox block after the other: with nothing else
+// resident to hide behind, that is T/2 dependent ~0.5 us steps (fp64: T steps of ~0.7 us).  Here the
+// noise of a 32-waypoint chunk is produced by ALL threads of the workgroup in parallel (one Philox
+// block each), parked in the LDS tile, and only the cheap 7-FMA recurrence runs serially, in place;
+// the tile is then flushed as row segments.  Same counter layout and the same recurrence expressions
+// as above, so the two kernels return identical samples.
+#define SGPMP_SMALL_TC 32
+#define SGPMP_SMALL_SPB 8
+template <typename real>
+__global__ void __launch_bounds__(256)
+sample_iso_small_kernel(int n, int T, int S, const real* __restrict__ coef, const real* __restrict__ means,
+                        int mode_offset, uint64_t seed, uint64_t draw, real* __restrict__ out) {
+    typedef real vec __attribute__((ext_vector_type(2)));
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int TC = SGPMP_SMALL_TC, SPB = SGPMP_SMALL_SPB;
+    const int m = blockIdx.y, d = 2 * n, pitch = TC * d + 4;
+    real* tile = reinterpret_cast<real*>(lds_raw);        // [SPB][TC*d + 4]
+    real* cf = tile + (size_t)SPB * pitch;                // [TC][8] recurrence coefficients of the chunk
+    const int s0 = blockIdx.x * SPB;
+    const int rows = min(SPB, S - s0);
+    const int chains = rows * n;
+    const int tid = threadIdx.x;
+    const size_t M = (size_t)T * d;
+    const real* mu = means + (size_t)m * M;
+    const int sl_scan = tid / n, k_scan = tid - sl_scan * n;
+    real p = 0, v = 0;
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int tc = min(TC, T - t0);
+        // ---- phase 1: noise of this chunk, one RNG block per thread and trip (+ the coefficients: the
+        // serial phase must not wait for global memory at every waypoint)
+        for (int w = tid; w < tc * 8; w += blockDim.x) cf[w] = coef[(size_t)t0 * 8 + w];
+        if (sizeof(real) == 4) {
+            const int pairs = (tc + 1) >> 1;              // t0 is even: blocks cover waypoints (2b, 2b+1)
+            for (int w = tid; w < chains * pairs; w += blockDim.x) {
+                const int c = w / pairs, b = w - c * pairs;
+                const int sl = c / n, k = c - sl * n;
+                NoiseGen<real> gen;
+                gen.init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)(s0 + sl), (uint32_t)k);
+                real e[4];
+                gen.get4(t0 + 2 * b, e);
+                real* o = tile + (size_t)sl * pitch + (2 * b) * d + k;
+                o[0] = e[0]; o[n] = e[1];
+                if (2 * b + 1 < tc) { o[d] = e[2]; o[d + n] = e[3]; }
+            }
+        } else {
+            for (int w = tid; w < chains * tc; w += blockDim.x) {
+                const int c = w / tc, tt = w - c * tc;
+                const int sl = c / n, k = c - sl * n;
+                NoiseGen<real> gen;
+                gen.init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)(s0 + sl), (uint32_t)k);
+                real e1, e2;
+                gen.get(t0 + tt, e1, e2);
+                real* o = tile + (size_t)sl * pitch + tt * d + k;
+                o[0] = e1; o[n] = e2;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: the recurrence, in place, one thread per chain
+        if (tid < chains) {
+            const real* c = cf;
+            real* o = tile + (size_t)sl_scan * pitch + k_scan;
+#pragma unroll 4
+            for (int tt = 0; tt < tc; ++tt, c += 8, o += d) {
+                const real e1 = o[0], e2 = o[n];
+                const real pn = c[0] * e1 + c[3] * p + c[4] * v;
+                const real vn = c[1] * e1 + c[2] * e2 + c[5] * p + c[6] * v;
+                p = pn; v = vn;
+                o[0] = p; o[n] = v;
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: flush row segments, x = mu + y
+        const int seg = tc * d / 2;
+        for (int w = tid; w < rows * seg; w += blockDim.x) {
+            const int r = w / seg, j = w - r * seg;
+            vec val = *reinterpret_cast<const vec*>(tile + (size_t)r * pitch + j * 2);
+            val += *reinterpret_cast<const vec*>(mu + (size_t)t0 * d + j * 2);
+            *reinterpret_cast<vec*>(out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d + j * 2) = val;
+        }
+        __syncthreads();
+    }
+}
+
 template <typename real, int N>
 __global__ void __launch_bounds__(128)
 sample_dense_kernel(int T, int S, const real* __restrict__ G, const real* __restrict__ H,
@@ -195,6 +280,15 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
         const int d = 2 * n;
         const int spw = 64 / n;                          // samples per wave (one lane per (sample, dof))
         int waves = (S + spw - 1) / spw;                 // waves needed per mode
+        if (!eps && (long long)waves * n_modes < 256 && !getenv("SGPMP_NO_SMALL_SAMPLER")) {
+            // less than one wave per CU: noise in parallel, recurrence from LDS (config 1: 48 -> 16 us;
+            // at config 2's 512 waves the standard kernel is still the faster one, 33 vs 45 us)
+            dim3 sgrid((S + SGPMP_SMALL_SPB - 1) / SGPMP_SMALL_SPB, n_modes);
+            const size_t slds = ((size_t)SGPMP_SMALL_SPB * (SGPMP_SMALL_TC * d + 4) + SGPMP_SMALL_TC * 8) * sizeof(real);
+            hipLaunchKernelGGL((sample_iso_small_kernel<real>), sgrid, dim3(256), slds, stream, n, T, S, coef, means,
+                               mode_offset, seed, draw, out);
+            return hipGetLastError();
+        }
         const int wpb = waves < 4 ? waves : 4;
         dim3 grid((waves + wpb - 1) / wpb, n_modes), block(64 * wpb);
         const size_t lds = (size_t)wpb * spw * (SGPMP_SAMPLE_TC * d + 4) * sizeof(real);

@@ -183,13 +183,17 @@ def test_native_noise_statistics_and_sharding_invariance(dtype):
 
 
 @pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
-@pytest.mark.parametrize("n,T,dense", [(2, 9, False), (7, 64, False), (3, 12, True)])
-def test_native_noise_samples_match_the_restated_stream(n, T, dense, dtype, rtol):
+@pytest.mark.parametrize("n,T,dense", [(2, 9, False), (7, 64, False), (3, 12, True), (2, 70, "standard"),
+                                        (7, 33, "standard")])
+def test_native_noise_samples_match_the_restated_stream(monkeypatch, n, T, dense, dtype, rtol):
     """The in-kernel Philox4x32-10 + Box-Muller stream, restated on the CPU (oracle/native_noise.py,
     pinned by the Random123 known-answer vectors), fed through the oracle's dense sampler must give
     the samples the HIP sampler produces from (seed, draw, global particle index) alone."""
     from oracle.native_noise import native_eps
     from stoch_gpmp_amd import _lib as L
+    if dense == "standard":       # tiny launches take sample_iso_small_kernel; this forces the main kernel
+        monkeypatch.setenv("SGPMP_NO_SMALL_SAMPLER", "1")
+        dense = False
     dt, ss, sg, sgoal, modes, S, off = 0.1, 0.3, 1.0, 0.4, 3, 11, 5
     d = 2 * n
     seed, draw = 0x1234567887654321, 77
