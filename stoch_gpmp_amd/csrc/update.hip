@@ -58,7 +58,26 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
         cmin = cv < cmin ? cv : cmin;
         csum += cv;
     }
-    zmax = -block_reduce<double>(-zmax, scratch, true);
+    // one combined reduction for (max z, sum c, min c): three block reductions cost nine barriers
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double oz = __shfl_xor(zmax, off, 64), os = __shfl_xor(csum, off, 64), om = __shfl_xor(cmin, off, 64);
+            zmax = oz > zmax ? oz : zmax;
+            csum += os;
+            cmin = om < cmin ? om : cmin;
+        }
+        __shared__ double red3[3 * 4];
+        if (lane == 0) { red3[wave] = zmax; red3[4 + wave] = csum; red3[8 + wave] = cmin; }
+        __syncthreads();
+        zmax = red3[0]; csum = red3[4]; cmin = red3[8];
+        for (int i = 1; i < nw; ++i) {
+            zmax = red3[i] > zmax ? red3[i] : zmax;
+            csum += red3[4 + i];
+            cmin = red3[8 + i] < cmin ? red3[8 + i] : cmin;
+        }
+    }
     double part = 0.;
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
         const double e = exp(w[s] - zmax);
@@ -67,8 +86,7 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
     }
     const double Z = block_reduce<double>(part, scratch, false);
     if (stats) {
-        const double tot = block_reduce<double>(csum, scratch, false);
-        const double mn = block_reduce<double>(cmin, scratch, true);
+        const double tot = csum, mn = cmin;
         if (threadIdx.x == 0) {
             // 64 shards of 4 doubles: a thousand workgroups adding to one address serialise
             // at the memory side (~30 us); the consumer sums the shards
@@ -174,13 +192,13 @@ __global__ void is_weights_kernel(int n, int T, int P, const real* __restrict__ 
                                   double temperature, int isotropic, real* __restrict__ out,
                                   double* __restrict__ zero_stats) {
     const int d = 2 * n;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (zero_stats && idx < SGPMP_STAT_SHARDS * 4) zero_stats[idx] = 0.;   // this step's statistics start from zero
-    const long long total = (long long)P * (T + 1) * d;
-    if (idx >= total) return;
-    const int i = (int)(idx % d);
-    const int t = (int)((idx / d) % (T + 1));
-    const int p = (int)(idx / ((long long)d * (T + 1)));
+    // grid = (ceil((T+1) d / 256), P): 32-bit index arithmetic (64-bit div / mod cost more than the math)
+    const int p = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_stats && p == 0 && e < SGPMP_STAT_SHARDS * 4) zero_stats[e] = 0.;   // this step's statistics start from zero
+    if (e >= (T + 1) * d) return;
+    const int t = e / d, i = e - t * d;
+    const size_t idx = (size_t)p * (T + 1) * d + e;
     const real* mu = means + (size_t)p * T * d;
     double v;
     if (t == T) {                       // spare block (kept for layout stability): unused by K3
@@ -223,13 +241,13 @@ hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& prior, con
     const long long total = (long long)n_particles * (T + 1) * 2 * n;
     if (total <= 0) return hipSuccess;
     const int block = 256;
-    const unsigned grid = (unsigned)((total + block - 1) / block);
+    const dim3 grid((unsigned)(((T + 1) * 2 * n + block - 1) / block), (unsigned)n_particles);
     if (dtype == SGPMP_F64)
-        hipLaunchKernelGGL((is_weights_kernel<double>), dim3(grid), dim3(block), 0, stream, n, T,
+        hipLaunchKernelGGL((is_weights_kernel<double>), grid, dim3(block), 0, stream, n, T,
                            n_particles, (const double*)means, prior.Qinv, prior.ks, prior.kg, prior.dt,
                            temperature, prior.isotropic, (double*)out, zero_stats);
     else
-        hipLaunchKernelGGL((is_weights_kernel<float>), dim3(grid), dim3(block), 0, stream, n, T,
+        hipLaunchKernelGGL((is_weights_kernel<float>), grid, dim3(block), 0, stream, n, T,
                            n_particles, (const float*)means, prior.Qinv, prior.ks, prior.kg, prior.dt,
                            temperature, prior.isotropic, (float*)out, zero_stats);
     return hipGetLastError();
