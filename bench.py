@@ -129,6 +129,20 @@ def cpu_baseline(args, torch):
     dt, threads = best
     its = 1.0 / dt
     cores_used = threads
+    # a second measured point at twice the particles (same thread count), to show that the per-particle
+    # extrapolation is linear ("report measured points"); skipped if it would take too long
+    points = [{"particles": Pc, "it_per_s": its}]
+    if args.workload == "panda" and dt * 2 * (args.cpu_iters + 1) < 15.0:
+        try:
+            ora2 = SC.oracle_panda_planner(W.PANDA, T, 2 * Pc, S, dtype=dtype, field_type=args.field, seed=0)
+            torch.set_num_threads(threads)
+            ora2.step(**obs)
+            t0 = time.perf_counter()
+            for _ in range(args.cpu_iters):
+                ora2.step(**obs)
+            points.append({"particles": 2 * Pc, "it_per_s": args.cpu_iters / (time.perf_counter() - t0)})
+        except Exception:                                   # (memory) keep the first point
+            pass
     return {
         "value": its * Pc / P_full, "unit": "iterations/s", "cores": cores_used, "kind": "port",
         "sample": (f"{Pc} of {P_full} particles at full S={S}, T={T}, {str(dtype).split('.')[-1]}, "
@@ -136,7 +150,7 @@ def cpu_baseline(args, torch):
                    f"several torch thread counts ({threads} threads of {cores} host cores); "
                    f"measured {its:.3f} it/s at P={Pc}; value = per-particle linear extrapolation to "
                    f"P={P_full} (the dense reference algorithm needs ~0.4 GB per particle)"),
-        "measured_it_per_s_at_sample": its, "sample_particles": Pc,
+        "measured_it_per_s_at_sample": its, "sample_particles": Pc, "measured_points": points,
         "torch_threads": threads, "host_cores": cores,
     }
 
