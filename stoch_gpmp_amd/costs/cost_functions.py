@@ -48,8 +48,9 @@ class Cost(ABC):
         return self._solo.eval(trajs, **observation)
 
     def get_linear_system(self, trajs, **observation):
-        raise NotImplementedError("get_linear_system serves the Gauss-Newton GPMP planner, which is "
-                                  "outside the StochGPMP hot path built here (SURVEY.md 8f)")
+        """Dense (A, b, K) of this cost for inspection / user code.  `GPMP` itself never builds these:
+        it consumes the same factors in block-tridiagonal form on the GPU (csrc/gpmp.hip)."""
+        raise NotImplementedError(f"{type(self).__name__} has no linear system")
 
 
 class CostComposite(Cost):
@@ -88,6 +89,24 @@ class CostComposite(Cost):
                                 "at the planner level (StochGPMP accepts any object with .eval)")
             out.extend(cost.descriptors())
         return out
+
+    def get_linear_system(self, trajs, **observation):
+        """cost_functions.py:60-85: rows of all children stacked, K block-diagonal.  Assembly is plain
+        tensor indexing (as in the reference); the field Jacobians inside come from the HIP kernel."""
+        trajs = trajs.reshape(-1, self.traj_len, self.dim)
+        As, bs, Ks = [], [], []
+        for cost in self.cost_list:
+            A, b, K = cost.get_linear_system(trajs, **observation)
+            if A is None or b is None or K is None:
+                continue
+            As.append(A.detach()); bs.append(b.detach()); Ks.append(K.detach())
+        A, b = torch.cat(As, dim=1), torch.cat(bs, dim=1)
+        K = torch.zeros(trajs.shape[0], A.shape[1], A.shape[1], device=trajs.device, dtype=trajs.dtype)
+        o = 0
+        for Ki in Ks:
+            K[:, o:o + Ki.shape[1], o:o + Ki.shape[1]] = Ki
+            o += Ki.shape[1]
+        return A, b, K
 
     def compile_into(self, engine):
         """Load this composite (and its FK chain) into an Engine's cost program."""
@@ -139,6 +158,27 @@ class CostGP(Cost):
     def descriptors(self):
         return [dict(kind=L.COST_GP, flags=L.FLAG_GP_START, sigma=self.sigma_gp, sigma2=self.sigma_start,
                      dt=self.dt, host_data=_host_list(self.start_state))]
+
+    def get_linear_system(self, trajs, x_trajs=None, **observation):
+        """cost_functions.py:148-168: start factor (H = I) in the first block row, GP factor i
+        (H1 = Phi on waypoint i, H2 = -I on waypoint i+1) in block row i+1."""
+        trajs = trajs.reshape(-1, self.traj_len, self.dim)
+        B, T, d = trajs.shape[0], self.traj_len, self.dim
+        kw = dict(device=trajs.device, dtype=trajs.dtype)
+        A = torch.zeros(B, d * T, d * T, **kw)
+        b = torch.zeros(B, d * T, 1, **kw)
+        K = torch.zeros(B, d * T, d * T, **kw)
+        eye = torch.eye(d, **kw)
+        A[:, :d, :d] = eye
+        b[:, :d, 0] = self.start_state.to(**kw) - trajs[:, 0]
+        K[:, :d, :d] = self.start_prior.K.to(**kw)
+        phi, Q_inv = self.gp_prior.phi.to(**kw), self.gp_prior.Q_inv[0].to(**kw)
+        for i in range(T - 1):
+            A[:, (i + 1) * d:(i + 2) * d, i * d:(i + 1) * d] = phi
+            A[:, (i + 1) * d:(i + 2) * d, (i + 1) * d:(i + 2) * d] = -eye
+            b[:, (i + 1) * d:(i + 2) * d, 0] = trajs[:, i + 1] - trajs[:, i] @ phi.t()
+            K[:, (i + 1) * d:(i + 2) * d, (i + 1) * d:(i + 2) * d] = Q_inv
+        return A, b, K
 
 
 class CostGPTrajectory(Cost):
@@ -222,6 +262,19 @@ class CostGoalPrior(Cost):
         return [dict(kind=L.COST_GOAL_PRIOR, sigma=self.sigma_goal_prior, dim0=self.num_goals,
                      dim1=self.num_particles_per_goal * self.num_samples,
                      host_data=_host_list(self.multi_goal_states))]
+
+    def get_linear_system(self, trajs, x_trajs=None, **observation):
+        """cost_functions.py:390-405: one unary factor on the last waypoint, goal of particle p is
+        p // num_particles_per_goal."""
+        trajs = trajs.reshape(-1, self.traj_len, self.dim)
+        B, T, d = trajs.shape[0], self.traj_len, self.dim
+        kw = dict(device=trajs.device, dtype=trajs.dtype)
+        A = torch.zeros(B, d, d * T, **kw)
+        A[:, :, -d:] = torch.eye(d, **kw)
+        goals = self.multi_goal_states.to(**kw).repeat_interleave(self.num_particles_per_goal, dim=0)
+        b = (goals - trajs[:, -1]).unsqueeze(-1)
+        K = (torch.eye(d, **kw) / self.sigma_goal_prior ** 2).repeat(B, 1, 1)
+        return A, b, K
 
 
 class CostGoal(Cost):

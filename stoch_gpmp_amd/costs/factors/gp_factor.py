@@ -36,6 +36,10 @@ class GPFactor:
         return torch.cat((torch.cat((m1, m2), dim=-1), torch.cat((m2, m3), dim=-1)), dim=-2)
 
     def get_error(self, x_traj, calc_jacobian=False):
+        """gp_factor.py:54-67: e_i = x_{i+1} - Phi x_i; constant Jacobians H1 = Phi, H2 = -I."""
+        error = (x_traj[:, 1:] - x_traj[:, :-1] @ self.phi.t()).unsqueeze(-1)
         if calc_jacobian:
-            raise NotImplementedError("Jacobians belong to the GPMP planner (out of scope, SURVEY.md 8f)")
-        return (x_traj[:, 1:] - x_traj[:, :-1] @ self.phi.t()).unsqueeze(-1)
+            H1 = self.phi.unsqueeze(0).repeat(self.num_factors, 1, 1)
+            H2 = -torch.eye(self.state_dim, **self.tensor_args).unsqueeze(0).repeat(self.num_factors, 1, 1)
+            return error, H1, H2
+        return error

@@ -17,9 +17,12 @@ class UnaryFactor:
         return torch.eye(self.dim, **self.tensor_args) / self.sigma ** 2   # unary_factor.py:19
 
     def get_error(self, x, calc_jacobian=False):
+        """unary_factor.py:22-29: error = mean - x; Jacobian H = I."""
+        error = self.mean - x
         if calc_jacobian:
-            raise NotImplementedError("Jacobians belong to the GPMP planner (out of scope, SURVEY.md 8f)")
-        return self.mean - x
+            H = torch.eye(self.dim, **self.tensor_args).unsqueeze(0).repeat(x.shape[0], 1, 1)
+            return error.reshape(x.shape[0], self.dim, 1), H
+        return error
 
     def set_mean(self, x):
         self.mean = x.clone().detach()

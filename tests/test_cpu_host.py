@@ -138,7 +138,7 @@ def test_cost_descriptors_follow_the_reference_constructors():
     with pytest.raises(TypeError):
         CostComposite(n, T, [gp], FK=lambda q: q)       # arbitrary FK callables cannot run in HIP
     with pytest.raises(NotImplementedError):
-        gp.get_linear_system(None)                      # GPMP-only, out of scope
+        CostGoal(n, T, sigma_goal=1.).get_linear_system(None)     # no linear system for the SE(3) goal
     H = torch.eye(4, dtype=torch.float64)
     H[:3, 3] = torch.tensor([0.4, 0.1, 0.5])
     ee = CostGoal(n, T, field=EESE3DistanceField(H, w_pos=2., w_rot=0.5, tensor_args=CPU),
@@ -228,3 +228,32 @@ def test_bench_and_entry_points_exist():
     ge = importlib.import_module("__graft_entry__")
     assert callable(ge.build) and callable(ge.smoke)
     assert os.path.exists(os.path.join(ROOT, "bench.py"))
+
+
+def test_dense_linear_systems_match_the_oracle():
+    """get_linear_system of CostGP / CostGoalPrior / CostComposite (cost_functions.py:60-85,148-168,
+    390-405) -- plain tensor assembly, no kernel involved -- against oracle/gpmp_equiv.py, which is
+    pinned against a run of the reference's GPMP."""
+    from oracle import gpmp_equiv as GP
+    from stoch_gpmp_amd.costs.cost_functions import CostComposite, CostGP, CostGoalPrior
+    n, T, nppg, dt = 3, 5, 2, 0.1
+    g = torch.Generator().manual_seed(0)
+    start = torch.randn(2 * n, generator=g, dtype=torch.float64)
+    goals = torch.randn(2, 2 * n, generator=g, dtype=torch.float64)
+    trajs = torch.randn(2 * nppg, T, 2 * n, generator=g, dtype=torch.float64)
+    gp = CostGP(n, T, start, dt, dict(sigma_start=0.01, sigma_gp=0.3), CPU)
+    gl = CostGoalPrior(n, T, multi_goal_states=goals, num_particles_per_goal=nppg, num_samples=1,
+                       sigma_goal_prior=0.5, tensor_args=CPU)
+    for got, want in ((gp.get_linear_system(trajs), GP.linear_system_gp(trajs, start, n, dt, 0.01, 0.3)),
+                      (gl.get_linear_system(trajs), GP.linear_system_goal_prior(trajs, goals, nppg, n, 0.5))):
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    A, b, K = CostComposite(n, T, [gp, gl], tensor_args=CPU).get_linear_system(trajs)
+    Ao, bo, Ko = GP.composite_linear_system(trajs, [GP.linear_system_gp(trajs, start, n, dt, 0.01, 0.3),
+                                                    GP.linear_system_goal_prior(trajs, goals, nppg, n, 0.5)])
+    assert torch.equal(A, Ao) and torch.equal(b, bo) and torch.equal(K, Ko)
+    err, H1, H2 = gp.gp_prior.get_error(trajs, calc_jacobian=True)
+    assert err.shape == (4, T - 1, 2 * n, 1) and H1.shape == H2.shape == (T - 1, 2 * n, 2 * n)
+    e, H = gp.start_prior.get_error(trajs[:, [0]], calc_jacobian=True)
+    assert e.shape == (4, 2 * n, 1) and torch.equal(H[0], torch.eye(2 * n, dtype=torch.float64))
+

@@ -488,6 +488,18 @@ def test_collision_linear_system_matches_reference_layout():
     close(A, Ao, 1e-9, atol=1e-9 * float(Ao.abs().max()))
     close(b, bo, 1e-10)
     close(K, Ko, 1e-12)
+    # the whole Panda cost list through CostComposite.get_linear_system against the oracle's stack
+    from oracle import gpmp_equiv as GP
+    from tests.hip_builders import hip_panda_cost
+    goals = torch.tensor([SC.PANDA["goal_q"] + [0.] * n], dtype=torch.float64)
+    full = hip_panda_cost(SC.PANDA, T, B, 1, F64, goals=goals.to(**F64))
+    A, b, K = full.get_linear_system(trajs.to(**F64), obstacle_spheres=sph.to(**F64))
+    Ao, bo, Ko = GP.composite_linear_system(
+        trajs, GP.panda_systems_fn(SC.PANDA, T, B, goals, fk_all_links)(trajs, obstacle_spheres=sph))
+    assert A.shape == Ao.shape and K.shape == Ko.shape
+    close(A, Ao, 1e-9, atol=1e-9 * float(Ao.abs().max()))
+    close(b, bo, 1e-9, atol=1e-12)
+    close(K, Ko, 1e-12)
     # occupancy / sdf are not differentiable here: the C ABI says so
     bad = CostCollision(n, T, field=LinkDistanceField(field_type="occupancy", tensor_args=F64), sigma_coll=sigma,
                         tensor_args=F64)
