@@ -63,36 +63,54 @@ __device__ __forceinline__ double gp_diag_const(const GpmpArgs& a, int t, int r,
     return v;
 }
 
-// sum over this rank's particles of the field part of diag(A^T K A): one thread per (t >= 1, joint j)
+// sum over this rank's particles of the field part of diag(A^T K A) (entries (t >= 1, joint j); the
+// rest of diag_sum stays zero): workgroup = 8 particles, threads over the contiguous (t, j) elements of
+// a particle's gradient rows, one fp64 atomic per element and workgroup into the zeroed output
+#define SGPMP_DIAG_PCHUNK 8
 template <typename real>
-__global__ void gpmp_diag_kernel(GpmpArgs a, double* __restrict__ diag_sum) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int d = 2 * a.n;
-    if (idx >= a.T * d) return;
-    const int t = idx / d, j = idx % d;
-    double s = 0.;
-    if (t >= 1 && j < a.n)
+__global__ void __launch_bounds__(256)
+gpmp_diag_kernel(GpmpArgs a, double* __restrict__ diag_sum) {
+    const int d = 2 * a.n, per = (a.T - 1) * a.n;
+    const int p0 = blockIdx.x * SGPMP_DIAG_PCHUNK, p1 = min(p0 + SGPMP_DIAG_PCHUNK, a.P);
+    for (int e = threadIdx.x; e < per; e += blockDim.x) {
+        double s = 0.;
         for (int k = 0; k < a.n_fields; ++k)
-            for (int p = 0; p < a.P; ++p) {
-                const double h = ld<real>(a.f[k].grad, ((size_t)p * (a.T - 1) + (t - 1)) * a.n + j);
+            for (int p = p0; p < p1; ++p) {
+                const double h = ld<real>(a.f[k].grad, (size_t)p * per + e);
                 s += a.f[k].K * h * h;
             }
-    diag_sum[idx] = s;
+        const int t1 = e / a.n, j = e - t1 * a.n;
+        atomicAdd(&diag_sum[(t1 + 1) * d + j], s);
+    }
 }
 
 template <typename real>
 __global__ void __launch_bounds__(64)
 gpmp_solve_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_theta, real* __restrict__ costs) {
     __shared__ double S[TS * TS], L[TS * TS], Li[TS * TS], Lp[TS * TS], W[TS * TS], E[TS * TS];
-    __shared__ double mu[SGPMP_MAX_T_GPMP * TS], y[SGPMP_MAX_T_GPMP * TS], g[TS], r[TS], tmp[TS];
+    __shared__ double g[TS], r[TS], tmp[TS], rinv[TS];
     __shared__ double csum[64];
+    // sized by the launch: means and solution [T][16], field values [F][T], field gradients [F][T][8]
+    extern __shared__ __align__(16) unsigned char gp_lds_raw[];
     const int l = threadIdx.x, p = blockIdx.x;
     const int n = a.n, d = 2 * n, T = a.T;
+    double* mu = reinterpret_cast<double*>(gp_lds_raw);
+    double* y = mu + (size_t)T * TS;
+    double* fv = y + (size_t)T * TS;                      // [F][T]    (index t-1)
+    double* fg = fv + (size_t)a.n_fields * T;             // [F][T][8]
     real* mp = means + (size_t)p * T * d;
     double* scr = a.scratch + (size_t)p * T * 2 * TS * TS;
     for (int e = l; e < T * TS; e += 64) {
         const int t = e / TS, i = e % TS;
         mu[e] = i < d ? (double)mp[t * d + i] : 0.;
+    }
+    // the particle's field values and Jacobians, staged once (the waypoint loop must not wait for HBM)
+    for (int f = 0; f < a.n_fields; ++f) {
+        for (int e = l; e < T - 1; e += 64) fv[f * T + e] = ld<real>(a.f[f].val, (size_t)p * (T - 1) + e);
+        for (int e = l; e < (T - 1) * n; e += 64) {
+            const int t1 = e / n, j = e - t1 * n;
+            fg[((size_t)f * T + t1) * 8 + j] = ld<real>(a.f[f].grad, ((size_t)p * (T - 1) + t1) * n + e - t1 * n);
+        }
     }
     for (int e = l; e < TS * TS; e += 64) {              // E = block (t, t-1) = -Q^-1 Phi, constant
         const int rr = e / TS, c = e % TS;
@@ -139,10 +157,9 @@ gpmp_solve_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_the
                     v -= a.Kgp * (pos ? a.c11 * ep + a.c12 * ev : a.c12 * ep + a.c22 * ev);
                     if (pos)
                         for (int f = 0; f < a.n_fields; ++f) {
-                            const size_t o = (size_t)p * (T - 1) + (t - 1);
-                            const double fv = ld<real>(a.f[f].val, o);
-                            v += a.f[f].K * (-ld<real>(a.f[f].grad, o * n + l)) * fv;     // A row = -grad f
-                            if (l == 0) cost += a.f[f].K * fv * fv;
+                            const double fval = fv[f * T + t - 1];
+                            v += a.f[f].K * (-fg[((size_t)f * T + t - 1) * 8 + l]) * fval;   // A row = -grad f
+                            if (l == 0) cost += a.f[f].K * fval * fval;
                         }
                 }
             }
@@ -157,8 +174,8 @@ gpmp_solve_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_the
                 double fpart = 0.;
                 if (t >= 1 && rr < n && c < n)
                     for (int f = 0; f < a.n_fields; ++f) {
-                        const size_t o = ((size_t)p * (T - 1) + (t - 1)) * n;
-                        fpart += a.f[f].K * ld<real>(a.f[f].grad, o + rr) * ld<real>(a.f[f].grad, o + c);
+                        const double* h = fg + ((size_t)f * T + t - 1) * 8;
+                        fpart += a.f[f].K * h[rr] * h[c];
                     }
                 v += fpart;
                 if (rr == c)
@@ -193,7 +210,9 @@ gpmp_solve_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_the
             const double piv = tmp[j];
             if (!(piv > 0.) || !(piv < 1e300)) { if (l == 0) *a.status = 1; }
             const double rt = sqrt(piv > 0. ? piv : 1.);
-            if (l < TS) L[l * TS + j] = l > j ? tmp[l] / rt : (l == j ? rt : 0.);
+            const double ri = 1. / rt;                               // one division per column, reused below
+            if (l < TS) L[l * TS + j] = l > j ? tmp[l] * ri : (l == j ? rt : 0.);
+            if (l == 0) rinv[j] = ri;
             __syncthreads();
         }
         // ---- Li = L^-1 (forward substitution, lanes over columns)
@@ -201,7 +220,7 @@ gpmp_solve_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_the
             if (l < TS) {
                 double v = (i == l) ? 1. : 0.;
                 for (int k = 0; k < i; ++k) v -= L[i * TS + k] * Li[k * TS + l];
-                Li[i * TS + l] = v / L[i * TS + i];
+                Li[i * TS + l] = v * rinv[i];
             }
             __syncthreads();
         }
@@ -225,10 +244,17 @@ gpmp_solve_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_the
         for (int i = 0; i < d; ++i) c += csum[i];
         if (costs) costs[p] = (real)c;
     }
-    // ---- backward: x_t = L_t^-T (y_t - W_{t+1}^T x_{t+1}), written into y in place
+    // ---- backward: x_t = L_t^-T (y_t - W_{t+1}^T x_{t+1}), written into y in place; the tiles of step
+    // t-1 are fetched while step t computes (Li still holds L_{T-1}^-1 from the forward sweep)
     for (int t = T - 1; t >= 0; --t) {
-        for (int e = l; e < TS * TS; e += 64) Li[e] = scr[(size_t)(2 * t) * TS * TS + e];
-        __syncthreads();
+        double nl[4], nw[4];
+        if (t >= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                nl[q] = scr[(size_t)(2 * (t - 1)) * TS * TS + l + 64 * q];
+                nw[q] = scr[(size_t)(2 * t + 1) * TS * TS + l + 64 * q];   // W_t, needed by step t-1
+            }
+        }
         if (l < TS) {
             double v = y[t * TS + l];
             if (t < T - 1)
@@ -241,7 +267,11 @@ gpmp_solve_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_the
             for (int c = l; c < TS; ++c) v += Li[c * TS + l] * r[c];
             y[t * TS + l] = v;
         }
-        for (int e = l; e < TS * TS; e += 64) W[e] = scr[(size_t)(2 * t + 1) * TS * TS + e];   // W_t for step t-1
+        __syncthreads();
+        if (t >= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { Li[l + 64 * q] = nl[q]; W[l + 64 * q] = nw[q]; }
+        }
         __syncthreads();
     }
     for (int e = l; e < T * d; e += 64) {
@@ -253,21 +283,23 @@ gpmp_solve_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_the
 }
 
 hipError_t launch_gpmp_diag(int dtype, const GpmpArgs& a, double* diag_sum, hipStream_t stream) {
-    const int total = a.T * 2 * a.n;
-    const unsigned grid = (unsigned)((total + 63) / 64);
-    if (dtype == SGPMP_F64) hipLaunchKernelGGL((gpmp_diag_kernel<double>), dim3(grid), dim3(64), 0, stream, a, diag_sum);
-    else hipLaunchKernelGGL((gpmp_diag_kernel<float>), dim3(grid), dim3(64), 0, stream, a, diag_sum);
+    hipError_t e = hipMemsetAsync(diag_sum, 0, (size_t)a.T * 2 * a.n * sizeof(double), stream);
+    if (e != hipSuccess || a.P <= 0 || a.n_fields == 0) return e;
+    const unsigned grid = (unsigned)((a.P + SGPMP_DIAG_PCHUNK - 1) / SGPMP_DIAG_PCHUNK);
+    if (dtype == SGPMP_F64) hipLaunchKernelGGL((gpmp_diag_kernel<double>), dim3(grid), dim3(256), 0, stream, a, diag_sum);
+    else hipLaunchKernelGGL((gpmp_diag_kernel<float>), dim3(grid), dim3(256), 0, stream, a, diag_sum);
     return hipGetLastError();
 }
 
 hipError_t launch_gpmp_solve(int dtype, const GpmpArgs& a, void* means, void* d_theta, void* costs,
                              hipStream_t stream) {
     if (a.P <= 0) return hipSuccess;
+    const size_t lds = ((size_t)2 * a.T * TS + (size_t)a.n_fields * a.T * 9) * sizeof(double);
     if (dtype == SGPMP_F64)
-        hipLaunchKernelGGL((gpmp_solve_kernel<double>), dim3(a.P), dim3(64), 0, stream, a, (double*)means,
+        hipLaunchKernelGGL((gpmp_solve_kernel<double>), dim3(a.P), dim3(64), lds, stream, a, (double*)means,
                            (double*)d_theta, (double*)costs);
     else
-        hipLaunchKernelGGL((gpmp_solve_kernel<float>), dim3(a.P), dim3(64), 0, stream, a, (float*)means,
+        hipLaunchKernelGGL((gpmp_solve_kernel<float>), dim3(a.P), dim3(64), lds, stream, a, (float*)means,
                            (float*)d_theta, (float*)costs);
     return hipGetLastError();
 }

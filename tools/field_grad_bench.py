@@ -1,5 +1,5 @@
 """Throughput of the analytic field Jacobian kernel (field_grad_kernel) at config-3 waypoint counts."""
-import sys, time; sys.path.insert(0, '.')
+import sys, time; sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import torch
 from stoch_gpmp_amd import workloads as W
 from stoch_gpmp_amd.costs.fields import LinkDistanceField, LinkSelfDistanceField

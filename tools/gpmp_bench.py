@@ -1,5 +1,5 @@
 """Gauss-Newton planner (GPMP) step time on the Panda problem: P particles x T waypoints."""
-import sys, time; sys.path.insert(0, '.')
+import sys, time; sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import torch
 from stoch_gpmp_amd import workloads as W
 from stoch_gpmp_amd.planner import GPMP

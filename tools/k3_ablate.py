@@ -1,5 +1,5 @@
 """Ablation of the cost sweep (K3) at config 3: time per launch for sub-sets of the cost list."""
-import sys, time; sys.path.insert(0, '.')
+import sys, time; sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import torch
 from stoch_gpmp_amd import workloads as W
 from stoch_gpmp_amd.costs.cost_functions import CostComposite

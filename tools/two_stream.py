@@ -1,6 +1,6 @@
 """Experiment: one GPU, the particle set split into K shards stepped concurrently on K streams
 (kernel tails of one shard overlap with the other's kernels)."""
-import sys, time; sys.path.insert(0, '.')
+import sys, time; sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import torch
 from stoch_gpmp_amd import workloads as W
 ta = {"device": torch.device("cuda:0"), "dtype": torch.float32}
