@@ -1,28 +1,35 @@
-"""UnaryFactor -- same interface as reference costs/factors/unary_factor.py (host-side mirror).
+"""UnaryFactor: a Gaussian factor pulling one state towards `mean` with isotropic standard deviation
+`sigma` (interface of reference costs/factors/unary_factor.py, host-side mirror).
 
-On the HIP path only `sigma` and `mean` are consumed (K = I / sigma^2 is applied inside the
-kernels); `K` and `get_error` exist for API parity and are tiny setup-time torch expressions."""
+The HIP kernels consume only (sigma, mean): the weight I / sigma^2 is applied inside them.  The
+tensors below (`K`, errors, the identity Jacobian) are small setup-time / inspection values."""
 import torch
 
 
 class UnaryFactor:
     def __init__(self, dim, sigma, mean=None, tensor_args=None):
-        self.sigma = sigma
-        self.mean = torch.zeros(dim, **tensor_args) if mean is None else mean
-        self.tensor_args = tensor_args
-        self.dim = dim
+        self.dim, self.sigma, self.tensor_args = dim, sigma, tensor_args
+        self.mean = mean if mean is not None else torch.zeros(dim, **tensor_args)
+
+    @property
+    def precision(self):
+        """Scalar weight 1 / sigma^2 of every state component."""
+        return 1.0 / (self.sigma * self.sigma)
 
     @property
     def K(self):
-        return torch.eye(self.dim, **self.tensor_args) / self.sigma ** 2   # unary_factor.py:19
+        """[dim, dim] weight matrix (unary_factor.py:19)."""
+        return self.precision * torch.eye(self.dim, **self.tensor_args)
 
     def get_error(self, x, calc_jacobian=False):
-        """unary_factor.py:22-29: error = mean - x; Jacobian H = I."""
-        error = self.mean - x
-        if calc_jacobian:
-            H = torch.eye(self.dim, **self.tensor_args).unsqueeze(0).repeat(x.shape[0], 1, 1)
-            return error.reshape(x.shape[0], self.dim, 1), H
-        return error
+        """mean - x, and with `calc_jacobian` also H = -d error / d x = I per batch entry
+        (unary_factor.py:22-29): -> error [B, dim, 1], H [B, dim, dim]."""
+        residual = torch.sub(self.mean, x)
+        if not calc_jacobian:
+            return residual
+        batch = x.shape[0]
+        jac = torch.eye(self.dim, **self.tensor_args).expand(batch, self.dim, self.dim).clone()
+        return residual.reshape(batch, self.dim, 1), jac
 
     def set_mean(self, x):
-        self.mean = x.clone().detach()
+        self.mean = x.detach().clone()
