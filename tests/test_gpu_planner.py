@@ -274,6 +274,33 @@ def test_full_size_planar_fused_step_equals_separate_calls(golden):
     assert float((end - torch.tensor(goals)[:, None, :2]).abs().max()) < 0.05
 
 
+@pytest.mark.parametrize("field_type", ["rbf", "sdf"])
+def test_full_size_fast_sweep_equals_generic_sweep(monkeypatch, field_type):
+    """BASELINE config 3 at FULL size (Panda, 1024 x 128 x 64, fp32): the two-trajectory LDS-prefetch
+    sweep against the single-trajectory generic-FK sweep (SGPMP_NO_DUAL_SWEEP + SGPMP_FORCE_GENERIC_FK) on
+    the very same 131 072 samples and importance-sampling weights -- every cost, not a sample of them."""
+    c = SC.PANDA
+    P, S, T = 1024, 128, 64
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
+    pl = hip_panda_planner(c, T, P, S, F32, field_type=field_type, seed=9)
+    pl.optimize(obstacle_spheres=sph)
+    samples = pl.state_samples
+    w = pl._engine.is_weights(pl.particle_means, pl.temperature)
+    sphc = sph.reshape(-1, 4).contiguous()
+    fast = pl._engine.cost_eval(samples, spheres=sphc, is_weights=w, rows_per_particle=S).clone()
+    monkeypatch.setenv("SGPMP_NO_DUAL_SWEEP", "1")
+    monkeypatch.setenv("SGPMP_FORCE_GENERIC_FK", "1")
+    slow = pl._engine.cost_eval(samples, spheres=sphc, is_weights=w, rows_per_particle=S)
+    assert fast.shape == (P * S,) and bool(torch.isfinite(fast).all())
+    rel = ((fast.double() - slow.double()).abs() / slow.double().abs().clamp_min(1.0)).max()
+    assert float(rel) < 2e-5, float(rel)
+    # the costs of the planner's own iteration are the fast kernel's
+    monkeypatch.delenv("SGPMP_NO_DUAL_SWEEP")
+    monkeypatch.delenv("SGPMP_FORCE_GENERIC_FK")
+    again = pl._engine.cost_eval(samples, spheres=sphc, is_weights=w, rows_per_particle=S)
+    assert torch.equal(again, fast)
+
+
 # --------------------------------------------------------------------------- example scripts
 def test_example_scripts_run_and_make_progress():
     """examples/*.py are this package's versions of the reference's two example scripts; a short run
