@@ -547,9 +547,13 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
                 if (pblocks < 1) pblocks = 1;
                 const bool pf = T <= 64 && T % 2 == 0 && !getenv("SGPMP_K3_NO_ONE") && !getenv("SGPMP_K3_NO_LDS_PREFETCH");
                 const bool one = T <= 64 && !getenv("SGPMP_K3_NO_ONE");
+                const bool pf_multi = T > 64 && T % 2 == 0 && !getenv("SGPMP_K3_NO_LDS_PREFETCH");
 #define DUAL_LAUNCH(FT)                                                                                    \
                 if (pf)                                                                                    \
                     hipLaunchKernelGGL((cost_sweep_dual_pf_kernel<ChainCode_panda::N, ChainCode_panda, FT>),          \
+                                       dim3((unsigned)pblocks), dim3(256), 0, stream, a, F);               \
+                else if (pf_multi)                                                                         \
+                    hipLaunchKernelGGL((cost_sweep_dual_pf_multi_kernel<ChainCode_panda::N, ChainCode_panda, FT>),    \
                                        dim3((unsigned)pblocks), dim3(256), 0, stream, a, F);               \
                 else if (one && FT == SGPMP_FIELD_RBF)                                                     \
                     hipLaunchKernelGGL((cost_sweep_dual_kernel<ChainCode_panda::N, ChainCode_panda, true, SGPMP_FIELD_RBF>), \
