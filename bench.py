@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the StochGPMP inner loop on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
 A step is ONE planner iteration = one body of the loop at reference planner.py:289-299 (draw S
 samples per particle, evaluate the composite cost, softmax-reweight, update the particle means) on
@@ -9,16 +9,23 @@ synthetic data.  Workload at N = 1: BASELINE.json configs[2] -- Panda 7-DoF (14-
 particles x 128 samples x 64 waypoints, 5 synthetic sphere obstacles (rbf field) + self-collision,
 fp32 compute with the prior factored in fp64.  At N > 1 every rank holds 1024 particles of a
 (1024 N)-particle problem (configs[3] at N = 8: weak scaling, particles sharded, no data-path
-collective; a [64,4]-double statistics all-reduce over RCCL per iteration).
+collective; a [64,4]-double statistics all-reduce over RCCL per iteration, enqueued by sgpmp_step).
 
-Prints one JSON line (rank 0).  `roofline` prices the dominant kernel (the cost sweep) against the
-HBM peak using its algorithmic bytes N*w + P*S*8 and its average duration measured
-with HIP events on the launch stream; `cpu_baseline` times the reference-equivalent PyTorch-CPU
-oracle on a bounded sample of the same workload on this box's host cores.
+With N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`) BEFORE anything touches the GPU
+and relays rank 0's JSON line and the exit code; under a launcher (WORLD_SIZE set) it is a rank.
+
+Prints one JSON line (rank 0).  `roofline` prices the dominant kernel against the HBM peak using its
+algorithmic bytes and its average duration measured with HIP events on the launch
+stream, with the VALU ceiling beside it; `cpu_baseline` times the reference-equivalent PyTorch-CPU
+oracle on a bounded sample of the same workload on this box's host cores, `cpu_fair` the banded fp64
+restatement (what a careful CPU implementation of the same mathematics costs).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +34,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0       # same guide: 6.29 TB/s measured float4 copy (79 % of spec)
+PROFILE_ROUND = "r02"
+GOALS4_PLANAR = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
 
 
 def parse():
@@ -41,57 +51,140 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--field", default="rbf", choices=["rbf", "sdf", "occupancy"])
     ap.add_argument("--spheres", type=int, default=5, help="number of sphere obstacles (panda; 64 = stress variant)")
+    ap.add_argument("--goals", type=int, default=1, help="panda: number of goals (config 5: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=3)
     return ap.parse_args()
 
 
-def build_planner(args, torch, rank, world, dev):
+# --------------------------------------------------------------------------------------- N > 1 launch
+def self_launch(args):
+    """Parent of a multi-GPU run: start one rank per GPU and relay.  Nothing here may initialise the
+    GPU (a process that has done so must never be replaced or forked into ranks), so torch is not
+    even imported."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return proc.returncode if proc.returncode != 0 or line is not None else 1
+
+
+# --------------------------------------------------------------------------------------- workloads
+PANDA_GOALS = [[0.5, 0.2, 0.3, -1.5, 0.1, 2.0, 0.3], [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5],
+               [0.9, -0.2, 0.4, -1.1, -0.3, 1.9, 0.8], [-0.8, 0.1, 0.6, -2.4, 0.4, 2.6, -0.2]]
+
+
+def build_planner(torch, workload, P_local, S, T, dtype, dev, rank=0, world=1, field="rbf", spheres=5,
+                  goals=1, shard_of=None, **kw):
+    """-> (planner, observation dict, workload name).  `shard_of` = (rank, world_size) builds one shard
+    of a bigger problem without a process group (config 5's per-GPU share on one GPU)."""
     from stoch_gpmp_amd import workloads as W
-    dtype = torch.float32 if args.dtype == "f32" else torch.float64
     ta = {"device": dev, "dtype": dtype}
-    if args.workload == "panda":
-        P_local = args.particles or 1024
-        S, T = args.samples or 128, args.traj_len or 64
-        pl = W.hip_panda_planner(W.PANDA, T, P_local * world, S, ta, field_type=args.field, seed=0,
-                                 rank=rank, world_size=world,
-                                 force_stats_allreduce=os.environ.get("SGPMP_BENCH_FORCE_DIST") == "1")
-        obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres(num=args.spheres)).to(**ta)}
+    if shard_of is not None:
+        rank, world = shard_of
+    if workload == "panda":
+        assert (P_local * world) % goals == 0
+        gl = None if goals == 1 else [g + [0.] * 7 for g in PANDA_GOALS[:goals]]
+        pl = W.hip_panda_planner(W.PANDA, T, P_local * world // goals, S, ta, field_type=field, seed=0,
+                                 goals=gl, rank=rank, world_size=world, **kw)
+        obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres(num=spheres)).to(**ta)}
         name = (f"Panda 7-DoF, {P_local * world} particles ({P_local}/GPU) x {S} samples x {T} waypoints, "
-                f"GP + goal-prior + self-collision + {args.spheres} sphere obstacles ({args.field}), synthetic")
+                f"{goals} goal(s), GP + goal-prior + self-collision + {spheres} sphere obstacles ({field}), synthetic")
     else:
         from stoch_gpmp_amd.envs.obst_map import synthetic_obstacle_map
-        P_local = args.particles or 256
-        S, T = args.samples or 64, args.traj_len or 128
-        goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
+        gl = GOALS4_PLANAR[:goals]
         om = synthetic_obstacle_map(seed=0, tensor_args=ta)
-        assert (P_local * world) % len(goals) == 0
-        pl = W.hip_planar_planner(W.PLANAR, T, goals, P_local * world // len(goals), S, om, ta, seed=0,
-                                  rank=rank, world_size=world)
+        assert (P_local * world) % len(gl) == 0
+        pl = W.hip_planar_planner(W.PLANAR, T, gl, P_local * world // len(gl), S, om, ta, seed=0,
+                                  rank=rank, world_size=world, **kw)
         obs = {}
         name = (f"2-D point mass, {P_local * world} particles ({P_local}/GPU) x {S} samples x {T} waypoints, "
-                "GP + goal-prior + 200x200 occupancy grid, synthetic")
-    return pl, obs, name, P_local, S, T, dtype
+                f"{len(gl)} goals, GP + goal-prior + 200x200 occupancy grid, synthetic")
+    return pl, obs, name
 
 
-def cpu_baseline(args, torch):
+def kernel_profile(torch, pl, obs, steps):
+    """Per-kernel device time with HIP events on the launch stream (a separate pass: the events sit
+    between the kernels, so this pass is never the one whose wall time is reported)."""
+    pl._engine.profile_enable(True)
+    for _ in range(steps):
+        pl.optimize(opt_iters=1, **obs)
+    torch.cuda.synchronize()
+    kms, launches = pl._engine.profile_read()
+    pl._engine.profile_enable(False)
+    assert launches == steps
+    return {k: v / launches for k, v in kms.items()}
+
+
+def time_loop(torch, pl, obs, steps, warmup, barrier=None):
+    for _ in range(warmup):
+        pl.optimize(opt_iters=1, **obs)
+    (barrier or torch.cuda.synchronize)()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pl.optimize(opt_iters=1, **obs)
+    (barrier or torch.cuda.synchronize)()
+    return time.perf_counter() - t0
+
+
+def other_configs(torch, dev):
+    """The other single-GPU configurations of BASELINE.json, each timed for a few hundred iterations
+    (they cost milliseconds): configs[0] in fp64, configs[1], configs[2] with the sdf field, and the
+    per-GPU share of configs[4] (512 of 4096 particles, 4 goals; shard 3 of 8)."""
+    f32, f64 = torch.float32, torch.float64
+    specs = [
+        ("config 1: planar 4 x 16 x 64, fp64", dict(workload="planar", P_local=4, S=16, T=64, dtype=f64, goals=2), 300),
+        ("config 2: planar 256 x 64 x 128, fp32", dict(workload="planar", P_local=256, S=64, T=128, dtype=f32, goals=4), 300),
+        ("config 3 with the sdf sphere field", dict(workload="panda", P_local=1024, S=128, T=64, dtype=f32, field="sdf"), 100),
+        ("config 5 share: Panda 4 goals, 512 of 4096 particles x 256 x 128, fp32 (shard 3 of 8)",
+         dict(workload="panda", P_local=512, S=256, T=128, dtype=f32, goals=4, shard_of=(3, 8)), 60),
+    ]
+    out = []
+    for label, spec, steps in specs:
+        pl, obs, name = build_planner(torch, dev=dev, **spec)
+        el = time_loop(torch, pl, obs, steps, 10)
+        kms = kernel_profile(torch, pl, obs, min(steps, 30))
+        out.append({"config": label, "workload": name, "iterations_per_s": steps / el,
+                    "ms_per_step": 1e3 * el / steps, "steps": steps, "kernel_ms_per_step": kms,
+                    "cost_kernel": pl._engine.last_cost_kernel(),
+                    "dtype": "f32" if spec["dtype"] == f32 else "f64"})
+        del pl
+        torch.cuda.empty_cache()
+    return out
+
+
+# --------------------------------------------------------------------------------------- CPU figures
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(args, torch, S, T, P_full):
     """Reference-equivalent PyTorch-CPU path (oracle/ref_equiv.py: replicated [P,M,M] precision,
     MultivariateNormal rebuilt per iteration, dense sampling, dense IS matmul) on a bounded sample:
     `cpu_particles` particles of the workload at its full S and T."""
     from tests import scenarios as SC
     from stoch_gpmp_amd import workloads as W
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    torch.set_num_threads(cores)
+    cores = host_cores()
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     Pc = args.cpu_particles
     if args.workload == "panda":
-        S, T = args.samples or 128, args.traj_len or 64
-        P_full = args.particles or 1024
         try:
             ora = SC.oracle_panda_planner(W.PANDA, T, Pc, S, dtype=dtype, field_type=args.field, seed=0)
         except ValueError:
@@ -102,13 +195,10 @@ def cpu_baseline(args, torch):
         obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres(num=args.spheres)).to(dtype)}
     else:
         from stoch_gpmp_amd.envs.obst_map import synthetic_obstacle_map
-        S, T = args.samples or 64, args.traj_len or 128
-        P_full = args.particles or 256
         om = synthetic_obstacle_map(seed=0, tensor_args={"device": torch.device("cpu"), "dtype": torch.float64})
-        goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
         Pc = max(Pc // 4, 1) * 4
         dtype = torch.float64      # the reference cannot build the planar priors in fp32 (README.md:35)
-        ora = SC.oracle_planar_planner(W.PLANAR, T, goals, Pc // 4, S, om.map, om.cell_size,
+        ora = SC.oracle_planar_planner(W.PLANAR, T, GOALS4_PLANAR, Pc // 4, S, om.map, om.cell_size,
                                        [om.origin_xi, om.origin_yi], seed=0)
         obs = {}
     # The dense algorithm is dominated by batched small-matrix LAPACK / bmm calls that do not scale
@@ -128,7 +218,6 @@ def cpu_baseline(args, torch):
             break
     dt, threads = best
     its = 1.0 / dt
-    cores_used = threads
     # a second measured point at twice the particles (same thread count), to show that the per-particle
     # extrapolation is linear ("report measured points"); skipped if it would take too long
     points = [{"particles": Pc, "it_per_s": its}]
@@ -144,7 +233,7 @@ def cpu_baseline(args, torch):
         except Exception:                                   # (memory) keep the first point
             pass
     return {
-        "value": its * Pc / P_full, "unit": "iterations/s", "cores": cores_used, "kind": "port",
+        "value": its * Pc / P_full, "unit": "iterations/s", "cores": threads, "kind": "port",
         "sample": (f"{Pc} of {P_full} particles at full S={S}, T={T}, {str(dtype).split('.')[-1]}, "
                    f"{args.cpu_iters} iterations after 1 warm-up, best of "
                    f"several torch thread counts ({threads} threads of {cores} host cores); "
@@ -155,17 +244,69 @@ def cpu_baseline(args, torch):
     }
 
 
+def cpu_fair(args, torch, S, T, P_full):
+    """The banded fp64 restatement (oracle/banded_equiv.py): prior factored once, per-DOF 2T x 2T
+    sampling GEMM, IS term as a dot product, same cost functions -- what a careful CPU implementation
+    of the same mathematics costs.  Panda workloads only; bounded sample, linear in the particles."""
+    if args.workload != "panda":
+        return None
+    from oracle import banded_equiv as B
+    from stoch_gpmp_amd import workloads as W
+    c, n = W.PANDA, 7
+    cores = host_cores()
+    Pc = 32
+    dtype = torch.float64
+    goal = torch.tensor([c["goal_q"] + [0.] * n], dtype=dtype)
+    start = torch.tensor(c["start_q"] + [0.] * n, dtype=dtype)
+    means = torch.stack([start + (goal[0] - start) * t / (T - 1) for t in range(T)]).repeat(Pc, 1, 1)
+    band = B.BandedPlanner(Pc, S, T, c["dt"], n, start, goal, B.panda_chunk_cost(c, T, S, goal, args.field),
+                           c["step_size"], c["temperature"], c["sigma_start_sample"], c["sigma_goal_sample"],
+                           c["sigma_gp_sample"], means, chunk=8)
+    sph = torch.as_tensor(W.panda_spheres(num=args.spheres)).to(dtype)
+    g = torch.Generator().manual_seed(0)
+    best = None
+    for threads in sorted({min(cores, 16), min(cores, 64), cores}):
+        torch.set_num_threads(threads)
+        eps = torch.randn(S, Pc, T * 2 * n, generator=g, dtype=dtype)
+        band.step(eps, obstacle_spheres=sph)
+        t0 = time.perf_counter()
+        iters = 2
+        for _ in range(iters):
+            eps = torch.randn(S, Pc, T * 2 * n, generator=g, dtype=dtype)   # noise generation is part of an iteration
+            band.step(eps, obstacle_spheres=sph)
+        dt = (time.perf_counter() - t0) / iters
+        if best is None or dt < best[0]:
+            best = (dt, threads)
+        if dt * (iters + 1) > 10.0:
+            break
+    dt, threads = best
+    return {"value": (1.0 / dt) * Pc / P_full, "unit": "iterations/s", "cores": threads, "kind": "port (banded restatement)",
+            "sample": (f"{Pc} of {P_full} particles at full S={S}, T={T}, float64, 2 iterations after 1 warm-up, "
+                       f"{threads} torch threads of {cores} host cores; measured {1.0 / dt:.3f} it/s at P={Pc}; "
+                       "value = linear extrapolation in the particle count (every step of this algorithm is "
+                       "linear in P)"),
+            "measured_it_per_s_at_sample": 1.0 / dt, "sample_particles": Pc, "host_cores": cores}
+
+
+# --------------------------------------------------------------------------------------- main (a rank)
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    # stdout carries exactly ONE line, the JSON: whatever a library prints to fd 1 meanwhile (RCCL's
+    # version banner, ...) is sent to stderr, and the line is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run "
-                             f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("SGPMP_BENCH_FORCE_DIST") == "1"   # (1-rank RCCL smoke test)
@@ -175,7 +316,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    pl, obs, name, P_local, S, T, dtype = build_planner(args, torch, rank, world, dev)
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    if args.workload == "panda":
+        P_local, S, T = args.particles or 1024, args.samples or 128, args.traj_len or 64
+        goals = args.goals
+    else:
+        P_local, S, T = args.particles or 256, args.samples or 64, args.traj_len or 128
+        goals = 4
+    pl, obs, name = build_planner(torch, args.workload, P_local, S, T, dtype, dev, rank, world,
+                                  field=args.field, spheres=args.spheres, goals=goals,
+                                  force_stats_allreduce=use_dist and world == 1)
     w = 4 if dtype == torch.float32 else 8
     d = pl.d_state_opt
 
@@ -184,50 +334,55 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        pl.optimize(opt_iters=1, **obs)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pl.optimize(opt_iters=1, **obs)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time_loop(torch, pl, obs, args.steps, args.warmup, barrier)
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     mean_cost, mean_min_cost = pl.global_stats()
-
-    # per-kernel device time with HIP events on the launch stream (separate pass: the events sit
-    # between the kernels, so this pass is not the one that is timed above)
-    prof_steps = min(args.steps, 50)
-    pl._engine.profile_enable(True)
-    for _ in range(prof_steps):
-        pl.optimize(opt_iters=1, **obs)
-    torch.cuda.synchronize()
-    kms, launches = pl._engine.profile_read()
-    pl._engine.profile_enable(False)
-    assert launches == prof_steps
+    kms = kernel_profile(torch, pl, obs, min(args.steps, 50))
 
     if rank == 0:
         N_elems = P_local * S * T * d
-        sweep_bytes = N_elems * w + P_local * S * 8
-        sweep_ms = kms["cost_sweep"] / launches
-        achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
-        iter_bytes = 3 * N_elems * w + 2 * P_local * T * d * w + 2 * P_local * S * 8
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
-        # the figure comes from the committed rocprofv3 --pmc passes of this same command (per launch,
-        # FETCH_SIZE doubled per the gfx950 correction); null when the workload is not the profiled one
-        traffic = None
-        # which K3 the dispatcher (csrc/cost_sweep.hip: cost_dispatch) picks for this workload
-        dual = (args.workload == "panda" and args.dtype == "f32" and args.field == "rbf"
-                and S % 2 == 0 and not os.environ.get("SGPMP_NO_DUAL_SWEEP"))
-        pf = dual and T <= 64 and T % 2 == 0 and not os.environ.get("SGPMP_K3_NO_LDS_PREFETCH")
-        sweep_kernel = ("cost_sweep_dual_pf_kernel" if pf else "cost_sweep_dual_kernel") if dual else "cost_sweep_kernel"
-        tf = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-        if os.path.exists(tf) and args.workload == "panda" and (P_local, S, T, args.dtype, args.field, args.spheres) == (1024, 128, 64, "f32", "rbf", 5):
-            kk = json.load(open(tf))["kernels"]
-            traffic = kk.get(sweep_kernel, kk.get("cost_sweep_kernel", {})).get("bytes")
+        fused = pl._engine.last_step_fused() if hasattr(pl._engine, "last_step_fused") else False
+        sweep_kernel = pl._engine.last_cost_kernel()          # what the dispatcher really launched
+        if fused:
+            # K2 and K3 in one launch: samples are written once and never re-read by the sweep;
+            # algorithmic bytes of the pair stay SURVEY.md 8(d)'s N*w (sampler write) + N*w (sweep
+            # read) + P*S*8 -- traffic the fusion legitimately avoids raises the fraction
+            dom_ms = kms["sample"] + kms["cost_sweep"]
+            dom_bytes = 2 * N_elems * w + P_local * S * 8
+            dom_name = sweep_kernel + " (K2+K3 fused)"
+        else:
+            dom_ms = kms["cost_sweep"]
+            dom_bytes = N_elems * w + P_local * S * 8
+            dom_name = sweep_kernel + " (K3)"
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        # bytes the iteration really moves: K4 reads only the sample rows whose softmax weight is not
+        # exactly zero (one row per particle when the update is an arg-min)
+        nnz_rows = int((pl._weights_buf != 0).sum())
+        iter_alg = 3 * N_elems * w + 2 * P_local * T * d * w + 2 * P_local * S * 8
+        iter_moved = ((1 if fused else 2) * N_elems * w + nnz_rows * T * d * w + 4 * P_local * T * d * w
+                      + 3 * P_local * S * 8)
+        ms_step = 1e3 * elapsed / args.steps
+        # HBM traffic and VALU instruction counts of the dominant kernel cannot be read from inside this
+        # process (PMC counters need rocprofv3): they come from the committed rocprofv3 --pmc passes of
+        # this same command (profiles/<round>/traffic.json), with provenance; null when not profiled
+        traffic = traffic_src = compute = None
+        tf = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")
+        is_headline = args.workload == "panda" and (P_local, S, T, args.dtype, args.field, args.spheres, goals) == \
+            (1024, 128, 64, "f32", "rbf", 5, 1)
+        if os.path.exists(tf) and is_headline:
+            prof = json.load(open(tf))
+            k = prof["kernels"].get(sweep_kernel)
+            if k:
+                traffic = k.get("bytes")
+                traffic_src = f"profiles/{PROFILE_ROUND}/traffic.json@{prof.get('tag', '?')} (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)"
+                if "valu_floor_ms" in k:
+                    compute = {"valu_wave_insts_per_launch": k.get("valu_insts"),
+                               "valu_floor_ms": k["valu_floor_ms"],
+                               "frac_of_valu_floor": k["valu_floor_ms"] / dom_ms,
+                               "how": k.get("valu_floor_how")}
         out = {
             "metric": "planner iterations/sec (and ms/iter) at fixed particles x samples x T",
             # whole-job aggregate: every rank advances its 1024-particle shard by one iteration per
@@ -238,27 +393,41 @@ def main():
                     f"iterations/s of a {P_local}-particle shard, summed over {world} shards",
             "planner_iterations_per_s": args.steps / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
             "config": {"workload": name, "particles_per_gpu": P_local, "particles_total": P_local * world,
                        "samples": S, "traj_len": T, "state_dim": d,
-                       "parallelism": f"particle-sharded x{world}" if world > 1 else "single GPU",
+                       "parallelism": f"particle-sharded x{world}, RCCL statistics all-reduce inside sgpmp_step"
+                       if world > 1 else "single GPU",
                        "noise": "philox (in-kernel)", "prior_factor_dtype": "f64"},
-            "roofline": {"bound": "hbm", "kernel": sweep_kernel + " (K3)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": sweep_bytes,
-                         "avg_launch_ms": sweep_ms},
-            "kernel_ms_per_step": {k: v / launches for k, v in kms.items()},
-            "iteration_roofline": {"algorithmic_bytes": iter_bytes,
-                                   "achieved_GBs": iter_bytes / (elapsed / args.steps) / 1e9,
-                                   "frac_of_hbm_peak": iter_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "frac_of_measured_copy_bw": achieved / HBM_COPY_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                         "compute": compute},
+            "kernel_ms_per_step": kms,
+            "iteration_roofline": {"algorithmic_bytes": iter_alg, "moved_bytes": iter_moved,
+                                   "k4_rows_read": nnz_rows,
+                                   "achieved_GBs": iter_alg / (ms_step * 1e-3) / 1e9,
+                                   "frac_of_hbm_peak": iter_alg / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "moved_GBs": iter_moved / (ms_step * 1e-3) / 1e9,
+                                   "moved_frac_of_hbm_peak": iter_moved / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "last_iteration": {"mean_cost_sum": mean_cost, "mean_min_cost": mean_min_cost},
         }
+        if world == 1 and not args.no_other_configs and is_headline:
+            del pl
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(torch, dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, torch)
+            out["cpu_baseline"] = cpu_baseline(args, torch, S, T, P_local)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+            fair = cpu_fair(args, torch, S, T, P_local)
+            if fair:
+                out["cpu_fair"] = fair
+                out["speedup_vs_cpu_fair"] = out["value"] / fair["value"]
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -115,6 +115,17 @@ const char* sgpmp_last_error(void);
 int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out);
 void sgpmp_destroy(sgpmp_ctx* ctx);
 
+/* Development switches (kernel-variant A/B, tests of the fallback paths).  Every switch has an
+ * environment variable SGPMP_<NAME> that is read ONCE, in sgpmp_create; this call changes a switch
+ * on a live context.  Names: force_generic_fk, no_flat_program, no_chain_codegen, no_dual_sweep,
+ * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step (0/1) and k3_blocks (count).
+ * No reference counterpart. */
+int sgpmp_set_option(sgpmp_ctx* ctx, const char* name, long long value);
+/* Name of the cost-sweep kernel the dispatcher chose at the last sgpmp_cost_eval / sgpmp_step
+ * (static string; "" before the first launch).  For bench.py's roofline label and the tests that
+ * must prove which kernel they exercised. */
+const char* sgpmp_last_cost_kernel(sgpmp_ctx* ctx);
+
 /* K1. GP-prior precision blocks + reverse block-Cholesky, fp64, one launch.
  * Replaces GPFactor.calc_phi/calc_Q_inv (gp_factor.py:36-52), UnaryFactor.K (unary_factor.py:19),
  * MultiMPPrior.get_const_vel_covariance (mp_priors_multi.py:170-202) and the precision->scale_tril
@@ -173,11 +184,37 @@ int sgpmp_update(sgpmp_ctx* ctx, const void* costs, int costs_dtype, const void*
  * K5 -> K2 -> K3 -> K4 on `stream`.  samples [P,S,T,d] is written (state_samples of the iteration);
  * costs [P,S] ctx dtype may be NULL. means updated in place. stats (DEVICE
  * double[SGPMP_STAT_SHARDS][4] or NULL) is zeroed at the start of the step and holds this step's
- * sharded sums afterwards. */
+ * sharded sums afterwards; with a communicator attached (sgpmp_comm_init) the step also enqueues
+ * their all-reduce on the side stream, so `stats` then holds the sums over ALL ranks once
+ * sgpmp_stats_wait has been honoured. */
 int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, int eps_modes,
                int eps_mode_offset, void* means, void* samples, void* costs, void* weights,
                void* grad, void* means_prev, const void* spheres, int n_spheres, double temperature,
                double step_size, double* stats, void* stream);
+
+/* ---- multi-GPU (one process per GPU; RCCL over xGMI) -------------------------------------------- */
+/* The reference is single-process and has no counterpart; these calls carry out SURVEY.md 8(e):
+ * particles are sharded by contiguous ranges (sgpmp_dims.particle_offset), the data path needs no
+ * exchange, and the per-iteration statistics are summed over ranks.  librccl is loaded with dlopen
+ * by the first of these calls; single-GPU users never need it.
+ *
+ * sgpmp_comm_unique_id: rank 0 obtains the 128-byte RCCL id and hands it to the other ranks by any
+ *   host-side channel (the Python host uses torch.distributed's store).
+ * sgpmp_comm_init: collective over all `world_size` ranks (ncclCommInitRank); attaches the
+ *   communicator to the context.  From then on sgpmp_step all-reduces its `stats` by itself. */
+int sgpmp_comm_unique_id(unsigned char* out128);
+int sgpmp_comm_init(sgpmp_ctx* ctx, const unsigned char* id128, int world_size, int rank);
+int sgpmp_comm_destroy(sgpmp_ctx* ctx);
+/* Sum stats (DEVICE double[SGPMP_STAT_SHARDS][4], produced on `stream`) over all ranks, in place, on
+ * the context's side stream: returns at once and never makes `stream` wait. (planner.py:668-672's
+ * statistic over all particles of all GPUs.) */
+int sgpmp_allreduce_stats(sgpmp_ctx* ctx, double* stats, void* stream);
+/* Make `stream` wait (stream-side, not host-side) for the pending all-reduce of `stats`
+ * (NULL: of every statistics buffer) -- call before reading or overwriting it. */
+int sgpmp_stats_wait(sgpmp_ctx* ctx, double* stats, void* stream);
+/* All ranks' particle means: local [P_local,T,d] -> all [P_global,T,d] on every rank (ncclAllGather on
+ * `stream`; equal shards only). */
+int sgpmp_allgather_means(sgpmp_ctx* ctx, const void* local_means, void* all_means, void* stream);
 
 /* ---- standalone field / FK ops (the planner <-> cost seam) ----------------------- */
 /* FK callable: q [B,n] -> link frames [B,L,4,4], L = 1 + n_joints (cost_functions.py:51-52). */

@@ -49,6 +49,14 @@ SIGNATURES = {
     "sgpmp_last_error": (C.c_char_p, []),
     "sgpmp_create": (_I, [C.POINTER(Dims), C.POINTER(_P)]),
     "sgpmp_destroy": (None, [_P]),
+    "sgpmp_set_option": (_I, [_P, C.c_char_p, C.c_longlong]),
+    "sgpmp_comm_unique_id": (_I, [C.c_char_p]),
+    "sgpmp_comm_init": (_I, [_P, C.c_char_p, _I, _I]),
+    "sgpmp_comm_destroy": (_I, [_P]),
+    "sgpmp_allreduce_stats": (_I, [_P, _P, _P]),
+    "sgpmp_stats_wait": (_I, [_P, _P, _P]),
+    "sgpmp_allgather_means": (_I, [_P, _P, _P, _P]),
+    "sgpmp_last_cost_kernel": (C.c_char_p, [_P]),
     "sgpmp_set_prior": (_I, [_P, _I, _D, _D, _D, _D, C.POINTER(_D), _P]),
     "sgpmp_get_prior": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
     "sgpmp_set_costs": (_I, [_P, C.POINTER(CostDesc), _I]),

@@ -4,8 +4,8 @@
 
 A cost object here is a descriptor: `CostComposite` turns its `cost_list` into
 `sgpmp_cost_desc[]` (include/sgpmp.h).  `eval(trajs, **observation)` runs K3 and returns [B] costs,
-like the reference (cost_functions.py:47-58).  `get_linear_system` belongs to the GPMP planner,
-which is out of scope, and raises.
+like the reference (cost_functions.py:47-58).  `get_linear_system` returns the reference's dense
+(A, b, K) for user code; the GPMP planner itself consumes the factors in block-tridiagonal form.
 """
 from abc import ABC, abstractmethod
 
@@ -28,9 +28,20 @@ class Cost(ABC):
         self.dim = 2 * n_dof
         self.traj_len = traj_len
         self._solo = None
+        self._version = 0
 
     def set_cost_factors(self):
         pass
+
+    def touch(self):
+        """Mark this cost as edited: a planner that has compiled it re-compiles before its next step
+        (the reference reads cost attributes live on every eval)."""
+        self._version += 1
+
+    def version(self):
+        """Edit counter of this cost and of the field it wraps."""
+        f = getattr(self, "field", None)
+        return self._version + (getattr(f, "_version", 0) if f is not None else 0)
 
     def __call__(self, trajs, **observation):
         return self.eval(trajs, **observation)
@@ -63,6 +74,11 @@ class CostComposite(Cost):
         self.tensor_args = tensor_args
         self._engines = {}
         self.chain = self._resolve_chain(FK)
+        # An FK callable that is not one of this package's URDF chains cannot run inside the HIP
+        # sweep: the composite then calls it (user torch code, as reference cost_functions.py:51-52
+        # does) and evaluates the link fields on the frames it returns (`sgpmp_field_eval`) --
+        # same results, one extra pass over the frames.
+        self.foreign_fk = FK is not None and self.chain is None
         for cost in cost_list:                          # children evaluate stand-alone through the same chain
             if getattr(cost, "_fk", None) is None:
                 cost._fk = FK
@@ -73,13 +89,18 @@ class CostComposite(Cost):
         if FK is None:
             return None
         owner = getattr(FK, "__self__", FK)          # bound method of a URDFChain, or the chain itself
-        chain = getattr(owner, "chain", None)
-        if chain is None:
-            raise TypeError(
-                "FK must be a stoch_gpmp_amd URDF chain (e.g. robots.panda.DifferentiableFrankaPanda("
-                ").compute_forward_kinematics_all_links): an arbitrary Python callable cannot run "
-                "inside the HIP cost sweep")
-        return chain
+        return getattr(owner, "chain", None)
+
+    @staticmethod
+    def _is_link_field_cost(cost):
+        return isinstance(cost, (CostCollision, CostGoal)) and cost.field is not None and \
+            getattr(cost.field, "works_on_frames", False)
+
+    def version(self):
+        v = self._version
+        for cost in self.cost_list:
+            v += cost.version() if hasattr(cost, "version") else 0
+        return v
 
     def descriptors(self):
         out = []
@@ -87,6 +108,8 @@ class CostComposite(Cost):
             if not hasattr(cost, "descriptors"):
                 raise TypeError(f"{type(cost).__name__} is not a stoch_gpmp_amd cost; wrap foreign costs "
                                 "at the planner level (StochGPMP accepts any object with .eval)")
+            if self.foreign_fk and self._is_link_field_cost(cost):
+                continue                                # evaluated on the foreign FK's frames in eval()
             out.extend(cost.descriptors())
         return out
 
@@ -115,15 +138,21 @@ class CostComposite(Cost):
         engine.set_costs(self.descriptors())
 
     def needs_spheres(self):
-        return any(dsc["kind"] == L.COST_SPHERES for dsc in self.descriptors())
+        return any(dsc["kind"] == L.COST_SPHERES for cost in self.cost_list if hasattr(cost, "descriptors")
+                   for dsc in cost.descriptors())
 
     def _engine(self, dtype, device):
         key = (dtype, str(device))
-        if key not in self._engines:
+        v = self.version()
+        ent = self._engines.get(key)
+        if ent is None:
             eng = Engine(self.n_dof, self.traj_len, 0, 1, tensor_args={"device": device, "dtype": dtype})
             self.compile_into(eng)
-            self._engines[key] = eng
-        return self._engines[key]
+            self._engines[key] = ent = [eng, v]
+        elif ent[1] != v:                                # a child cost / field was edited since
+            self.compile_into(ent[0])
+            ent[1] = v
+        return ent[0]
 
     def eval(self, trajs, **observation):
         trajs = trajs.reshape(-1, self.traj_len, self.dim)
@@ -136,7 +165,19 @@ class CostComposite(Cost):
             raise AttributeError("obstacle_spheres observation is required by LinkDistanceField costs")
         if spheres is not None:
             spheres = spheres.to(device=trajs.device, dtype=trajs.dtype).reshape(-1, 4).contiguous()
-        return self._engine(trajs.dtype, trajs.device).cost_eval(trajs, spheres=spheres)
+        costs = self._engine(trajs.dtype, trajs.device).cost_eval(trajs, spheres=spheres)
+        if self.foreign_fk:
+            # cost_functions.py:51-52: x_trajs = FK(q).reshape(B, T, -1, 4, 4); then every link-field
+            # child as in CostCollision.eval / CostGoal.eval (cost_functions.py:247-261, 308-321)
+            B = trajs.shape[0]
+            x_trajs = self.FK(trajs.view(-1, self.dim)[:, :self.n_dof]).reshape(B, self.traj_len, -1, 4, 4)
+            for cost in self.cost_list:
+                if self._is_link_field_cost(cost):
+                    factor = cost.obst_factor if isinstance(cost, CostCollision) else cost.goal_factor
+                    err = factor.get_error(trajs, cost.field, x_trajs=x_trajs, calc_jacobian=False,
+                                           obstacle_spheres=spheres)
+                    costs = costs + factor.K * err.sum(1)
+        return costs
 
 
 class CostGP(Cost):
@@ -153,6 +194,7 @@ class CostGP(Cost):
 
     def set_cost_factors(self):
         self.start_prior = UnaryFactor(self.dim, self.sigma_start, self.start_state, self.tensor_args)
+        self._version = getattr(self, '_version', 0) + 1
         self.gp_prior = GPFactor(self.n_dof, self.sigma_gp, self.dt, self.traj_len - 1, self.tensor_args)
 
     def descriptors(self):
@@ -194,6 +236,7 @@ class CostGPTrajectory(Cost):
 
     def set_cost_factors(self):
         self.gp_prior = GPFactor(self.n_dof, self.sigma_gp, self.dt, self.traj_len - 1, self.tensor_args)
+        self._version = getattr(self, '_version', 0) + 1
 
     def descriptors(self):
         return [dict(kind=L.COST_GP, flags=0, sigma=self.sigma_gp, dt=self.dt)]
@@ -211,6 +254,7 @@ class CostCollision(Cost):
 
     def set_cost_factors(self):
         self.obst_factor = FieldFactor(self.n_dof, self.sigma_coll, [1, self.traj_len])
+        self._version = getattr(self, '_version', 0) + 1
 
     def descriptors(self):
         if self.field is None:
@@ -257,6 +301,7 @@ class CostGoalPrior(Cost):
     def set_cost_factors(self):
         self.multi_goal_prior = [UnaryFactor(self.dim, self.sigma_goal_prior, self.multi_goal_states[i],
                                              self.tensor_args) for i in range(self.num_goals)]
+        self._version = getattr(self, '_version', 0) + 1
 
     def descriptors(self):
         return [dict(kind=L.COST_GOAL_PRIOR, sigma=self.sigma_goal_prior, dim0=self.num_goals,
@@ -289,6 +334,7 @@ class CostGoal(Cost):
 
     def set_cost_factors(self):
         self.goal_factor = FieldFactor(self.n_dof, self.sigma_goal, [self.traj_len - 1, self.traj_len])
+        self._version = getattr(self, '_version', 0) + 1
 
     def descriptors(self):
         if self.field is None:

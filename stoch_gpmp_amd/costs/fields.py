@@ -24,6 +24,7 @@ class DistanceField(ABC):
     def __init__(self, tensor_args=None):
         self.tensor_args = tensor_args
         self._engines = {}
+        self._version = 0           # edit counter: planners re-compile their cost program when it moves
 
     @abstractmethod
     def descriptor(self, sigma):
@@ -64,6 +65,7 @@ class DistanceField(ABC):
 
 class LinkDistanceField(DistanceField):
     """reference fields.py:30-89 (rbf / sdf / occupancy against sphere obstacles)."""
+    works_on_frames = True          # compute_cost takes link frames [.., L, 4, 4]
     _TYPES = {"rbf": L.FIELD_RBF, "sdf": L.FIELD_SDF, "occupancy": L.FIELD_OCCUPANCY}
 
     def __init__(self, field_type='rbf', clamp_sdf=False, num_interpolate=0,
@@ -95,6 +97,7 @@ class LinkDistanceField(DistanceField):
 
 class LinkSelfDistanceField(DistanceField):
     """reference fields.py:92-127 (pairwise rbf over all link points, diagonal included)."""
+    works_on_frames = True
 
     def __init__(self, margin=0.03, num_interpolate=0, link_interpolate_range=[5, 7], **kwargs):
         super().__init__(**kwargs)
@@ -128,6 +131,7 @@ def SE3_distance(H1, H2, w_pos=1., w_rot=1.):
 
 class EESE3DistanceField(DistanceField):
     """reference fields.py:130-153: distance of the LAST link frame to a target frame."""
+    works_on_frames = True
 
     def __init__(self, target_H, w_pos=1., w_rot=1., square=True, **kwargs):
         super().__init__(**kwargs)
@@ -137,8 +141,12 @@ class EESE3DistanceField(DistanceField):
         self.w_rot = w_rot
 
     def update_target(self, target_H):
+        """fields.py:140-141.  The reference reads `target_H` on every eval; here the target is part
+        of the compiled cost program, so the edit counter tells every planner / composite holding
+        this field to re-compile before its next evaluation."""
         self.target_H = target_H
         self._engines = {}
+        self._version += 1
 
     def descriptor(self, sigma, square=None):
         H = torch.as_tensor(self.target_H).detach().cpu().double().reshape(-1, 4, 4)[0]

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cctype>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -49,7 +51,29 @@ struct sgpmp_ctx {
     double* d_costs64;            // [P, S]
     bool profiling;
     std::vector<StepEvents> events;
+    SgpmpToggles tg;              // development switches, read from the environment at creation
+    SgpmpComm* comm;              // RCCL communicator (multi-GPU runs), or null
+    const char* last_cost_kernel; // name of the cost-sweep kernel the dispatcher picked last
 };
+
+// name -> field of SgpmpToggles (environment variable = "SGPMP_" + upper-case name)
+static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[] = {
+    {"force_generic_fk", &SgpmpToggles::force_generic_fk}, {"no_flat_program", &SgpmpToggles::no_flat_program},
+    {"no_chain_codegen", &SgpmpToggles::no_chain_codegen}, {"no_dual_sweep", &SgpmpToggles::no_dual_sweep},
+    {"k3_no_one", &SgpmpToggles::k3_no_one}, {"k3_no_lds_prefetch", &SgpmpToggles::k3_no_lds_prefetch},
+    {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
+};
+
+static void toggles_from_env(SgpmpToggles& tg) {
+    std::memset(&tg, 0, sizeof(tg));
+    for (const auto& t : kToggleNames) {
+        std::string env = "SGPMP_";
+        for (const char* p = t.name; *p; ++p) env += (char)toupper(*p);
+        const char* v = getenv(env.c_str());
+        tg.*(t.flag) = (v && *v && std::strcmp(v, "0") != 0) ? 1 : 0;
+    }
+    if (const char* e = getenv("SGPMP_K3_BLOCKS")) tg.k3_blocks = atoll(e);
+}
 
 extern "C" int sgpmp_abi_version(void) { return SGPMP_ABI_VERSION; }
 extern "C" const char* sgpmp_last_error(void) { return g_err.c_str(); }
@@ -100,6 +124,9 @@ extern "C" int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out) {
     c->have_costs = false; c->prog_dirty = false; c->have_chain = false; c->profiling = false;
     std::memset(&c->h_prog, 0, sizeof(c->h_prog));
     std::memset(&c->h_chain, 0, sizeof(c->h_chain));
+    toggles_from_env(c->tg);
+    c->last_cost_kernel = "";
+    c->comm = nullptr;
     int rc;
     if ((rc = alloc_prior(c, c->prior[0])) != SGPMP_OK) return rc;
     if ((rc = alloc_prior(c, c->prior[1])) != SGPMP_OK) return rc;
@@ -113,8 +140,70 @@ extern "C" int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out) {
     return SGPMP_OK;
 }
 
+extern "C" int sgpmp_set_option(sgpmp_ctx* c, const char* name, long long value) {
+    if (!c || !name) return fail(SGPMP_EINVAL, "sgpmp_set_option: null argument");
+    if (std::strcmp(name, "k3_blocks") == 0) { c->tg.k3_blocks = value; return SGPMP_OK; }
+    for (const auto& t : kToggleNames)
+        if (std::strcmp(name, t.name) == 0) { c->tg.*(t.flag) = value != 0; return SGPMP_OK; }
+    return fail(SGPMP_EINVAL, std::string("sgpmp_set_option: unknown option ") + name);
+}
+
+extern "C" const char* sgpmp_last_cost_kernel(sgpmp_ctx* c) { return c ? c->last_cost_kernel : ""; }
+
+// ---------------------------------------------------------------------------------- collectives
+#define COMMCHK(expr)                                                                        \
+    do {                                                                                     \
+        const char* e_ = (expr);                                                             \
+        if (e_) return fail(SGPMP_EHIP, std::string(#expr) + ": " + e_);                     \
+    } while (0)
+
+extern "C" int sgpmp_comm_unique_id(unsigned char* out128) {
+    if (!out128) return fail(SGPMP_EINVAL, "sgpmp_comm_unique_id: null argument");
+    COMMCHK(comm_unique_id(out128));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_comm_init(sgpmp_ctx* c, const unsigned char* id128, int world_size, int rank) {
+    if (!c || !id128 || world_size < 1 || rank < 0 || rank >= world_size)
+        return fail(SGPMP_EINVAL, "sgpmp_comm_init: bad argument");
+    if (c->comm) { comm_destroy(c->comm); c->comm = nullptr; }
+    COMMCHK(comm_create(id128, world_size, rank, &c->comm));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_comm_destroy(sgpmp_ctx* c) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_comm_destroy: null argument");
+    comm_destroy(c->comm);
+    c->comm = nullptr;
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_allreduce_stats(sgpmp_ctx* c, double* stats, void* stream) {
+    if (!c || !stats) return fail(SGPMP_EINVAL, "sgpmp_allreduce_stats: null argument");
+    if (!c->comm) return fail(SGPMP_ESTATE, "sgpmp_allreduce_stats: no communicator (sgpmp_comm_init)");
+    COMMCHK(comm_allreduce_stats(c->comm, stats, (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_stats_wait(sgpmp_ctx* c, double* stats, void* stream) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_stats_wait: null argument");
+    if (c->comm) COMMCHK(comm_stats_wait(c->comm, stats, (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_allgather_means(sgpmp_ctx* c, const void* local_means, void* all_means, void* stream) {
+    if (!c || !local_means || !all_means) return fail(SGPMP_EINVAL, "sgpmp_allgather_means: null argument");
+    if (!c->comm) return fail(SGPMP_ESTATE, "sgpmp_allgather_means: no communicator (sgpmp_comm_init)");
+    if ((long long)c->dims.num_particles * comm_world(c->comm) != c->dims.num_particles_global)
+        return fail(SGPMP_EINVAL, "sgpmp_allgather_means: shards must be equal (ragged shards: gather on the host side)");
+    COMMCHK(comm_allgather(c->comm, local_means, all_means, (size_t)c->dims.num_particles * c->M * c->esz,
+                           (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
 extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     if (!c) return;
+    comm_destroy(c->comm);
     free_prior(c->prior[0]);
     free_prior(c->prior[1]);
     hipFree(c->d_qc); hipFree(c->d_prog); hipFree(c->d_chain); hipFree(c->d_isw);
@@ -430,7 +519,7 @@ extern "C" int sgpmp_sample(sgpmp_ctx* c, int which, uint64_t seed, uint64_t dra
     if (n_modes == 0) return SGPMP_OK;
     HIPCHK(launch_sample(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, c->prior[which], seed, draw, means,
                          n_modes, mode_offset, n_samples, eps, eps_modes, eps_mode_offset, out,
-                         (hipStream_t)stream));
+                         (hipStream_t)stream, c->tg));
     return SGPMP_OK;
 }
 
@@ -452,7 +541,7 @@ extern "C" int sgpmp_cost_eval(sgpmp_ctx* c, const void* trajs, int64_t batch, i
     HIPCHK(launch_cost(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, c->h_prog, c->d_chain,
                        c->h_chain, trajs, batch, batch_offset, spheres, n_spheres, is_weights,
                        rows_per_particle, c->prior[SGPMP_PRIOR_SAMPLE].dt, costs, costs64,
-                       (hipStream_t)stream));
+                       (hipStream_t)stream, c->tg, &c->last_cost_kernel));
     return SGPMP_OK;
 }
 
@@ -502,18 +591,22 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         HIPCHK(hipEventRecord(se->ev[0], st));
     }
     const PriorDev& pr = c->prior[SGPMP_PRIOR_SAMPLE];
+    // (K5 zeroes `stats`: an all-reduce of an earlier step may still be reading it on the side stream)
+    if (c->comm && stats) COMMCHK(comm_stats_wait(c->comm, stats, st));
     HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, means, P, temperature, c->d_isw, stats, st));
     if (se) HIPCHK(hipEventRecord(se->ev[1], st));
     HIPCHK(launch_sample(D.dtype, D.n_dof, D.traj_len, pr, seed, draw, means, P, D.particle_offset, S, eps,
-                         eps_modes, eps_mode_offset, samples, st));
+                         eps_modes, eps_mode_offset, samples, st, c->tg));
     if (se) HIPCHK(hipEventRecord(se->ev[2], st));
     HIPCHK(launch_cost(D.dtype, D.n_dof, D.traj_len, c->h_prog, c->d_chain, c->h_chain,
                        samples, (long long)P * S, (long long)D.particle_offset * S, spheres, n_spheres,
-                       c->d_isw, S, pr.dt, costs, c->d_costs64, st));
+                       c->d_isw, S, pr.dt, costs, c->d_costs64, st, c->tg, &c->last_cost_kernel));
     if (se) HIPCHK(hipEventRecord(se->ev[3], st));
     HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
                          temperature, step_size, weights, grad, means_prev, stats, st));
     if (se) HIPCHK(hipEventRecord(se->ev[4], st));
+    // multi-GPU: sum the statistics over all ranks on the side stream (never gates the next step)
+    if (c->comm && stats) COMMCHK(comm_allreduce_stats(c->comm, stats, st));
     return SGPMP_OK;
 }
 

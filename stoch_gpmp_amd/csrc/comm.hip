@@ -1,0 +1,146 @@
+// Multi-GPU collectives of the StochGPMP path behind the C ABI: RCCL over xGMI, one process per GPU.
+//
+// Particles never interact (reference planner.py:263-275 reduces over the samples of ONE particle),
+// so the data path has no collective.  What crosses GPUs:
+//   * once per iteration, an all-reduce (sum) of the [SGPMP_STAT_SHARDS][4] fp64 statistics that K4
+//     accumulates -- the reference's print_info statistic (planner.py:668-672) made global.  It runs
+//     on a SIDE stream chained with events, so it never gates the next iteration's kernels and no
+//     Python runs in the loop (sgpmp_step enqueues it itself when a communicator is attached);
+//   * on request, an all-gather of the particle means.
+//
+// librccl is loaded with dlopen at sgpmp_comm_init (no link-time dependency: a single-GPU user never
+// touches it, and inside a PyTorch process the already-loaded librccl.so.1 is the one that is used).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "sgpmp_internal.h"
+
+struct RcclApi {
+    void* handle;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*);
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+    const char* (*GetErrorString)(ncclResult_t);
+};
+
+static RcclApi g_rccl = {};
+
+static const char* load_rccl() {
+    if (g_rccl.handle) return nullptr;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return "librccl.so.1 not found (dlopen)";
+#define SYM(field, name)                                            \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(h, name);          \
+    if (!g_rccl.field) return "librccl: missing symbol " name;
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(AllGather, "ncclAllGather")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.handle = h;
+    return nullptr;
+}
+
+struct SgpmpComm {
+    ncclComm_t comm;
+    int rank, world;
+    hipStream_t side;                                        // the all-reduce runs here
+    hipEvent_t produced;                                     // main stream: statistics complete
+    std::vector<std::pair<double*, hipEvent_t>> reduced;     // per statistics buffer: all-reduce complete
+};
+
+static hipEvent_t* reduced_event(SgpmpComm* c, double* stats, bool create) {
+    for (auto& p : c->reduced)
+        if (p.first == stats) return &p.second;
+    if (!create) return nullptr;
+    if (c->reduced.size() >= 8) {                            // buffers come and go (reset()): keep the table small
+        for (auto& p : c->reduced) hipEventDestroy(p.second);
+        c->reduced.clear();
+    }
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    c->reduced.emplace_back(stats, e);
+    return &c->reduced.back().second;
+}
+
+const char* comm_unique_id(unsigned char* out128) {
+    if (const char* e = load_rccl()) return e;
+    ncclUniqueId id;
+    const ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return g_rccl.GetErrorString(r);
+    std::memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return nullptr;
+}
+
+const char* comm_create(const unsigned char* id128, int world, int rank, SgpmpComm** out) {
+    if (const char* e = load_rccl()) return e;
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    SgpmpComm* c = new SgpmpComm();
+    c->rank = rank; c->world = world; c->comm = nullptr;
+    const ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { delete c; return g_rccl.GetErrorString(r); }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->produced, hipEventDisableTiming) != hipSuccess) {
+        g_rccl.CommDestroy(c->comm);
+        delete c;
+        return "comm_create: cannot create the side stream / event";
+    }
+    *out = c;
+    return nullptr;
+}
+
+void comm_destroy(SgpmpComm* c) {
+    if (!c) return;
+    hipStreamSynchronize(c->side);
+    for (auto& p : c->reduced) hipEventDestroy(p.second);
+    hipEventDestroy(c->produced);
+    hipStreamDestroy(c->side);
+    if (c->comm) g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+int comm_rank(const SgpmpComm* c) { return c->rank; }
+int comm_world(const SgpmpComm* c) { return c->world; }
+
+// `stream` has just produced `stats`: sum them over all ranks, in place, on the side stream.
+const char* comm_allreduce_stats(SgpmpComm* c, double* stats, hipStream_t stream) {
+    hipEvent_t* done = reduced_event(c, stats, true);
+    if (!done) return "comm_allreduce_stats: cannot create an event";
+    if (hipEventRecord(c->produced, stream) != hipSuccess) return "hipEventRecord failed";
+    if (hipStreamWaitEvent(c->side, c->produced, 0) != hipSuccess) return "hipStreamWaitEvent failed";
+    const ncclResult_t r = g_rccl.AllReduce(stats, stats, (size_t)SGPMP_STAT_SHARDS * 4, ncclDouble, ncclSum,
+                                            c->comm, c->side);
+    if (r != ncclSuccess) return g_rccl.GetErrorString(r);
+    if (hipEventRecord(*done, c->side) != hipSuccess) return "hipEventRecord failed";
+    return nullptr;
+}
+
+// Before `stream` touches `stats` again (K5 zeroes it; a reader copies it): wait -- on the stream, not
+// on the host -- for the all-reduce that may still be using it.  stats == NULL: every pending one.
+const char* comm_stats_wait(SgpmpComm* c, double* stats, hipStream_t stream) {
+    for (auto& p : c->reduced)
+        if (!stats || p.first == stats)
+            if (hipStreamWaitEvent(stream, p.second, 0) != hipSuccess) return "hipStreamWaitEvent failed";
+    return nullptr;
+}
+
+// [count] elements of `bytes_per_elem` from every rank -> [world * count] on every rank, on `stream`.
+const char* comm_allgather(SgpmpComm* c, const void* send, void* recv, size_t bytes, hipStream_t stream) {
+    const ncclResult_t r = g_rccl.AllGather(send, recv, bytes, ncclUint8, c->comm, stream);
+    if (r != ncclSuccess) return g_rccl.GetErrorString(r);
+    return nullptr;
+}

@@ -498,8 +498,11 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
                                 const ChainDev& h_chain, const real* trajs, long long batch,
                                 long long batch_offset, const real* spheres, int n_spheres,
                                 const real* isw, int rows_per_particle, double is_dt, real* costs,
-                                double* costs64, hipStream_t stream) {
+                                double* costs64, hipStream_t stream, const SgpmpToggles& tg, const char** picked) {
     const int n_links = h_chain.n_links;
+    const char* unused_name;
+    if (!picked) picked = &unused_name;
+    constexpr bool f64 = sizeof(real) == 8;
     if (batch + batch_offset >= (1LL << 31)) return hipErrorInvalidValue;   // row indices are 32-bit
     CostArgs<real> a;
     a.T = T; a.chain = d_chain; a.n_links = n_links; a.trajs = trajs;
@@ -511,7 +514,7 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
     size_t lds = 0;
     const bool fk = h_prog.needs_fk != 0;
     // register path: revolute-first chain, no interpolated points, an instantiated (n, joints) pair
-    bool reg = fk && h_chain.plan.fast && !getenv("SGPMP_FORCE_GENERIC_FK");
+    bool reg = fk && h_chain.plan.fast && !tg.force_generic_fk;
     for (int i = 0; i < h_prog.n_terms; ++i)
         if (h_prog.terms[i].n_interp > 0) reg = false;
     const int nj = n_links - 1;
@@ -528,26 +531,28 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     FlatProg<real> F;
-    const bool flat = make_flat<real>(h_prog, F) && !getenv("SGPMP_NO_FLAT_PROGRAM");
+    const bool flat = make_flat<real>(h_prog, F) && !tg.no_flat_program;
     auto log2_exact = [](long long v) { int s = 0; while ((1LL << s) < v && s < 62) ++s; return (1LL << s) == v ? s : -1; };
     a.rpp_shift = log2_exact(a.rows_per_particle);
     a.rpg_shift = (flat && F.has_goal) ? log2_exact(F.goal.rows_per_goal) : -1;
-    if (reg && h_chain.plan.codegen_id == 1 && n == ChainCode_panda::N && !getenv("SGPMP_NO_CHAIN_CODEGEN")) {
+    if (reg && h_chain.plan.codegen_id == 1 && n == ChainCode_panda::N && !tg.no_chain_codegen) {
         if constexpr (sizeof(real) == 4) {
             // two trajectories per wave on packed fp32 math (cost_sweep_dual.inc) when rows pair up
             const bool pairs_ok = (batch_offset % 2 == 0) && (!isw || a.rows_per_particle % 2 == 0) &&
                                   (!F.has_goal || F.goal.rows_per_goal % 2 == 0);
             const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
             const bool sph_ok = !F.has_sph || n_spheres <= SGPMP_SPH_LDS;
-            if (flat && !F.has_grid && pairs_ok && sph_ok && !getenv("SGPMP_NO_DUAL_SWEEP")) {
+            if (flat && !F.has_grid && pairs_ok && sph_ok && !tg.no_dual_sweep) {
                 long long pblocks = ((batch + 1) / 2 + 3) / 4;
                 long long pcap = 256LL * 20;          // 20 workgroups per CU (4 resident): measured optimum (tools/k3_grid_sweep.sh)
-                if (const char* e = getenv("SGPMP_K3_BLOCKS")) pcap = atoll(e);
+                if (tg.k3_blocks > 0) pcap = tg.k3_blocks;
                 if (pblocks > pcap) pblocks = pcap;
                 if (pblocks < 1) pblocks = 1;
-                const bool pf = T <= 64 && T % 2 == 0 && !getenv("SGPMP_K3_NO_ONE") && !getenv("SGPMP_K3_NO_LDS_PREFETCH");
-                const bool one = T <= 64 && !getenv("SGPMP_K3_NO_ONE");
-                const bool pf_multi = T > 64 && T % 2 == 0 && !getenv("SGPMP_K3_NO_LDS_PREFETCH");
+                const bool pf = T <= 64 && T % 2 == 0 && !tg.k3_no_one && !tg.k3_no_lds_prefetch;
+                const bool one = T <= 64 && !tg.k3_no_one;
+                const bool pf_multi = T > 64 && T % 2 == 0 && !tg.k3_no_lds_prefetch;
+                *picked = pf ? "cost_sweep_dual_pf_kernel" : pf_multi ? "cost_sweep_dual_pf_multi_kernel"
+                                                                      : "cost_sweep_dual_kernel";
 #define DUAL_LAUNCH(FT)                                                                                    \
                 if (pf)                                                                                    \
                     hipLaunchKernelGGL((cost_sweep_dual_pf_kernel<ChainCode_panda::N, ChainCode_panda, FT>),          \
@@ -568,6 +573,7 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
                 return hipGetLastError();
             }
         }
+        *picked = f64 ? "cost_sweep_kernel<f64, generated chain>" : "cost_sweep_kernel<f32, generated chain>";
         if (flat)
             hipLaunchKernelGGL((cost_sweep_kernel<real, ChainCode_panda::N, 1000, true>), dim3((unsigned)blocks),
                                dim3(256), 0, stream, a, P, F);
@@ -578,6 +584,7 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
     }
 #define COST_REG(NN, NJJ)                                                                          \
     if (reg && n == NN && nj == NJJ) {                                                             \
+        *picked = f64 ? "cost_sweep_kernel<f64, register FK>" : "cost_sweep_kernel<f32, register FK>"; \
         hipLaunchKernelGGL((cost_sweep_kernel<real, NN, NJJ, false>), dim3((unsigned)blocks), dim3(256), 0, \
                            stream, a, P, F);                                                       \
         return hipGetLastError();                                                                  \
@@ -591,6 +598,8 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
         blocks = (batch + block / 64 - 1) / (block / 64);
         if (blocks > cap) blocks = cap;
     }
+    *picked = fk ? (f64 ? "cost_sweep_kernel<f64, generic FK>" : "cost_sweep_kernel<f32, generic FK>")
+                 : (f64 ? "cost_sweep_kernel<f64, no FK>" : "cost_sweep_kernel<f32, no FK>");
 #define COST_CASE(NN)                                                                              \
     case NN:                                                                                       \
         if (fk)                                                                                    \
@@ -615,17 +624,17 @@ hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const
                        const ChainDev& h_chain, const void* trajs, long long batch,
                        long long batch_offset, const void* spheres, int n_spheres,
                        const void* is_weights, int rows_per_particle, double is_dt, void* costs,
-                       double* costs64, hipStream_t stream) {
+                       double* costs64, hipStream_t stream, const SgpmpToggles& tg, const char** picked) {
     hipError_t e;
     if (dtype == SGPMP_F64)
         e = cost_dispatch<double>(n, T, h_prog, d_chain, h_chain, (const double*)trajs, batch,
                                   batch_offset, (const double*)spheres, n_spheres,
                                   (const double*)is_weights, rows_per_particle, is_dt, (double*)costs,
-                                  costs64, stream);
+                                  costs64, stream, tg, picked);
     else
         e = cost_dispatch<float>(n, T, h_prog, d_chain, h_chain, (const float*)trajs, batch,
                                  batch_offset, (const float*)spheres, n_spheres, (const float*)is_weights,
-                                 rows_per_particle, is_dt, (float*)costs, costs64, stream);
+                                 rows_per_particle, is_dt, (float*)costs, costs64, stream, tg, picked);
     // end-effector goal terms act on the last waypoint only: one thread per trajectory, added to
     // the costs the sweep has just written (same stream)
     for (int i = 0; i < h_prog.n_terms && e == hipSuccess; ++i)

@@ -273,14 +273,14 @@ template <typename real>
 static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t seed, uint64_t draw,
                                   const real* means, int n_modes, int mode_offset, int S,
                                   const real* eps, int eps_modes, int eps_mode_offset, real* out,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, const SgpmpToggles& tg) {
     constexpr bool f64 = sizeof(real) == 8;
     if (prior.isotropic) {
         const real* coef = f64 ? (const real*)prior.iso64 : (const real*)prior.iso32;
         const int d = 2 * n;
         const int spw = 64 / n;                          // samples per wave (one lane per (sample, dof))
         int waves = (S + spw - 1) / spw;                 // waves needed per mode
-        if (!eps && (long long)waves * n_modes < 256 && !getenv("SGPMP_NO_SMALL_SAMPLER")) {
+        if (!eps && (long long)waves * n_modes < 256 && !tg.no_small_sampler) {
             // less than one wave per CU: noise in parallel, recurrence from LDS (config 1: 48 -> 16 us;
             // at config 2's 512 waves the standard kernel is still the faster one, 33 vs 45 us)
             dim3 sgrid((S + SGPMP_SMALL_SPB - 1) / SGPMP_SMALL_SPB, n_modes);
@@ -325,12 +325,12 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
 hipError_t launch_sample(int dtype, int n, int T, const PriorDev& prior, uint64_t seed, uint64_t draw,
                          const void* means, int n_modes, int mode_offset, int n_samples,
                          const void* eps, int eps_modes, int eps_mode_offset, void* out,
-                         hipStream_t stream) {
+                         hipStream_t stream, const SgpmpToggles& tg) {
     if (dtype == SGPMP_F64)
         return sample_dispatch<double>(n, T, prior, seed, draw, (const double*)means, n_modes,
                                        mode_offset, n_samples, (const double*)eps, eps_modes,
-                                       eps_mode_offset, (double*)out, stream);
+                                       eps_mode_offset, (double*)out, stream, tg);
     return sample_dispatch<float>(n, T, prior, seed, draw, (const float*)means, n_modes, mode_offset,
                                   n_samples, (const float*)eps, eps_modes, eps_mode_offset,
-                                  (float*)out, stream);
+                                  (float*)out, stream, tg);
 }

@@ -87,6 +87,34 @@ struct ChainDev {
     FkPlan plan;
 };
 
+// ---------------------------------------------------------------------------------- debug toggles
+// Development switches (A/B of kernel variants, tests of the fallback paths).  Read from the
+// SGPMP_* environment variables ONCE, when a context is created; `sgpmp_set_option` changes them on
+// a live context.  Nothing on the launch path calls getenv().
+struct SgpmpToggles {
+    int force_generic_fk;     // SGPMP_FORCE_GENERIC_FK     link positions through LDS, any chain
+    int no_flat_program;      // SGPMP_NO_FLAT_PROGRAM      interpret the term list instead of named fields
+    int no_chain_codegen;     // SGPMP_NO_CHAIN_CODEGEN     run-time chain constants instead of generated code
+    int no_dual_sweep;        // SGPMP_NO_DUAL_SWEEP        one trajectory per wave
+    int k3_no_one;            // SGPMP_K3_NO_ONE            no single-pass specialisation
+    int k3_no_lds_prefetch;   // SGPMP_K3_NO_LDS_PREFETCH   register-held prefetch
+    int no_small_sampler;     // SGPMP_NO_SMALL_SAMPLER     standard sampler for tiny launches
+    int no_fused_step;        // SGPMP_NO_FUSED_STEP        K2 and K3 as separate kernels inside sgpmp_step
+    long long k3_blocks;      // SGPMP_K3_BLOCKS            workgroup cap of the dual sweep (0: default)
+};
+
+// ---------------------------------------------------------------------------------- collectives (comm.hip)
+// RCCL communicator of one context; every function returns NULL on success or a static error string.
+struct SgpmpComm;
+const char* comm_unique_id(unsigned char* out128);
+const char* comm_create(const unsigned char* id128, int world, int rank, SgpmpComm** out);
+void comm_destroy(SgpmpComm* c);
+int comm_rank(const SgpmpComm* c);
+int comm_world(const SgpmpComm* c);
+const char* comm_allreduce_stats(SgpmpComm* c, double* stats, hipStream_t stream);
+const char* comm_stats_wait(SgpmpComm* c, double* stats, hipStream_t stream);
+const char* comm_allgather(SgpmpComm* c, const void* send, void* recv, size_t bytes, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------- launchers
 // (defined in the .hip files; all asynchronous on `stream`)
 hipError_t launch_prior_factor(int n, int T, double dt, double ks, double kg, const double* d_qc_inv,
@@ -95,13 +123,13 @@ hipError_t launch_prior_factor(int n, int T, double dt, double ks, double kg, co
 hipError_t launch_sample(int dtype, int n, int T, const PriorDev& prior, uint64_t seed, uint64_t draw,
                          const void* means, int n_modes, int mode_offset, int n_samples,
                          const void* eps, int eps_modes, int eps_mode_offset, void* out,
-                         hipStream_t stream);
+                         hipStream_t stream, const SgpmpToggles& tg);
 
 hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const ChainDev* d_chain,
                        const ChainDev& h_chain, const void* trajs, long long batch,
                        long long batch_offset, const void* spheres, int n_spheres,
                        const void* is_weights, int rows_per_particle, double is_dt, void* costs,
-                       double* costs64, hipStream_t stream);
+                       double* costs64, hipStream_t stream, const SgpmpToggles& tg, const char** picked);
 
 hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& prior, const void* means,
                              int n_particles, double temperature, void* out, double* zero_stats,

@@ -28,6 +28,7 @@ class Engine:
             L.check(self.lib.sgpmp_create(C.byref(self.dims), C.byref(self._ctx)))
         self._keep = []          # tensors whose device memory the cost program points at
         self.n_links = None
+        self._prior_key = {}     # which -> arguments of the last successful set_prior
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx:
@@ -40,18 +41,64 @@ class Engine:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ development switches
+    def set_option(self, name, value=1):
+        """Flip a development switch of this context (include/sgpmp.h: sgpmp_set_option)."""
+        L.check(self.lib.sgpmp_set_option(self._ctx, name.encode(), int(value)))
+
+    def last_cost_kernel(self):
+        """Name of the cost-sweep kernel the dispatcher picked at the last launch."""
+        return self.lib.sgpmp_last_cost_kernel(self._ctx).decode()
+
+    # ------------------------------------------------------------------ multi-GPU (RCCL behind the C ABI)
+    def comm_unique_id(self):
+        """128-byte RCCL id (rank 0 calls this and hands the bytes to the other ranks)."""
+        buf = C.create_string_buffer(128)
+        L.check(self.lib.sgpmp_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, world_size, rank):
+        """Collective: attach an RCCL communicator; sgpmp_step then all-reduces its statistics itself."""
+        assert len(unique_id) == 128
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_comm_init(self._ctx, unique_id, int(world_size), int(rank)))
+
+    def allreduce_stats(self, stats):
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_allreduce_stats(self._ctx, L.ptr(stats), L.stream_ptr()))
+
+    def stats_wait(self, stats=None):
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_stats_wait(self._ctx, L.ptr(stats), L.stream_ptr()))
+
+    def allgather_means(self, local_means, world_size):
+        self._chk(local_means, "means")
+        out = torch.empty((local_means.shape[0] * world_size,) + tuple(local_means.shape[1:]),
+                          **self.tensor_args)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_allgather_means(self._ctx, L.ptr(local_means), L.ptr(out), L.stream_ptr()))
+        return out
+
     # ------------------------------------------------------------------ setup
     def set_prior(self, which, dt, sigma_start, sigma_gp, sigma_goal=None, Q_c_inv=None):
-        qc = None
+        qc, flat = None, None
         if Q_c_inv is not None:
             flat = [float(v) for v in torch.as_tensor(Q_c_inv).detach().cpu().double().flatten()]
             assert len(flat) == self.n * self.n
             qc = (C.c_double * len(flat))(*flat)
+        # K1's output depends on these numbers only: a repeated call (reset() of a planner whose
+        # sigmas did not change) keeps the factor that is already on the device
+        key = (float(dt), float(sigma_start), None if sigma_gp is None else float(sigma_gp),
+               None if sigma_goal is None else float(sigma_goal), None if flat is None else tuple(flat))
+        if self._prior_key.get(which) == key:
+            return
+        self._prior_key.pop(which, None)
         with torch.cuda.device(self.device):
             L.check(self.lib.sgpmp_set_prior(
                 self._ctx, which, float(dt), float(sigma_start),
                 float(sigma_gp) if sigma_gp is not None else -1.0,
                 float(sigma_goal) if sigma_goal is not None else -1.0, qc, L.stream_ptr()))
+        self._prior_key[which] = key
 
     def get_prior(self, which):
         """-> (blocks [4,d,d], G [T,d,d], H [T,d,d]) as fp64 CPU tensors (inspection/tests)."""

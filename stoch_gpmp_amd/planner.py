@@ -16,7 +16,11 @@ Additions over the reference API (all optional keyword arguments):
                              reference's call order (planner.py:48-49,213,227,243), fed to K2 --
                              identical seeds then give the reference's trajectories (parity mode).
   rank / world_size          shard the particles over one process per GPU (contiguous ranges);
-                             statistics are all-reduced over RCCL once per iteration.
+                             statistics are all-reduced over RCCL once per iteration, inside
+                             `sgpmp_step` (C ABI, side stream; no Python in the loop).  The RCCL
+                             id travels through torch.distributed, which must be initialised.
+                             collective='torch' keeps the torch.distributed all-reduce instead
+                             (what the gloo CPU tests exercise).
   step()                     one loop body, public (the reference only has it inline).
 """
 import time
@@ -71,7 +75,9 @@ class StochGPMP:
 
         if seed is not None:
             torch.manual_seed(seed)              # same global side effect as planner.py:48-49
-        self.seed = 0 if seed is None else int(seed)
+        # unseeded planners must not all replay one stream: like the reference (which keeps drawing
+        # from torch's global generator) they take their key from that generator's current seed
+        self.seed = int(torch.initial_seed()) & ((1 << 63) - 1) if seed is None else int(seed)
 
         self.n_dof = n_dof
         self.d_state_opt = 2 * self.n_dof
@@ -118,6 +124,10 @@ class StochGPMP:
         self._draw = 0
         self._pending_reduce = []
         self._force_reduce = bool(kwargs.get('force_stats_allreduce', False))   # 1-rank RCCL smoke test
+        self._collective = kwargs.get('collective', 'rccl')
+        if self._collective not in ('rccl', 'torch'):
+            raise ValueError("collective must be 'rccl' or 'torch'")
+        self._comm_attached = False
 
         self.reset(start_state, multi_goal_states, initial_particle_means=initial_particle_means)
 
@@ -177,15 +187,20 @@ class StochGPMP:
             self.num_particles_local
         M = T * d
 
-        if self._engine is not None:
-            self._engine.close()
-        self._engine = Engine(n, T, Pl, S, G, nppg, self.p0, P, tensor_args=ta)
+        # The context (factor buffers, cost program, RCCL communicator) and the iteration buffers
+        # survive reset(): a receding-horizon loop resets every control cycle, and K1's output only
+        # depends on (dt, sigmas), which Engine.set_prior remembers.
+        fresh = self._engine is None
+        if fresh:
+            self._engine = Engine(n, T, Pl, S, G, nppg, self.p0, P, tensor_args=ta)
+            self._attach_comm()
         eng = self._engine
         goal_init = self.sigma_goal_init if self.goal_directed else None
         goal_sample = self.sigma_goal_sample if self.goal_directed else None
         # K1 twice (init + sampling priors): planner.py:206-212, 218-225
         eng.set_prior(L.PRIOR_SAMPLE, self.dt, self.sigma_start_sample, self.sigma_gp_sample, goal_sample)
-        self._draw = 0
+        # (the draw counter keeps running across reset(), as the reference's generator does: a
+        # replanning loop must not see the same noise after every reset)
 
         if initial_particle_means is not None:
             if isinstance(initial_particle_means, str) and initial_particle_means == 'const_vel':
@@ -204,30 +219,40 @@ class StochGPMP:
         # flatten(0,1): p = g * nppg + k (planner.py:215); keep this rank's shard
         self.particle_means = pm.reshape(P, T, d)[self.p0:self.p1].contiguous().clone()
 
-        # persistent buffers of the iteration
-        self.state_samples = torch.empty(Pl, S, T, d, **ta)
-        self._samples_buf = self.state_samples          # iteration buffer (pointers are pre-bound)
-        self._costs = torch.empty(Pl, S, **ta)
-        self._costs64 = torch.empty(Pl, S, device=ta['device'], dtype=torch.float64)
+        # persistent buffers of the iteration.  NOTE: optimize() hands out VIEWS of these (the
+        # reference returns views of its sample tensor too, planner.py:246-249, but clones of the
+        # means): results kept across calls must be cloned by the caller.
+        if fresh:
+            self._samples_buf = torch.empty(Pl, S, T, d, **ta)      # iteration buffer (pointers are pre-bound)
+            self._costs = torch.empty(Pl, S, **ta)
+            self._costs64 = torch.empty(Pl, S, device=ta['device'], dtype=torch.float64)
+            self._weights_buf = torch.empty(Pl, S, **ta)
+            self._grad = torch.empty(Pl, T, d, **ta)
+            self._means_prev = torch.empty(Pl, T, d, **ta)
+            self._stats = torch.zeros(2, L.STAT_SHARDS, 4, device=ta['device'], dtype=torch.float64)
+            # views handed back by optimize(): created once, the buffers are persistent
+            self._weights = self._weights_buf.view(-1, S, 1, 1)
+            self._views = (self._means_prev[..., :n], self._means_prev[..., -n:],
+                           self._samples_buf[..., :n], self._samples_buf[..., -n:])
+        else:
+            self._engine.stats_wait(None)                # a side-stream all-reduce may still use _stats
+            self._stats.zero_()
+        self.state_samples = self._samples_buf
         self._costs64_fresh = False
-        self._weights_buf = torch.empty(Pl, S, **ta)
-        self._grad = torch.empty(Pl, T, d, **ta)
-        self._means_prev = torch.empty(Pl, T, d, **ta)
-        self._stats = torch.zeros(2, L.STAT_SHARDS, 4, device=ta['device'], dtype=torch.float64)
         self._stats_slot = 0
         self._step_calls = {}
-        # views handed back by optimize(): created once, the buffers are persistent
-        self._weights = self._weights_buf.view(-1, S, 1, 1)
-        self._views = (self._means_prev[..., :n], self._means_prev[..., -n:],
-                       self.state_samples[..., :n], self.state_samples[..., -n:])
         self._Sigma_inv = None
-        self._obs_cache = (None, None)
+        self._obs_src = None        # strong reference to the caller's obstacle tensor (see _spheres)
+        self._obs_ver = -1
+        self._obs_dev = None
 
         # cost program: our CostComposite is compiled into the engine; anything else with .eval is
         # called as user code on the samples tensor (planner.py:76,231)
-        self._native_cost = hasattr(self.cost, "compile_into")
+        # (a composite around a foreign FK callable evaluates its link fields outside the sweep)
+        self._native_cost = hasattr(self.cost, "compile_into") and not getattr(self.cost, "foreign_fk", False)
         if self._native_cost:
             self.cost.compile_into(eng)
+            self._cost_version = self.cost.version()
         else:
             eng.set_costs([])
 
@@ -261,13 +286,32 @@ class StochGPMP:
 
     # ------------------------------------------------------------------------------- helpers
     def _spheres(self, observation):
+        """observation['obstacle_spheres'] as a contiguous [O,4] device tensor of the planner's dtype.
+
+        A tensor that already is one is used in place (its pointer goes to the kernels, so in-place
+        edits by the caller are seen).  Anything else is converted into a planner-owned buffer that
+        keeps its address while the sphere count stays the same.  The source tensor is held by a
+        strong reference and re-converted whenever it is another object or its version counter
+        moved -- never keyed on id(), which CPython reuses as soon as a tensor is freed."""
         sph = observation.get('obstacle_spheres', None)
         if sph is None:
+            self._obs_src = None
             return None
-        key = (id(sph), sph._version)
-        if self._obs_cache[0] != key:
-            self._obs_cache = (key, sph.to(**self.tensor_args).reshape(-1, 4).contiguous())
-        return self._obs_cache[1]
+        ta = self.tensor_args
+        direct = (sph.is_cuda and sph.device == torch.device(ta['device']) and sph.dtype == ta['dtype']
+                  and sph.is_contiguous() and sph.numel() % 4 == 0)
+        if direct:
+            self._obs_src = sph
+            return sph.view(-1, 4)
+        if sph is self._obs_src and sph._version == self._obs_ver:
+            return self._obs_dev
+        conv = sph.detach().to(**ta).reshape(-1, 4)
+        if self._obs_dev is None or self._obs_dev.shape != conv.shape:
+            self._obs_dev = conv.contiguous().clone()
+        else:
+            self._obs_dev.copy_(conv)
+        self._obs_src, self._obs_ver = sph, sph._version
+        return self._obs_dev
 
     def _draw_eps(self):
         if self.noise != 'torch':
@@ -276,9 +320,29 @@ class StochGPMP:
         return torch.randn(self.num_samples, self.num_particles, self.traj_len * self.d_state_opt,
                            dtype=ta['dtype']).to(ta['device'])
 
+    def _attach_comm(self):
+        """Give the engine an RCCL communicator over the ranks of the process group (multi-GPU runs)."""
+        import torch.distributed as dist
+        self._comm_attached = False
+        if not ((self.world_size > 1 or self._force_reduce) and self._collective == 'rccl'
+                and dist.is_available() and dist.is_initialized()):
+            return
+        group = self.process_group
+        if dist.get_world_size(group) != self.world_size:
+            return                                       # a shard run stand-alone: no peers to reduce with
+        box = [self._engine.comm_unique_id() if dist.get_rank(group) == 0 else None]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group,
+                                   device=torch.device(self.tensor_args['device']))
+        self._engine.comm_init(box[0], self.world_size, dist.get_rank(group))
+        self._comm_attached = True
+
     def _reduce_stats(self, slot):
-        # (a shard run stand-alone -- world_size > 1 without a process group -- has no peers to reduce with)
-        if (self.world_size > 1 or self._force_reduce) and torch.distributed.is_initialized():
+        if self._comm_attached:
+            return                                       # sgpmp_step enqueued the RCCL all-reduce itself
+        # torch.distributed path (collective='torch'; a shard run stand-alone has no peers to reduce with)
+        if (self.world_size > 1 or self._force_reduce) and torch.distributed.is_initialized() \
+                and self._collective == 'torch':
             self._pending_reduce.append(allreduce_stats_async(self._stats[slot], self.process_group))
             if len(self._pending_reduce) > 1:           # never gate the next iteration's kernels
                 self._pending_reduce.pop(0).wait()
@@ -289,6 +353,8 @@ class StochGPMP:
         for w in self._pending_reduce:
             w.wait()
         self._pending_reduce = []
+        if self._comm_attached:
+            self._engine.stats_wait(None)                # stream-side wait for the side-stream all-reduce
         s = self._stats[self._stats_slot ^ 1].sum(0).cpu()      # sum the shards
         cnt = max(float(s[2]), 1.0)
         return float(s[0]) / cnt, float(s[1]) / cnt
@@ -300,12 +366,17 @@ class StochGPMP:
         if not self._native_cost:
             return self._step_foreign_cost(**observation)
         slot = self._stats_slot
+        cv = self.cost.version()
+        if cv != self._cost_version:                     # a field / cost was edited (e.g. update_target)
+            self.cost.compile_into(self._engine)
+            self._cost_version = cv
         if self.num_particles_local > 0:
             if self.noise == 'philox':
                 # hot path: all arguments except the draw counter are pre-bound (one ctypes call)
-                sph = observation.get('obstacle_spheres', None)
-                key = (slot, None if sph is None else (id(sph), sph._version), self.temperature,
-                       self.step_size, self.particle_means.data_ptr(), self.state_samples.data_ptr())
+                sph = self._spheres(observation)
+                key = (slot, 0 if sph is None else sph.data_ptr(), 0 if sph is None else sph.shape[0],
+                       self.temperature, self.step_size, self.particle_means.data_ptr(),
+                       self.state_samples.data_ptr())
                 call = self._step_calls.get(key)
                 if call is None:
                     if len(self._step_calls) > 8:
@@ -313,8 +384,7 @@ class StochGPMP:
                     call = self._engine.prepare_step(
                         self.seed, self.particle_means, self.state_samples, self.temperature,
                         self.step_size, costs=self._costs, weights=self._weights_buf, grad=self._grad,
-                        means_prev=self._means_prev, spheres=self._spheres(observation),
-                        stats=self._stats[slot])
+                        means_prev=self._means_prev, spheres=sph, stats=self._stats[slot])
                     self._step_calls[key] = call
                 call(self._draw)
             else:
@@ -435,6 +505,8 @@ class StochGPMP:
         """All ranks' particle means [P,T,d] (RCCL all-gather over xGMI); identity on one GPU."""
         if self.world_size == 1:
             return self.particle_means
+        if self._comm_attached and self.num_particles_local * self.world_size == self.num_particles:
+            return self._engine.allgather_means(self.particle_means, self.world_size)
         return allgather_means(self.particle_means, self.num_particles, self.world_size,
                                self.process_group)
 

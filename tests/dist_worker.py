@@ -1,0 +1,46 @@
+"""One rank of the 2-GPU parity check (launched by tests/test_gpu_dist.py through
+`python -m torch.distributed.run`): a particle-sharded StochGPMP over RCCL must reproduce, bit for
+bit, the slice of the unsharded planner that this rank owns, and its all-reduced statistics must be
+the unsharded run's."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch                                   # noqa: E402
+import torch.distributed as dist               # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from tests import scenarios as SC
+    from tests.hip_builders import hip_panda_planner
+    ta = {"device": dev, "dtype": torch.float32}
+    P, S, T, iters = 64 * world, 32, 32, 3
+    sph = torch.as_tensor(SC.panda_spheres()).to(**ta)
+    full = hip_panda_planner(SC.PANDA, T, P, S, ta, seed=4)                     # unsharded, on this GPU
+    shard = hip_panda_planner(SC.PANDA, T, P, S, ta, seed=4, rank=rank, world_size=world)
+    assert shard._comm_attached, "RCCL communicator not attached"
+    assert torch.equal(shard.particle_means, full.particle_means[shard.p0:shard.p1])
+    for _ in range(iters):
+        full.optimize(obstacle_spheres=sph)
+        shard.optimize(obstacle_spheres=sph)
+    assert torch.equal(shard.particle_means, full.particle_means[shard.p0:shard.p1]), "means differ"
+    assert torch.equal(shard._costs, full._costs[shard.p0:shard.p1]), "costs differ"
+    gs, gf = shard.global_stats(), full.global_stats()
+    assert abs(gs[0] / gf[0] - 1) < 1e-12 and abs(gs[1] / gf[1] - 1) < 1e-12, (gs, gf)
+    allm = shard.gather_particle_means()
+    assert torch.equal(allm, full.particle_means), "all-gathered means differ"
+    dist.barrier()
+    if rank == 0:
+        print(f"DIST_OK world={world} stats={gs}")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

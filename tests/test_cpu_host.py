@@ -135,8 +135,15 @@ def test_cost_descriptors_follow_the_reference_constructors():
                                                 sigma_coll=0.01)],
                        FK=fk.compute_forward_kinematics_all_links, tensor_args=CPU)
     assert len(cc.descriptors()) == 2 and len(cc.chain) == 10 and not cc.needs_spheres()
-    with pytest.raises(TypeError):
-        CostComposite(n, T, [gp], FK=lambda q: q)       # arbitrary FK callables cannot run in HIP
+    # an arbitrary FK callable (cost_functions.py:39,51-52) is legal: its link-field children leave the
+    # compiled program and are evaluated on the frames the callable returns
+    fc = CostComposite(n, T, [gp, CostCollision(n, T, field=LinkSelfDistanceField(tensor_args=CPU),
+                                                sigma_coll=0.01)], FK=lambda q: q, tensor_args=CPU)
+    assert fc.foreign_fk and fc.chain is None and len(fc.descriptors()) == 1 and not cc.foreign_fk
+    # edit counters: a moved target / re-built factor is visible to whoever compiled the cost
+    v0 = cc.version()
+    gp.set_cost_factors()
+    assert cc.version() > v0
     with pytest.raises(NotImplementedError):
         CostGoal(n, T, sigma_goal=1.).get_linear_system(None)     # no linear system for the SE(3) goal
     H = torch.eye(4, dtype=torch.float64)

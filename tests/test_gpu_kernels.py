@@ -572,6 +572,7 @@ def test_update_with_fp32_costs_tensor():
     (6, 2, 3, "sdf"),           # shortest trajectory (one GP factor)
     (4, 64, 1, "occupancy"),    # exactly one full pass, one sphere
     (4, 66, 130, "rbf"),        # more spheres than the LDS staging holds -> falls back; T just over a pass
+    (4, 66, 128, "rbf"),        # exactly the staging limit -> stays on the two-trajectory multi-pass kernel
     (5, 64, 40, "sdf"),         # odd batch tail (5 rows: last pair has one row)
 ])
 def test_cost_sweep_dispatch_corners_match_oracle_fp32(S, T, n_sph, field_type):
@@ -600,6 +601,64 @@ def test_cost_sweep_dispatch_corners_match_oracle_fp32(S, T, n_sph, field_type):
     o64 = e64.cost_eval(trajs.to(**F64).contiguous(), spheres=sph.to(**F64).reshape(-1, 4).contiguous(),
                         is_weights=w.to(**F64).contiguous(), rows_per_particle=S)
     close(o32, o64, 2e-4)
+
+
+@pytest.mark.parametrize("T,field_type,kernel", [
+    (66, "rbf", "cost_sweep_dual_pf_multi_kernel"), (128, "rbf", "cost_sweep_dual_pf_multi_kernel"),
+    (130, "sdf", "cost_sweep_dual_pf_multi_kernel"), (128, "occupancy", "cost_sweep_dual_pf_multi_kernel"),
+    (65, "rbf", "cost_sweep_dual_kernel"), (129, "sdf", "cost_sweep_dual_kernel"),
+    (64, "rbf", "cost_sweep_dual_pf_kernel"), (63, "rbf", "cost_sweep_dual_kernel"),
+])
+@pytest.mark.parametrize("with_is", [False, True])
+def test_two_trajectory_sweeps_full_program_match_oracle_fp32(T, field_type, kernel, with_is):
+    """The two-trajectory fp32 kernels with their FULL program -- CostGP (start factor + GP factors),
+    multi-goal prior, self and sphere fields, importance-sampling term -- against the fp64 oracle:
+    the multi-pass LDS-prefetch kernel (even T > 64: carried neighbour, per-lane running sum, partial last
+    pass, unary factors gated on first / last pass), the register-prefetch multi-pass kernel (odd T > 64),
+    the single-pass ones, with an odd batch tail.  The dispatcher's choice is asserted, not assumed."""
+    from stoch_gpmp_amd import _lib as L
+    from tests.hip_builders import hip_panda_cost
+    c, n = SC.PANDA, 7
+    nppg, S, G = 3, 6, 2
+    goals = [c["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n]
+    g = torch.Generator().manual_seed(1000 + T)
+    # smooth trajectories (random walk) so that the GP term does not drown everything else in fp32
+    q = torch.cumsum(torch.randn(G * nppg, S, T, n, generator=g) * 0.01, dim=2) + torch.rand(G * nppg, S, 1, n, generator=g)
+    v = torch.randn(G * nppg, S, T, n, generator=g) * 0.05
+    trajs = torch.cat([q, v], dim=-1).double()
+    sph = torch.as_tensor(SC.panda_spheres(num=9, seed=7))
+    ora = SC.oracle_panda_cost(c, T, nppg, S, torch.float64, field_type=field_type, goals=goals)
+    ref = ora.eval(trajs, obstacle_spheres=sph).reshape(G * nppg, S)
+    w = torch.randn(G * nppg, T + 1, 2 * n, generator=g).double() * 50.
+    if with_is:
+        x = trajs
+        e = torch.cat([x[..., 1:, :n] - x[..., :-1, :n] - c["dt"] * x[..., :-1, n:],
+                       x[..., 1:, n:] - x[..., :-1, n:]], dim=-1)
+        Ax = torch.cat([x[..., :1, :], e, x[..., -1:, :]], dim=-2)
+        ref = ref + (Ax * w.unsqueeze(1)).sum((-1, -2))
+    hip = hip_panda_cost(c, T, nppg, S, F32, field_type=field_type, goals=goals)
+    eng = hip._engine(torch.float32, DEV)
+    sph32 = sph.to(**F32).reshape(-1, 4).contiguous()
+    t32 = trajs.to(**F32).contiguous()
+    # the importance-sampling term of the sweep uses the time step of the sampling prior: give the
+    # engine one (same dt as the cost's GP factor)
+    eng.set_prior(L.PRIOR_SAMPLE, c["dt"], 1e-3, 0.1, 0.07)
+    out = eng.cost_eval(t32, spheres=sph32, is_weights=w.to(**F32).contiguous() if with_is else None,
+                        rows_per_particle=S).reshape(G * nppg, S)
+    assert eng.last_cost_kernel() == kernel, eng.last_cost_kernel()
+    # fp32 rounding of the inputs bounds what any fp32 kernel can do: compare with the fp64 sweep of the
+    # SAME rounded trajectories (tight) and with the oracle on the unrounded ones (loose)
+    e64 = hip_panda_cost(c, T, nppg, S, F64, field_type=field_type, goals=goals)._engine(torch.float64, DEV)
+    e64.set_prior(L.PRIOR_SAMPLE, c["dt"], 1e-3, 0.1, 0.07)
+    exact = e64.cost_eval(t32.double().contiguous(), spheres=sph.to(**F64).reshape(-1, 4).contiguous(),
+                          is_weights=w.to(**F32).double().contiguous() if with_is else None,
+                          rows_per_particle=S).reshape(G * nppg, S)
+    close(out, exact, 2e-5)
+    close(out, ref, 5e-3)
+    # odd tail: the last pair has a single row
+    odd = eng.cost_eval(t32.reshape(-1, T, 2 * n)[:2 * S + 3].contiguous(), spheres=sph32,
+                        is_weights=w.to(**F32).contiguous() if with_is else None, rows_per_particle=S)
+    assert torch.equal(odd, out.reshape(-1)[:2 * S + 3])
 
 
 def test_zero_sized_batches_are_no_ops():

@@ -184,6 +184,126 @@ def test_planar_fp32_against_fp64_oracle_same_noise(golden):
     assert agree.mean() >= 0.75, f"only {agree.mean():.2f} of the particles within 1e-3"
 
 
+def _is_dot(samples, w, n, dt):
+    """Importance-sampling inner product (A x) . w with A x = (x_0, e_0 .. e_{T-2}, x_{T-1}),
+    e_t = x_{t+1} - Phi x_t (planner.py:233-236 in the factored form the kernels use); fp64 torch."""
+    x = samples.double()
+    pos, vel = x[..., :n], x[..., n:]
+    e = torch.cat([pos[..., 1:, :] - pos[..., :-1, :] - dt * vel[..., :-1, :],
+                   vel[..., 1:, :] - vel[..., :-1, :]], dim=-1)                      # [P,S,T-1,d]
+    Ax = torch.cat([x[..., :1, :], e, x[..., -1:, :]], dim=-2)                       # [P,S,T+1,d]
+    return (Ax * w.double().unsqueeze(1)).sum((-1, -2))
+
+
+def _fp32_panda_run(T, nppg, S, iters, goals=None, field_type='rbf', n_sph=5, seed=13, expect_kernel=None):
+    """Panda fp32 planner in its DEFAULT mode (in-kernel Philox noise) against the fp64 oracle driven by
+    the CPU restatement of that stream.  Means are re-synchronised after every iteration so that each
+    iteration is an independent trial of "does the fp32 path move every particle where the fp64
+    reference moves it".  Returns per-iteration records."""
+    from oracle.native_noise import native_eps
+    c, n = SC.PANDA, 7
+    G = 1 if goals is None else len(goals)
+    P = G * nppg
+    sph = torch.as_tensor(SC.panda_spheres(num=n_sph, seed=seed))
+    eps0 = torch.from_numpy(native_eps(seed, 0, range(G), nppg, T, n, "float32")).double()
+    ora = SC.oracle_panda_planner(c, T, nppg, S, seed=seed, eps_init=eps0, goals=goals, field_type=field_type)
+    pl = hip_panda_planner(c, T, nppg, S, F32, seed=seed, goals=goals, field_type=field_type)
+    assert rel_err(pl.particle_means, ora.particle_means) < 2e-5
+    pl.particle_means.copy_(ora.particle_means.to(**F32))
+    scale = float(ora.particle_means.abs().max())
+    out = []
+    for it in range(iters):
+        eps = torch.from_numpy(native_eps(seed, 2 + it, range(P), S, T, n, "float32")).double()
+        ora.particle_means.copy_(pl.particle_means.cpu().double())      # identical (fp32-representable) means
+        ora.prior.set_mean(ora.particle_means.view(P, -1))
+        costs_o, _ = ora.step(eps=eps, obstacle_spheres=sph)
+        _, _, _, _, costs, _ = pl.optimize(obstacle_spheres=sph.to(**F32))
+        if expect_kernel is not None:
+            assert pl._engine.last_cost_kernel() == expect_kernel, pl._engine.last_cost_kernel()
+        samples_err = float((pl.state_samples.cpu().double() - ora.state_samples).abs().max())
+        assert samples_err < 2e-5 * float(ora.state_samples.abs().max())
+        # the fp32 kernel's arithmetic alone: fp64 sweep of the very same (fp32-rounded) samples
+        e64 = pl.cost._engine(torch.float64, DEV)
+        exact = e64.cost_eval(pl.state_samples.double().contiguous(), batch_offset=0,
+                              spheres=sph.to(**F64).reshape(-1, 4).contiguous()).reshape(P, S).cpu()
+        w = pl._engine.is_weights(pl._means_prev.contiguous(), pl.temperature)      # pre-update means
+        exact = exact + _is_dot(pl.state_samples.cpu(), w.cpu(), n, c["dt"])
+        c32 = costs.cpu().double()
+        d = (pl.particle_means.cpu().double() - ora.particle_means).abs().amax(dim=(1, 2)) / scale
+        out.append(dict(
+            cost_rel=float(((c32 - costs_o).abs() / costs_o.abs()).max()),
+            arith_rel=float(((c32 - exact).abs() / exact.abs()).max()),
+            rounding_rel=float(((exact - costs_o).abs() / costs_o.abs()).max()),
+            argmin_same=float((c32.argmin(1) == costs_o.argmin(1)).double().mean()),
+            means_within_1e3=float((d < 1e-3).double().mean()), worst=float(d.max())))
+    return out
+
+
+def _report(tag, recs):
+    frac = float(np.mean([r["means_within_1e3"] for r in recs]))
+    print(f"\n[fp32 parity] {tag}: particles within 1e-3 of the fp64 means: {frac:.4f} "
+          f"(per iteration {[round(r['means_within_1e3'], 4) for r in recs]}); same arg-min {np.mean([r['argmin_same'] for r in recs]):.4f}; "
+          f"cost rel err vs oracle {max(r['cost_rel'] for r in recs):.2e} = kernel arithmetic "
+          f"{max(r['arith_rel'] for r in recs):.2e} + fp32 rounding of the samples {max(r['rounding_rel'] for r in recs):.2e}")
+    return frac
+
+
+def test_panda_fp32_headline_kernel_means_match_fp64_oracle():
+    """north_star: fp32 trajectory means within 1e-3 of the reference CPU path.  The headline kernel
+    (cost_sweep_dual_pf_kernel: even S, even T <= 64, rbf) over 6 iterations, 48 particles, native
+    noise.  With temperature = 1 and costs of 1e9-1e11 the update is an arg-min over samples, so a
+    particle agrees unless fp32 flips the arg-min; the agreeing fraction is printed and bounded."""
+    recs = _fp32_panda_run(T=32, nppg=48, S=32, iters=6, expect_kernel="cost_sweep_dual_pf_kernel")
+    frac = _report("Panda 48x32x32 rbf (dual_pf)", recs)
+    assert max(r["cost_rel"] for r in recs) < 5e-3
+    assert frac >= 0.99, frac                          # measured on MI355X: 1.0000 (arg-min identical for every particle)
+
+
+def test_panda_fp32_config5_kernel_means_match_fp64_oracle():
+    """BASELINE config 5 in its stated precision and in miniature: 2 goals, T = 128 (two passes of
+    cost_sweep_dual_pf_multi_kernel with the carried neighbour waypoint), fp64 prior + fp32 cost path,
+    GP + multi-goal prior + IS + self + sphere fields, against the fp64 oracle: costs and means."""
+    n = 7
+    goals = [SC.PANDA["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n]
+    recs = _fp32_panda_run(T=128, nppg=6, S=16, iters=4, goals=goals, n_sph=7,
+                           expect_kernel="cost_sweep_dual_pf_multi_kernel")
+    frac = _report("Panda 2 goals x 6 x 16 x 128 rbf (dual_pf_multi)", recs)
+    assert max(r["cost_rel"] for r in recs) < 5e-3
+    assert frac >= 0.99, frac                          # measured: 1.0000
+    recs = _fp32_panda_run(T=66, nppg=6, S=16, iters=3, goals=goals, n_sph=7, field_type='sdf',
+                           expect_kernel="cost_sweep_dual_pf_multi_kernel")
+    frac = _report("Panda 2 goals x 6 x 16 x 66 sdf (dual_pf_multi)", recs)
+    assert max(r["cost_rel"] for r in recs) < 5e-3 and frac >= 0.99
+
+
+def test_planar_fp32_means_match_fp64_oracle_native_noise(golden):
+    """The planar twin of the test above (config 2's kernels: fp32 generic sweep with the grid lookup)."""
+    from oracle.native_noise import native_eps
+    z = golden("g2_planar_e2e.npz")
+    T, nppg, S, n, seed = 64, 32, 32, 2, 5
+    goals = z["goals"]
+    G = len(goals)
+    P = G * nppg
+    eps0 = torch.from_numpy(native_eps(seed, 0, range(G), nppg, T, n, "float32")).double()
+    ora = SC.oracle_planar_planner(SC.PLANAR, T, goals, nppg, S, z["grid"], float(z["cell_size"]),
+                                   z["c_offset"], seed=seed, eps_init=eps0)
+    pl = hip_planar_planner(SC.PLANAR, T, goals, nppg, S, planar_map(golden, F32), F32, seed=seed)
+    scale = float(ora.particle_means.abs().max())
+    fr, same = [], []
+    for it in range(6):
+        eps = torch.from_numpy(native_eps(seed, 2 + it, range(P), S, T, n, "float32")).double()
+        ora.particle_means.copy_(pl.particle_means.cpu().double())
+        ora.prior.set_mean(ora.particle_means.view(P, -1))
+        costs_o, _ = ora.step(eps=eps)
+        _, _, _, _, costs, _ = pl.optimize()
+        assert rel_err(costs, costs_o) < 5e-3
+        d = (pl.particle_means.cpu().double() - ora.particle_means).abs().amax(dim=(1, 2)) / scale
+        fr.append(float((d < 1e-3).double().mean()))
+        same.append(float((costs.cpu().argmin(1) == costs_o.argmin(1)).double().mean()))
+    print(f"\n[fp32 parity] planar 64x32x64: particles within 1e-3: {np.mean(fr):.4f} {fr}; same arg-min {np.mean(same):.4f}")
+    assert np.mean(fr) >= 0.99                         # measured: 1.0000 (arg-min identical for 99.7 %)
+
+
 # --------------------------------------------------------------------------- API surface
 def test_api_surface_and_errors(golden):
     om = planar_map(golden, F32)
@@ -216,6 +336,109 @@ def test_api_surface_and_errors(golden):
     before = p2.particle_means.clone()
     out = p2.optimize(opt_iters=2)
     assert out[4].shape == (2, 4) and not torch.equal(before, p2.particle_means)
+
+
+# --------------------------------------------------------------------------- live observations / edits
+def test_moving_obstacles_are_seen_on_every_call():
+    """optimize(obstacle_spheres=...) must use THIS call's spheres (reference fields.py:63-76 reads the
+    observation on every eval): fresh tensors per call -- whose id() CPython recycles --, CPU tensors,
+    and one device tensor edited in place, all against a planner fed explicit per-call copies."""
+    import gc
+    T, nppg, S = 16, 4, 8
+    base = torch.as_tensor(SC.panda_spheres()).float()
+    a = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=3)            # fresh CPU tensors (freed at once)
+    b = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=3)            # one device tensor, edited in place
+    c = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=3)            # fresh device tensors
+    frozen = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=3)       # never told that the spheres moved
+    live = base.to(DEV).clone()
+    first = base.to(DEV).clone()
+    differs = 0
+    for i in range(6):
+        shift = torch.tensor([0.03 * i, -0.02 * i, 0.01 * i, 0.0])
+        a.optimize(obstacle_spheres=torch.tensor((base + shift).tolist()))
+        gc.collect()
+        live.copy_((base + shift).to(DEV))
+        b.optimize(obstacle_spheres=live)
+        c.optimize(obstacle_spheres=(base + shift).to(DEV))
+        frozen.optimize(obstacle_spheres=first)
+        assert torch.equal(a._costs, b._costs) and torch.equal(a._costs, c._costs), f"call {i}"
+        assert torch.equal(a.particle_means, b.particle_means) and torch.equal(a.particle_means, c.particle_means)
+        differs += int(not torch.equal(a._costs, frozen._costs))
+    assert differs >= 4          # the moved spheres do change the costs (the check above is not vacuous)
+
+
+def test_update_target_reaches_a_live_planner():
+    """EESE3DistanceField.update_target (fields.py:140-141): the reference reads target_H on every eval,
+    so a planner that already compiled the cost must follow the new target on its next step."""
+    from stoch_gpmp_amd.costs.cost_functions import CostGoal
+    from stoch_gpmp_amd.costs.fields import EESE3DistanceField
+    from oracle.fk import fk_all_links
+    T, nppg, S, n = 16, 3, 8, 7
+    H1 = fk_all_links(torch.tensor([[0.3, -0.5, 0.2, -1.9, 0.1, 1.6, 0.4]], dtype=torch.float64))[0, -1].clone()
+    H2 = fk_all_links(torch.tensor([[-0.6, 0.1, 0.5, -1.2, -0.3, 2.2, 0.0]], dtype=torch.float64))[0, -1].clone()
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
+
+    def build(H):
+        pl = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=6)
+        field = EESE3DistanceField(H, w_pos=1., w_rot=0.5, tensor_args=F32)
+        pl.cost.cost_list.append(CostGoal(n, T, field=field, sigma_goal=1e-4, tensor_args=F32))
+        pl.step_size = 0.0                                   # keep the means: both planners see the same draws
+        return pl, field
+    moved, field = build(H1)
+    fresh, _ = build(H2)
+    moved.optimize(obstacle_spheres=sph)
+    fresh.optimize(obstacle_spheres=sph)
+    assert not torch.equal(moved._costs, fresh._costs)       # different targets, different costs
+    field.update_target(H2)
+    moved.optimize(obstacle_spheres=sph)
+    fresh.optimize(obstacle_spheres=sph)
+    assert torch.equal(moved.state_samples, fresh.state_samples)
+    assert torch.equal(moved._costs, fresh._costs)
+
+
+def test_arbitrary_fk_callable_gives_the_native_results():
+    """cost_functions.py:39,51-52: FK is ANY callable q[B*T,n] -> [B*T,L,4,4].  A plain Python function
+    (here: a closure around the chain's FK, so the expected numbers are known) takes the frames-in
+    path; costs must match the in-sweep FK path, in a composite and through a planner."""
+    from stoch_gpmp_amd.costs.cost_functions import CostComposite
+    from stoch_gpmp_amd.robots.panda import DifferentiableFrankaPanda
+    c, n = SC.PANDA, 7
+    T, nppg, S = 12, 3, 6
+    for ta, tol in ((F64, 1e-10), (F32, 2e-4)):
+        sph = torch.as_tensor(SC.panda_spheres()).to(**ta)
+        native = hip_panda_cost(c, T, nppg, S, ta, field_type='sdf')
+        robot = DifferentiableFrankaPanda(gripper=False, device=DEV)
+        calls = []
+
+        def my_fk(q):
+            calls.append(q.shape)
+            return robot.compute_forward_kinematics_all_links(q)
+        foreign = CostComposite(n, T, hip_panda_cost(c, T, nppg, S, ta, field_type='sdf').cost_list,
+                                FK=my_fk, tensor_args=ta)
+        assert foreign.foreign_fk and not native.foreign_fk
+        g = torch.Generator().manual_seed(2)
+        trajs = torch.cat([torch.rand(nppg, S, T, n, generator=g) * 2 - 1,
+                           torch.randn(nppg, S, T, n, generator=g) * 0.1], dim=-1).to(**ta)
+        # drop the GP / goal terms for the comparison in fp32 (they would swamp the fields)
+        native.cost_list = native.cost_list[2:]
+        foreign.cost_list = foreign.cost_list[2:]
+        a = native.eval(trajs, obstacle_spheres=sph)
+        b = foreign.eval(trajs, obstacle_spheres=sph)
+        assert calls and calls[-1] == (nppg * S * T, n)
+        assert rel_err(b, a) < tol
+    # through the planner: the composite is then user code to StochGPMP (slow path), and it runs
+    pl = hip_panda_planner(c, T, nppg, S, F32, seed=1)
+    pl_f = hip_panda_planner(c, T, nppg, S, F32, seed=1)
+    robot = DifferentiableFrankaPanda(gripper=False, device=DEV)
+    pl_f.cost = CostComposite(n, T, pl_f.cost.cost_list, FK=lambda q: robot.compute_forward_kinematics_all_links(q),
+                              tensor_args=F32)
+    pl_f._draw = 0                                       # replay the same draws as `pl` (test-only)
+    pl_f.reset()
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
+    o1 = pl.optimize(obstacle_spheres=sph)
+    o2 = pl_f.optimize(obstacle_spheres=sph)
+    assert torch.equal(pl.state_samples, pl_f.state_samples)
+    assert rel_err(o2[4], o1[4]) < 1e-4
 
 
 # --------------------------------------------------------------------------- full-size properties
@@ -254,6 +477,64 @@ def test_full_size_sharded_equals_unsharded_bitwise():
     assert not torch.equal(full.particle_means, ref_means0)
 
 
+def test_config4_eight_shards_equal_unsharded_bitwise():
+    """BASELINE config 4 on one GPU: Panda 8192 x 128 x 64 fp32 (3.8 GB of samples) run unsharded, then
+    as the eight `rank = r, world_size = 8` shards of 1024 particles run one after the other
+    (particle_offset up to 7168): means and costs must be bit-identical -- the 8-GPU run IS the 1-GPU run."""
+    P, S, T = 8192, 128, 64
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
+    full = _full_panda(P, S, T, F32)
+    means0 = full.particle_means.clone()
+    for _ in range(2):
+        full.optimize(obstacle_spheres=sph)
+    full_means, full_costs = full.particle_means.clone(), full._costs.clone()
+    assert full._engine.last_cost_kernel() == "cost_sweep_dual_pf_kernel"
+    stats_full = full._stats[full._stats_slot ^ 1].sum(0).cpu()
+    del full
+    torch.cuda.empty_cache()
+    stats_sum = torch.zeros(4, dtype=torch.float64)
+    for r in range(8):
+        h = _full_panda(P, S, T, F32, rank=r, world_size=8)
+        assert (h.p0, h.p1) == (1024 * r, 1024 * (r + 1))
+        assert torch.equal(h.particle_means, means0[h.p0:h.p1])
+        for _ in range(2):
+            h.optimize(obstacle_spheres=sph)
+        assert torch.equal(h.particle_means, full_means[h.p0:h.p1]), f"shard {r}: means differ"
+        assert torch.equal(h._costs, full_costs[h.p0:h.p1]), f"shard {r}: costs differ"
+        stats_sum += h._stats[h._stats_slot ^ 1].sum(0).cpu()
+        del h
+    # what the RCCL all-reduce would sum: shard statistics add up to the unsharded run's
+    assert float(stats_sum[2]) == P and abs(float(stats_sum[0] / stats_full[0]) - 1) < 1e-12
+    assert abs(float(stats_sum[1] / stats_full[1]) - 1) < 1e-12
+
+
+@pytest.mark.parametrize("field_type", ["rbf", "sdf"])
+def test_config5_share_fast_sweep_equals_generic_sweep(field_type):
+    """BASELINE config 5's per-GPU share at FULL size (Panda, 512 x 256 x 128, fp32, 4 goals -> this
+    shard holds half of goal 0's particles): cost_sweep_dual_pf_multi_kernel against the single-trajectory
+    generic-FK sweep on all 131 072 trajectories, with IS weights and the multi-goal prior."""
+    c, n = SC.PANDA, 7
+    S, T = 256, 128
+    goals = [c["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n,
+             [0.9, -0.2, 0.4, -1.1, -0.3, 1.9, 0.8] + [0.] * n, [-0.8, 0.1, 0.6, -2.4, 0.4, 2.6, -0.2] + [0.] * n]
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
+    pl = hip_panda_planner(c, T, 1024, S, F32, field_type=field_type, seed=9, goals=goals, rank=3, world_size=8)
+    assert pl.num_particles == 4096 and pl.num_particles_local == 512 and pl.p0 == 1536
+    pl.optimize(obstacle_spheres=sph)
+    assert pl._engine.last_cost_kernel() == "cost_sweep_dual_pf_multi_kernel"
+    samples = pl.state_samples
+    w = pl._engine.is_weights(pl.particle_means, pl.temperature)
+    sphc = sph.reshape(-1, 4).contiguous()
+    kw = dict(batch_offset=pl.p0 * S, spheres=sphc, is_weights=w, rows_per_particle=S)
+    fast = pl._engine.cost_eval(samples, **kw).clone()
+    pl._engine.set_option("no_dual_sweep", 1)
+    pl._engine.set_option("force_generic_fk", 1)
+    slow = pl._engine.cost_eval(samples, **kw)
+    assert pl._engine.last_cost_kernel() == "cost_sweep_kernel<f32, generic FK>"
+    rel = ((fast.double() - slow.double()).abs() / slow.double().abs().clamp_min(1.0)).max()
+    assert fast.shape == (512 * S,) and bool(torch.isfinite(fast).all()) and float(rel) < 2e-5, float(rel)
+
+
 def test_full_size_planar_fused_step_equals_separate_calls(golden):
     """BASELINE config 2 shape (planar, 256 x 64 x 128, fp32): sgpmp_step == K5,K2,K3,K4 called one
     by one through the reference-shaped methods (sample_and_eval + _update_distribution)."""
@@ -275,7 +556,7 @@ def test_full_size_planar_fused_step_equals_separate_calls(golden):
 
 
 @pytest.mark.parametrize("field_type", ["rbf", "sdf"])
-def test_full_size_fast_sweep_equals_generic_sweep(monkeypatch, field_type):
+def test_full_size_fast_sweep_equals_generic_sweep(field_type):
     """BASELINE config 3 at FULL size (Panda, 1024 x 128 x 64, fp32): the two-trajectory LDS-prefetch
     sweep against the single-trajectory generic-FK sweep (SGPMP_NO_DUAL_SWEEP + SGPMP_FORCE_GENERIC_FK) on
     the very same 131 072 samples and importance-sampling weights -- every cost, not a sample of them."""
@@ -288,15 +569,17 @@ def test_full_size_fast_sweep_equals_generic_sweep(monkeypatch, field_type):
     w = pl._engine.is_weights(pl.particle_means, pl.temperature)
     sphc = sph.reshape(-1, 4).contiguous()
     fast = pl._engine.cost_eval(samples, spheres=sphc, is_weights=w, rows_per_particle=S).clone()
-    monkeypatch.setenv("SGPMP_NO_DUAL_SWEEP", "1")
-    monkeypatch.setenv("SGPMP_FORCE_GENERIC_FK", "1")
+    assert pl._engine.last_cost_kernel() == "cost_sweep_dual_pf_kernel"
+    pl._engine.set_option("no_dual_sweep", 1)
+    pl._engine.set_option("force_generic_fk", 1)
     slow = pl._engine.cost_eval(samples, spheres=sphc, is_weights=w, rows_per_particle=S)
+    assert pl._engine.last_cost_kernel() == "cost_sweep_kernel<f32, generic FK>"
     assert fast.shape == (P * S,) and bool(torch.isfinite(fast).all())
     rel = ((fast.double() - slow.double()).abs() / slow.double().abs().clamp_min(1.0)).max()
     assert float(rel) < 2e-5, float(rel)
     # the costs of the planner's own iteration are the fast kernel's
-    monkeypatch.delenv("SGPMP_NO_DUAL_SWEEP")
-    monkeypatch.delenv("SGPMP_FORCE_GENERIC_FK")
+    pl._engine.set_option("no_dual_sweep", 0)
+    pl._engine.set_option("force_generic_fk", 0)
     again = pl._engine.cost_eval(samples, spheres=sphc, is_weights=w, rows_per_particle=S)
     assert torch.equal(again, fast)
 
