@@ -595,12 +595,27 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     if (c->comm && stats) COMMCHK(comm_stats_wait(c->comm, stats, st));
     HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, means, P, temperature, c->d_isw, stats, st));
     if (se) HIPCHK(hipEventRecord(se->ev[1], st));
-    HIPCHK(launch_sample(D.dtype, D.n_dof, D.traj_len, pr, seed, draw, means, P, D.particle_offset, S, eps,
-                         eps_modes, eps_mode_offset, samples, st, c->tg));
-    if (se) HIPCHK(hipEventRecord(se->ev[2], st));
-    HIPCHK(launch_cost(D.dtype, D.n_dof, D.traj_len, c->h_prog, c->d_chain, c->h_chain,
-                       samples, (long long)P * S, (long long)D.particle_offset * S, spheres, n_spheres,
-                       c->d_isw, S, pr.dt, costs, c->d_costs64, st, c->tg, &c->last_cost_kernel));
+    // K2 + K3: one fused launch when the step qualifies (in-kernel noise, fp32 Panda-type program), else
+    // the sampler followed by the sweep
+    bool fused = false;
+    if (!eps) {
+        if (se) HIPCHK(hipEventRecord(se->ev[2], st));   // (fused: all of K2 + K3 is booked on the sweep)
+        HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, means, P,
+                                 D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, costs,
+                                 c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused));
+        for (int i = 0; fused && i < c->h_prog.n_terms; ++i)
+            if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL)
+                HIPCHK(launch_ee_goal(D.dtype, D.n_dof, D.traj_len, c->h_prog.terms[i], c->d_chain, samples,
+                                      (long long)P * S, costs, c->d_costs64, st));
+    }
+    if (!fused) {
+        HIPCHK(launch_sample(D.dtype, D.n_dof, D.traj_len, pr, seed, draw, means, P, D.particle_offset, S, eps,
+                             eps_modes, eps_mode_offset, samples, st, c->tg));
+        if (se) HIPCHK(hipEventRecord(se->ev[2], st));
+        HIPCHK(launch_cost(D.dtype, D.n_dof, D.traj_len, c->h_prog, c->d_chain, c->h_chain,
+                           samples, (long long)P * S, (long long)D.particle_offset * S, spheres, n_spheres,
+                           c->d_isw, S, pr.dt, costs, c->d_costs64, st, c->tg, &c->last_cost_kernel));
+    }
     if (se) HIPCHK(hipEventRecord(se->ev[3], st));
     HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
                          temperature, step_size, weights, grad, means_prev, stats, st));

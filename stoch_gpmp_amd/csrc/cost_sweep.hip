@@ -32,6 +32,7 @@
 #include <cstring>
 
 #include "chain_code_generated.h"
+#include "rng.h"
 #include "sgpmp_internal.h"
 
 template <typename real> struct RealOps;
@@ -492,6 +493,61 @@ static bool make_flat(const CostProgram& p, FlatProg<real>& f) {
 
 #include "cost_sweep_kernel.inc"
 #include "cost_sweep_dual.inc"
+#include "fused_step.inc"
+
+// K2 + K3 in one launch (fused_step.inc) when the step qualifies; *launched says whether it did.
+hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
+                             const ChainDev& h_chain, uint64_t seed, uint64_t draw, const void* means, int P,
+                             int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
+                             const void* isw, void* costs, double* costs64, hipStream_t stream,
+                             const SgpmpToggles& tg, const char** picked, bool* launched) {
+    *launched = false;
+    using CCp = ChainCode_panda;
+    if (dtype != SGPMP_F32 || tg.no_fused_step || tg.no_dual_sweep || tg.no_chain_codegen || tg.force_generic_fk ||
+        tg.no_flat_program)
+        return hipSuccess;
+    if (!prior.isotropic || n != CCp::N || !h_chain.plan.fast || h_chain.plan.codegen_id != 1) return hipSuccess;
+    if (S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0 || n_spheres > SGPMP_FUSED_SPH || !isw || !samples || P < 1)
+        return hipSuccess;
+    FlatProg<float> F;
+    if (!make_flat<float>(h_prog, F) || F.has_grid) return hipSuccess;
+    for (int i = 0; i < h_prog.n_terms; ++i)
+        if (h_prog.terms[i].n_interp > 0) return hipSuccess;
+    if (F.has_goal && (F.goal.rows_per_goal % SGPMP_FUSED_SPW != 0 || F.goal.dim0 > SGPMP_FUSED_GOALS)) return hipSuccess;
+    if (F.has_gp && (float)prior.dt != F.gp.dt) return hipSuccess;       // IS term and GP factors share Phi
+    const long long batch = (long long)P * S, batch_offset = (long long)mode_offset * S;
+    if (batch + batch_offset >= (1LL << 31)) return hipSuccess;
+    auto log2_exact = [](long long v) { int s = 0; while ((1LL << s) < v && s < 62) ++s; return (1LL << s) == v ? s : -1; };
+    CostArgs<float> a;
+    a.T = T; a.chain = nullptr; a.n_links = h_chain.n_links; a.trajs = (const float*)samples;
+    a.batch = batch; a.batch_offset = batch_offset; a.spheres = (const float*)spheres; a.n_spheres = n_spheres;
+    a.isw = (const float*)isw; a.rows_per_particle = S; a.is_dt = (float)prior.dt;
+    a.costs = (float*)costs; a.costs64 = costs64;
+    a.rpp_shift = log2_exact(S);
+    a.rpg_shift = F.has_goal ? log2_exact(F.goal.rows_per_goal) : -1;
+    FusedArgs fs;
+    fs.coef = prior.iso32; fs.means = (const float*)means; fs.samples = (float*)samples;
+    fs.seed = seed; fs.draw = draw; fs.mode_offset = mode_offset; fs.S = S;
+    fs.gpp = S / SGPMP_FUSED_SPW; fs.gpp_shift = log2_exact(fs.gpp);
+    const long long nitems = batch / SGPMP_FUSED_SPW;
+    long long blocks = (nitems + 3) / 4;
+    // one item per wave measured fastest at config 3 (4096 workgroups 0.216 ms/iteration, 2048: 0.219,
+    // 1024: 0.227): the per-workgroup set-up is small and the hardware dispatcher balances better than
+    // a grid-stride loop; the loop stays for batches beyond 2^20 items and for the k3_blocks switch
+    long long cap = 1LL << 18;
+    if (tg.k3_blocks > 0) cap = tg.k3_blocks;
+    if (blocks > cap) blocks = cap;
+    const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
+    if (ft == SGPMP_FIELD_RBF)
+        hipLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_RBF>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);
+    else if (ft == SGPMP_FIELD_SDF)
+        hipLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_SDF>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);
+    else
+        hipLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_OCCUPANCY>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);
+    if (picked) *picked = "fused_step_kernel";
+    *launched = true;
+    return hipGetLastError();
+}
 
 template <typename real>
 static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const ChainDev* d_chain,

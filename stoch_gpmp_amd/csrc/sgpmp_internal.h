@@ -131,6 +131,13 @@ hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const
                        const void* is_weights, int rows_per_particle, double is_dt, void* costs,
                        double* costs64, hipStream_t stream, const SgpmpToggles& tg, const char** picked);
 
+// K2 + K3 fused (cost_sweep.hip / fused_step.inc): launches only when the step qualifies (*launched)
+hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
+                             const ChainDev& h_chain, uint64_t seed, uint64_t draw, const void* means, int P,
+                             int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
+                             const void* isw, void* costs, double* costs64, hipStream_t stream,
+                             const SgpmpToggles& tg, const char** picked, bool* launched);
+
 hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& prior, const void* means,
                              int n_particles, double temperature, void* out, double* zero_stats,
                              hipStream_t stream);

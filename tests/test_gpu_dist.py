@@ -120,5 +120,5 @@ def test_bench_single_rank_rccl_smoke():
     lines = p.stdout.strip().splitlines()
     assert len(lines) == 1, lines                       # stdout is the JSON line and nothing else
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 1 and "cost_sweep_dual_pf_kernel" in line["roofline"]["kernel"]
+    assert line["n_gpus"] == 1 and "fused_step_kernel" in line["roofline"]["kernel"]
     assert line["roofline"]["frac"] > 0 and line["last_iteration"]["mean_cost_sum"] > 0

@@ -195,7 +195,8 @@ def _is_dot(samples, w, n, dt):
     return (Ax * w.double().unsqueeze(1)).sum((-1, -2))
 
 
-def _fp32_panda_run(T, nppg, S, iters, goals=None, field_type='rbf', n_sph=5, seed=13, expect_kernel=None):
+def _fp32_panda_run(T, nppg, S, iters, goals=None, field_type='rbf', n_sph=5, seed=13, expect_kernel=None,
+                    fused=True):
     """Panda fp32 planner in its DEFAULT mode (in-kernel Philox noise) against the fp64 oracle driven by
     the CPU restatement of that stream.  Means are re-synchronised after every iteration so that each
     iteration is an independent trial of "does the fp32 path move every particle where the fp64
@@ -208,6 +209,8 @@ def _fp32_panda_run(T, nppg, S, iters, goals=None, field_type='rbf', n_sph=5, se
     eps0 = torch.from_numpy(native_eps(seed, 0, range(G), nppg, T, n, "float32")).double()
     ora = SC.oracle_panda_planner(c, T, nppg, S, seed=seed, eps_init=eps0, goals=goals, field_type=field_type)
     pl = hip_panda_planner(c, T, nppg, S, F32, seed=seed, goals=goals, field_type=field_type)
+    if not fused:
+        pl._engine.set_option("no_fused_step", 1)        # sampler and sweep as two launches
     assert rel_err(pl.particle_means, ora.particle_means) < 2e-5
     pl.particle_means.copy_(ora.particle_means.to(**F32))
     scale = float(ora.particle_means.abs().max())
@@ -248,30 +251,34 @@ def _report(tag, recs):
     return frac
 
 
-def test_panda_fp32_headline_kernel_means_match_fp64_oracle():
-    """north_star: fp32 trajectory means within 1e-3 of the reference CPU path.  The headline kernel
-    (cost_sweep_dual_pf_kernel: even S, even T <= 64, rbf) over 6 iterations, 48 particles, native
-    noise.  With temperature = 1 and costs of 1e9-1e11 the update is an arg-min over samples, so a
-    particle agrees unless fp32 flips the arg-min; the agreeing fraction is printed and bounded."""
-    recs = _fp32_panda_run(T=32, nppg=48, S=32, iters=6, expect_kernel="cost_sweep_dual_pf_kernel")
-    frac = _report("Panda 48x32x32 rbf (dual_pf)", recs)
+@pytest.mark.parametrize("fused,kernel", [(True, "fused_step_kernel"), (False, "cost_sweep_dual_pf_kernel")])
+def test_panda_fp32_headline_kernel_means_match_fp64_oracle(fused, kernel):
+    """north_star: fp32 trajectory means within 1e-3 of the reference CPU path.  The headline kernels
+    (the fused sampler + sweep launch, and cost_sweep_dual_pf_kernel behind the separate sampler: even
+    S, even T <= 64, rbf) over 6 iterations, 48 particles, native noise.  With temperature = 1 and
+    costs of 1e9-1e11 the update is an arg-min over samples, so a particle agrees unless fp32 flips
+    the arg-min; the agreeing fraction is printed and bounded."""
+    recs = _fp32_panda_run(T=32, nppg=48, S=32, iters=6, expect_kernel=kernel, fused=fused)
+    frac = _report(f"Panda 48x32x32 rbf ({kernel})", recs)
     assert max(r["cost_rel"] for r in recs) < 5e-3
     assert frac >= 0.99, frac                          # measured on MI355X: 1.0000 (arg-min identical for every particle)
 
 
-def test_panda_fp32_config5_kernel_means_match_fp64_oracle():
-    """BASELINE config 5 in its stated precision and in miniature: 2 goals, T = 128 (two passes of
-    cost_sweep_dual_pf_multi_kernel with the carried neighbour waypoint), fp64 prior + fp32 cost path,
-    GP + multi-goal prior + IS + self + sphere fields, against the fp64 oracle: costs and means."""
+@pytest.mark.parametrize("fused,kernel", [(True, "fused_step_kernel"), (False, "cost_sweep_dual_pf_multi_kernel")])
+def test_panda_fp32_config5_kernel_means_match_fp64_oracle(fused, kernel):
+    """BASELINE config 5 in its stated precision and in miniature: 2 goals, T = 128 (eight 16-waypoint
+    chunks of the fused launch / two passes of cost_sweep_dual_pf_multi_kernel with the carried
+    neighbour waypoint), fp64 prior + fp32 cost path, GP + multi-goal prior + IS + self + sphere fields,
+    against the fp64 oracle: costs and means."""
     n = 7
     goals = [SC.PANDA["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n]
-    recs = _fp32_panda_run(T=128, nppg=6, S=16, iters=4, goals=goals, n_sph=7,
-                           expect_kernel="cost_sweep_dual_pf_multi_kernel")
-    frac = _report("Panda 2 goals x 6 x 16 x 128 rbf (dual_pf_multi)", recs)
+    recs = _fp32_panda_run(T=128, nppg=6, S=16, iters=4, goals=goals, n_sph=7, expect_kernel=kernel, fused=fused)
+    frac = _report(f"Panda 2 goals x 6 x 16 x 128 rbf ({kernel})", recs)
     assert max(r["cost_rel"] for r in recs) < 5e-3
     assert frac >= 0.99, frac                          # measured: 1.0000
+    # T = 66 is not a multiple of the fused launch's 16-waypoint chunk: always the two-launch path
     recs = _fp32_panda_run(T=66, nppg=6, S=16, iters=3, goals=goals, n_sph=7, field_type='sdf',
-                           expect_kernel="cost_sweep_dual_pf_multi_kernel")
+                           expect_kernel="cost_sweep_dual_pf_multi_kernel", fused=fused)
     frac = _report("Panda 2 goals x 6 x 16 x 66 sdf (dual_pf_multi)", recs)
     assert max(r["cost_rel"] for r in recs) < 5e-3 and frac >= 0.99
 
@@ -336,6 +343,40 @@ def test_api_surface_and_errors(golden):
     before = p2.particle_means.clone()
     out = p2.optimize(opt_iters=2)
     assert out[4].shape == (2, 4) and not torch.equal(before, p2.particle_means)
+
+
+# --------------------------------------------------------------------------- fused sampler + sweep launch
+@pytest.mark.parametrize("nppg,G,S,T,field_type,n_sph,fused", [
+    (3, 1, 8, 16, "rbf", 5, True),            # smallest: one item per particle, one chunk
+    (3, 2, 24, 48, "sdf", 9, True),           # two goals, three items per particle (not a power of two), three chunks
+    (5, 1, 16, 32, "occupancy", 1, True),
+    (2, 1, 8, 80, "rbf", 32, True),           # five chunks, the sphere-staging limit of the fused launch
+    (2, 1, 8, 32, "rbf", 33, False),          # one sphere too many -> sampler + two-trajectory sweep
+    (2, 1, 12, 32, "rbf", 5, False),          # S not a multiple of 8
+    (2, 1, 8, 24, "rbf", 5, False),           # T not a multiple of 16
+])
+def test_fused_step_corners_match_the_two_launch_path(nppg, G, S, T, field_type, n_sph, fused):
+    """sgpmp_step's fused launch (fused_step.inc) against the same step as sampler + sweep: identical
+    noise keys, so the samples agree to the last bit or two (the two samplers order one fused
+    multiply-add differently at tiny sizes) and the costs to fp32 rounding; the dispatcher's choice
+    is asserted for every corner, including the fall-backs."""
+    c, n = SC.PANDA, 7
+    goals = None if G == 1 else [c["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n][:G]
+    sph = torch.as_tensor(SC.panda_spheres(num=n_sph, seed=3)).to(**F32)
+    a = hip_panda_planner(c, T, nppg, S, F32, field_type=field_type, seed=17, goals=goals)
+    b = hip_panda_planner(c, T, nppg, S, F32, field_type=field_type, seed=17, goals=goals)
+    b._engine.set_option("no_fused_step", 1)
+    for it in range(3):
+        a.optimize(obstacle_spheres=sph)
+        b.optimize(obstacle_spheres=sph)
+        assert (a._engine.last_cost_kernel() == "fused_step_kernel") == fused, a._engine.last_cost_kernel()
+        assert b._engine.last_cost_kernel() != "fused_step_kernel"
+        scale = float(b.state_samples.abs().max())
+        assert float((a.state_samples - b.state_samples).abs().max()) <= 4e-7 * scale
+        assert rel_err(a._costs, b._costs) < 2e-5
+        assert torch.equal(a._costs.argmin(1), b._costs.argmin(1))
+        assert float((a.particle_means - b.particle_means).abs().max()) <= 1e-6 * scale
+        b.particle_means.copy_(a.particle_means)
 
 
 # --------------------------------------------------------------------------- live observations / edits
@@ -488,7 +529,7 @@ def test_config4_eight_shards_equal_unsharded_bitwise():
     for _ in range(2):
         full.optimize(obstacle_spheres=sph)
     full_means, full_costs = full.particle_means.clone(), full._costs.clone()
-    assert full._engine.last_cost_kernel() == "cost_sweep_dual_pf_kernel"
+    assert full._engine.last_cost_kernel() == "fused_step_kernel"
     stats_full = full._stats[full._stats_slot ^ 1].sum(0).cpu()
     del full
     torch.cuda.empty_cache()
@@ -521,18 +562,23 @@ def test_config5_share_fast_sweep_equals_generic_sweep(field_type):
     pl = hip_panda_planner(c, T, 1024, S, F32, field_type=field_type, seed=9, goals=goals, rank=3, world_size=8)
     assert pl.num_particles == 4096 and pl.num_particles_local == 512 and pl.p0 == 1536
     pl.optimize(obstacle_spheres=sph)
-    assert pl._engine.last_cost_kernel() == "cost_sweep_dual_pf_multi_kernel"
+    assert pl._engine.last_cost_kernel() == "fused_step_kernel"
+    step_costs = pl._costs.clone()                           # what the fused launch computed for its own samples
     samples = pl.state_samples
-    w = pl._engine.is_weights(pl.particle_means, pl.temperature)
+    w = pl._engine.is_weights(pl._means_prev, pl.temperature)     # weights of the PRE-update means, as in the step
     sphc = sph.reshape(-1, 4).contiguous()
     kw = dict(batch_offset=pl.p0 * S, spheres=sphc, is_weights=w, rows_per_particle=S)
     fast = pl._engine.cost_eval(samples, **kw).clone()
+    assert pl._engine.last_cost_kernel() == "cost_sweep_dual_pf_multi_kernel"
     pl._engine.set_option("no_dual_sweep", 1)
     pl._engine.set_option("force_generic_fk", 1)
     slow = pl._engine.cost_eval(samples, **kw)
     assert pl._engine.last_cost_kernel() == "cost_sweep_kernel<f32, generic FK>"
     rel = ((fast.double() - slow.double()).abs() / slow.double().abs().clamp_min(1.0)).max()
     assert fast.shape == (512 * S,) and bool(torch.isfinite(fast).all()) and float(rel) < 2e-5, float(rel)
+    # ... and the fused launch (sampler + sweep in one kernel) agrees with both on every trajectory
+    rel = ((step_costs.reshape(-1).double() - slow.double()).abs() / slow.double().abs().clamp_min(1.0)).max()
+    assert float(rel) < 2e-5, float(rel)
 
 
 def test_full_size_planar_fused_step_equals_separate_calls(golden):
@@ -565,8 +611,10 @@ def test_full_size_fast_sweep_equals_generic_sweep(field_type):
     sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
     pl = hip_panda_planner(c, T, P, S, F32, field_type=field_type, seed=9)
     pl.optimize(obstacle_spheres=sph)
+    assert pl._engine.last_cost_kernel() == "fused_step_kernel"
+    step_costs = pl._costs.clone()
     samples = pl.state_samples
-    w = pl._engine.is_weights(pl.particle_means, pl.temperature)
+    w = pl._engine.is_weights(pl._means_prev, pl.temperature)     # weights of the PRE-update means, as in the step
     sphc = sph.reshape(-1, 4).contiguous()
     fast = pl._engine.cost_eval(samples, spheres=sphc, is_weights=w, rows_per_particle=S).clone()
     assert pl._engine.last_cost_kernel() == "cost_sweep_dual_pf_kernel"
@@ -577,7 +625,10 @@ def test_full_size_fast_sweep_equals_generic_sweep(field_type):
     assert fast.shape == (P * S,) and bool(torch.isfinite(fast).all())
     rel = ((fast.double() - slow.double()).abs() / slow.double().abs().clamp_min(1.0)).max()
     assert float(rel) < 2e-5, float(rel)
-    # the costs of the planner's own iteration are the fast kernel's
+    # the fused launch of the planner's own iteration: same samples, same costs
+    rel = ((step_costs.reshape(-1).double() - slow.double()).abs() / slow.double().abs().clamp_min(1.0)).max()
+    assert float(rel) < 2e-5, float(rel)
+    # a second evaluation reproduces the fast kernel's costs bit for bit
     pl._engine.set_option("no_dual_sweep", 0)
     pl._engine.set_option("force_generic_fk", 0)
     again = pl._engine.cost_eval(samples, spheres=sphc, is_weights=w, rows_per_particle=S)
