@@ -135,9 +135,29 @@ const char* sgpmp_last_cost_kernel(sgpmp_ctx* ctx);
 int sgpmp_set_prior(sgpmp_ctx* ctx, int which, double dt, double sigma_start, double sigma_gp,
                     double sigma_goal, const double* qc_inv, void* stream);
 
+/* MultiMPPrior.set_Sigma_invs (mp_priors_multi.py:125-128): one precision matrix PER MODE, given by its
+ * blocks -- D HOST double[n_modes][T][d][d] (diagonal blocks), E HOST double[n_modes][T-1][d][d] with
+ * E[m][t] = Sigma_m^-1[t+1-block, t-block]; anything outside the block-tridiagonal band must be zero
+ * (the caller checks).  K1 factors every mode (one workgroup each, fp64 MFMA); sgpmp_sample then uses
+ * mode m's factor for mean m, sgpmp_prior_quadform its precision.  The planner loop (sgpmp_step,
+ * sgpmp_is_weights) keeps requiring the shared closed-form prior of sgpmp_set_prior.
+ * Synchronous; SGPMP_ENOTPD when a matrix is not positive definite. */
+int sgpmp_set_prior_blocks(sgpmp_ctx* ctx, int which, int n_modes, const double* D, const double* E,
+                           void* stream);
+
+/* MultiMPPrior.log_prob (mp_priors_multi.py:209-210 -> torch MultivariateNormal.log_prob): the quadratic
+ * forms q_r = (x_r - mu_m)^T Sigma_m^-1 (x_r - mu_m), m = r % n_modes, for x DEVICE [rows, T*d] and
+ * means DEVICE [n_modes, T*d] in ctx dtype -> out DEVICE double[rows]  (log_prob = -q/2 - M/2 log 2pi
+ * + 1/2 log det Sigma_m^-1; the log-determinant is a by-product of K1's factor, see sgpmp_get_prior). */
+int sgpmp_prior_quadform(sgpmp_ctx* ctx, int which, const void* x, int64_t rows, const void* means,
+                         int n_modes, double* out, void* stream);
+
 /* Test/inspection hook: copy K1's outputs to HOST buffers (any may be NULL). Synchronous.
  *   blocks  double[4*d*d]  D_0, D_interior, D_last, E = Sigma_inv[(i+1)-block, i-block]
- *   G, H    double[T*d*d]  scan coefficients:  y_t = G_t eps_t + H_t y_{t-1}  (= scale_tril @ eps) */
+ *   G, H    double[T*d*d]  scan coefficients:  y_t = G_t eps_t + H_t y_{t-1}  (= scale_tril @ eps);
+ *           after sgpmp_set_prior_blocks: double[n_modes*T*d*d] and `blocks` is not written.
+ *   G_t = B_t^-1 is lower triangular and Sigma^-1 = L_inv^T L_inv with diag blocks B_t, so
+ *   log det Sigma^-1 = -2 sum_t sum_i log G_t[i][i]. */
 int sgpmp_get_prior(sgpmp_ctx* ctx, int which, double* blocks, double* G, double* H);
 
 /* CostComposite(cost_list, FK) compiled to a device cost program (cost_functions.py:34-58). */

@@ -59,6 +59,8 @@ SIGNATURES = {
     "sgpmp_last_cost_kernel": (C.c_char_p, [_P]),
     "sgpmp_set_prior": (_I, [_P, _I, _D, _D, _D, _D, C.POINTER(_D), _P]),
     "sgpmp_get_prior": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
+    "sgpmp_set_prior_blocks": (_I, [_P, _I, _I, C.POINTER(_D), C.POINTER(_D), _P]),
+    "sgpmp_prior_quadform": (_I, [_P, _I, _P, _I64, _P, _I, _P, _P]),
     "sgpmp_set_costs": (_I, [_P, C.POINTER(CostDesc), _I]),
     "sgpmp_set_fk": (_I, [_P, C.POINTER(Joint), _I]),
     "sgpmp_sample": (_I, [_P, _I, _U64, _U64, _P, _I, _I, _I, _P, _I, _I, _P, _P]),

@@ -8,8 +8,8 @@ blocks K1 emits once, `set_mean` only swaps the mean pointer, and `sample` is th
 """
 import torch
 
-from .. import _lib as L
-from ..engine import Engine
+from ... import _lib as L
+from ...engine import Engine
 
 
 class MultiMPPrior:
@@ -41,6 +41,8 @@ class MultiMPPrior:
             self._engine.set_prior(L.PRIOR_SAMPLE, dt, sigma_start, None, sigma_goal, Q_c_inv=qc)
         self._seed, self._draw = seed, 0
         self._Sigma_inv = None
+        self._Sigma_invs = None          # per-mode precisions after set_Sigma_invs
+        self._logdet = None              # log det Sigma_m^-1 per mode (from K1's factor)
 
     # ---- reference API
     @property
@@ -59,6 +61,8 @@ class MultiMPPrior:
 
     @property
     def Sigma_invs(self):
+        if self._Sigma_invs is not None:
+            return self._Sigma_invs
         return self.Sigma_inv.unsqueeze(0).expand(self.num_modes, -1, -1)
 
     def get_mean(self, reshape=True):
@@ -71,8 +75,30 @@ class MultiMPPrior:
         self.means = means_new.clone().detach().contiguous()
 
     def set_Sigma_invs(self, Sigma_invs_new):
-        raise NotImplementedError("per-mode covariance adaptation has no caller in the reference "
-                                  "(mp_priors_multi.py:125-128) and is not built")
+        """mp_priors_multi.py:125-128: one precision matrix per mode.  The reference hands the dense
+        [modes,M,M] tensor to torch's MultivariateNormal (a dense Cholesky per mode); here K1 factors each
+        matrix on its block-tridiagonal structure (d x d blocks), which is what every trajectory prior of
+        this family has -- a matrix with weight outside that band is refused with ValueError, and so is
+        one that is not symmetric positive definite (torch raises ValueError there too)."""
+        assert Sigma_invs_new.shape == self.Sigma_invs.shape
+        new = Sigma_invs_new.clone().detach()
+        d, T, modes = self.state_dim, self.num_steps + 1, self.num_modes
+        S = new.double().cpu().reshape(modes, T, d, T, d).permute(0, 1, 3, 2, 4)        # [m, ti, tj, d, d]
+        idx = torch.arange(T)
+        D = S[:, idx, idx]                                                               # [m, T, d, d]
+        E = S[:, idx[1:], idx[:-1]]                                                      # [m, T-1, d, d]
+        band = torch.zeros(T, T, dtype=torch.bool)
+        band[idx, idx] = True
+        band[idx[1:], idx[:-1]] = True
+        band[idx[:-1], idx[1:]] = True
+        scale = float(S.abs().max())
+        if float(S[:, ~band].abs().max() if T > 2 else 0.) > 1e-12 * scale:
+            raise ValueError("set_Sigma_invs: precision matrices must be block tridiagonal in the d x d waypoint blocks")
+        if float((S - S.permute(0, 2, 1, 4, 3)).abs().max()) > 1e-9 * scale:
+            raise ValueError("set_Sigma_invs: precision matrices must be symmetric")
+        self._engine.set_prior_blocks(L.PRIOR_SAMPLE, D, E)                              # ValueError if not PD
+        self._Sigma_invs = new
+        self._logdet = None
 
     def const_vel_trajectory(self, start_state, goal_state, dt, num_steps, dof):
         traj = torch.zeros(num_steps + 1, 2 * dof, **self.tensor_args)
@@ -96,5 +122,26 @@ class MultiMPPrior:
         self._draw += 1
         return out
 
+    def _log_dets(self):
+        """log det Sigma_m^-1 per mode from K1's factor: Sigma^-1 = L_inv^T L_inv with lower-triangular
+        diagonal blocks B_t, and K1 emits G_t = B_t^-1."""
+        if self._logdet is None:
+            per_mode = self._Sigma_invs is not None
+            _, G, _ = self._engine.get_prior(L.PRIOR_SAMPLE, n_modes=self.num_modes if per_mode else None)
+            G = G.reshape(-1, self.num_steps + 1, self.state_dim, self.state_dim)
+            ld = -2. * torch.log(torch.diagonal(G, dim1=-2, dim2=-1)).sum((-1, -2))       # [modes] or [1]
+            self._logdet = ld.expand(self.num_modes).clone()
+        return self._logdet
+
     def log_prob(self, x):
-        raise NotImplementedError("log_prob is not on the StochGPMP path")
+        """mp_priors_multi.py:209-210 -> torch MultivariateNormal.log_prob: x [..., modes, M] -> [..., modes]
+        = -1/2 (x - mu)^T Sigma^-1 (x - mu) - M/2 log(2 pi) + 1/2 log det Sigma^-1, with the quadratic form
+        evaluated on the block-tridiagonal precision by `prior_quadform_kernel` (fp64 accumulation)."""
+        import math
+        assert x.shape[-1] == self.M and x.shape[-2] == self.num_modes
+        lead = x.shape[:-1]
+        xr = x.reshape(-1, self.M).to(**self.tensor_args).contiguous()
+        q = self._engine.prior_quadform(L.PRIOR_SAMPLE, xr, self.means)
+        ld = self._log_dets().to(q.device)
+        out = -0.5 * q.reshape(-1, self.num_modes) - 0.5 * self.M * math.log(2. * math.pi) + 0.5 * ld
+        return out.reshape(lead).to(self.tensor_args['dtype'])

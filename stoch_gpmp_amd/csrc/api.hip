@@ -95,7 +95,7 @@ static int alloc_prior(sgpmp_ctx* c, PriorDev& p) {
 
 static void free_prior(PriorDev& p) {
     hipFree(p.blocks); hipFree(p.G); hipFree(p.H); hipFree(p.iso64); hipFree(p.iso32);
-    hipFree(p.Qinv); hipFree(p.G32); hipFree(p.H32); hipFree(p.status);
+    hipFree(p.Qinv); hipFree(p.G32); hipFree(p.H32); hipFree(p.status); hipFree(p.Dm); hipFree(p.Em);
     std::memset(&p, 0, sizeof(p));
 }
 
@@ -233,6 +233,7 @@ extern "C" int sgpmp_set_prior(sgpmp_ctx* c, int which, double dt, double sigma_
     p.dt = dt;
     p.isotropic = qc_inv ? 0 : 1;
     p.valid = 0;
+    p.n_factor_modes = 0;                                        // back to one shared closed-form factor
     HIPCHK(launch_prior_factor(n, c->dims.traj_len, dt, p.ks, p.kg, c->d_qc, p.isotropic, p, st));
     int status = 0;
     HIPCHK(hipMemcpyAsync(&status, p.status, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -243,15 +244,65 @@ extern "C" int sgpmp_set_prior(sgpmp_ctx* c, int which, double dt, double sigma_
     return SGPMP_OK;
 }
 
+// MultiMPPrior.set_Sigma_invs (mp_priors_multi.py:125-128): per-mode block-tridiagonal precisions.
+extern "C" int sgpmp_set_prior_blocks(sgpmp_ctx* c, int which, int n_modes, const double* D, const double* E,
+                                      void* stream) {
+    if (!c || (which != 0 && which != 1) || n_modes < 1 || !D || (c->dims.traj_len > 1 && !E))
+        return fail(SGPMP_EINVAL, "sgpmp_set_prior_blocks: bad argument");
+    const int n = c->dims.n_dof, T = c->dims.traj_len;
+    const size_t dd = (size_t)c->d * c->d, nD = (size_t)n_modes * T * dd, nE = (size_t)n_modes * (T - 1) * dd;
+    hipStream_t st = (hipStream_t)stream;
+    PriorDev& p = c->prior[which];
+    p.valid = 0;
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(p.G); hipFree(p.H); hipFree(p.G32); hipFree(p.H32); hipFree(p.Dm); hipFree(p.Em);
+    p.G = p.H = p.Dm = p.Em = nullptr; p.G32 = p.H32 = nullptr;
+    HIPCHK(hipMalloc(&p.G, sizeof(double) * nD));
+    HIPCHK(hipMalloc(&p.H, sizeof(double) * nD));
+    HIPCHK(hipMalloc(&p.G32, sizeof(float) * nD));
+    HIPCHK(hipMalloc(&p.H32, sizeof(float) * nD));
+    HIPCHK(hipMalloc(&p.Dm, sizeof(double) * nD));
+    HIPCHK(hipMalloc(&p.Em, sizeof(double) * (nE ? nE : 1)));
+    HIPCHK(hipMemcpyAsync(p.Dm, D, sizeof(double) * nD, hipMemcpyHostToDevice, st));
+    if (nE) HIPCHK(hipMemcpyAsync(p.Em, E, sizeof(double) * nE, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(p.status, 0, sizeof(int), st));
+    p.isotropic = 0;
+    p.n_factor_modes = n_modes;
+    HIPCHK(launch_prior_factor_blocks(n, T, n_modes, p.Dm, p.Em, p, st));
+    int status = 0;
+    HIPCHK(hipMemcpyAsync(&status, p.status, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (status != 0)
+        return fail(SGPMP_ENOTPD, "sgpmp_set_prior_blocks: a precision matrix is not positive definite");
+    p.valid = 1;
+    return SGPMP_OK;
+}
+
+// Quadratic forms (x_r - mu_m)^T Sigma_m^-1 (x_r - mu_m), m = r % n_modes, for MultiMPPrior.log_prob.
+extern "C" int sgpmp_prior_quadform(sgpmp_ctx* c, int which, const void* x, int64_t rows, const void* means,
+                                    int n_modes, double* out, void* stream) {
+    if (!c || (which != 0 && which != 1) || rows < 0 || n_modes < 1 || (rows > 0 && (!x || !means || !out)))
+        return fail(SGPMP_EINVAL, "sgpmp_prior_quadform: bad argument");
+    const PriorDev& p = c->prior[which];
+    if (!p.valid) return fail(SGPMP_ESTATE, "sgpmp_prior_quadform: prior not set");
+    if (p.n_factor_modes > 0 && n_modes > p.n_factor_modes)
+        return fail(SGPMP_EINVAL, "sgpmp_prior_quadform: more modes than precision matrices");
+    HIPCHK(launch_prior_quadform(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, rows, n_modes, x, means, p, out,
+                                 (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
 extern "C" int sgpmp_get_prior(sgpmp_ctx* c, int which, double* blocks, double* G, double* H) {
     if (!c || (which != 0 && which != 1)) return fail(SGPMP_EINVAL, "sgpmp_get_prior: bad argument");
     const PriorDev& p = c->prior[which];
     if (!p.valid) return fail(SGPMP_ESTATE, "sgpmp_get_prior: prior not set");
     const size_t dd = (size_t)c->d * c->d, T = c->dims.traj_len;
+    const size_t modes = p.n_factor_modes > 0 ? p.n_factor_modes : 1;     // per-mode factors: [modes][T][d][d]
     HIPCHK(hipDeviceSynchronize());
-    if (blocks) HIPCHK(hipMemcpy(blocks, p.blocks, sizeof(double) * 4 * dd, hipMemcpyDeviceToHost));
-    if (G) HIPCHK(hipMemcpy(G, p.G, sizeof(double) * T * dd, hipMemcpyDeviceToHost));
-    if (H) HIPCHK(hipMemcpy(H, p.H, sizeof(double) * T * dd, hipMemcpyDeviceToHost));
+    if (blocks && p.n_factor_modes == 0)
+        HIPCHK(hipMemcpy(blocks, p.blocks, sizeof(double) * 4 * dd, hipMemcpyDeviceToHost));
+    if (G) HIPCHK(hipMemcpy(G, p.G, sizeof(double) * modes * T * dd, hipMemcpyDeviceToHost));
+    if (H) HIPCHK(hipMemcpy(H, p.H, sizeof(double) * modes * T * dd, hipMemcpyDeviceToHost));
     return SGPMP_OK;
 }
 
@@ -573,6 +624,8 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
                           double step_size, double* stats, void* stream) {
     if (!c || !means || !samples) return fail(SGPMP_EINVAL, "sgpmp_step: null argument");
     if (!c->prior[SGPMP_PRIOR_SAMPLE].valid) return fail(SGPMP_ESTATE, "sgpmp_step: sampling prior not set");
+    if (c->prior[SGPMP_PRIOR_SAMPLE].n_factor_modes > 0)
+        return fail(SGPMP_ESTATE, "sgpmp_step: per-mode precisions (sgpmp_set_prior_blocks) are for sampling / log_prob only");
     if (!(temperature > 0.)) return fail(SGPMP_EINVAL, "sgpmp_step: temperature must be positive");
     int rc;
     if ((rc = finalize_program(c)) != SGPMP_OK) return rc;
@@ -591,9 +644,12 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         HIPCHK(hipEventRecord(se->ev[0], st));
     }
     const PriorDev& pr = c->prior[SGPMP_PRIOR_SAMPLE];
-    // (K5 zeroes `stats`: an all-reduce of an earlier step may still be reading it on the side stream)
-    if (c->comm && stats) COMMCHK(comm_stats_wait(c->comm, stats, st));
-    HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, means, P, temperature, c->d_isw, stats, st));
+    // multi-GPU: the step's statistics accumulate in a context-owned ring slot; their all-reduce (side
+    // stream, enqueued at the end of the step) writes the sums over all ranks into the caller's `stats`
+    double* acc_stats = stats;
+    hipEvent_t k4_done = nullptr;
+    if (c->comm && stats) COMMCHK(comm_step_begin(c->comm, st, &acc_stats, &k4_done));
+    HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, means, P, temperature, c->d_isw, acc_stats, st));
     if (se) HIPCHK(hipEventRecord(se->ev[1], st));
     // K2 + K3: one fused launch when the step qualifies (in-kernel noise, fp32 Panda-type program), else
     // the sampler followed by the sweep
@@ -618,10 +674,10 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     }
     if (se) HIPCHK(hipEventRecord(se->ev[3], st));
     HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
-                         temperature, step_size, weights, grad, means_prev, stats, st));
+                         temperature, step_size, weights, grad, means_prev, acc_stats, st, k4_done));
     if (se) HIPCHK(hipEventRecord(se->ev[4], st));
     // multi-GPU: sum the statistics over all ranks on the side stream (never gates the next step)
-    if (c->comm && stats) COMMCHK(comm_allreduce_stats(c->comm, stats, st));
+    if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats));
     return SGPMP_OK;
 }
 

@@ -54,13 +54,26 @@ static const char* load_rccl() {
     return nullptr;
 }
 
+#define SGPMP_COMM_RING 8
 struct SgpmpComm {
     ncclComm_t comm;
     int rank, world;
     hipStream_t side;                                        // the all-reduce runs here
     hipEvent_t produced;                                     // main stream: statistics complete
     std::vector<std::pair<double*, hipEvent_t>> reduced;     // per statistics buffer: all-reduce complete
+    // sgpmp_step's own statistics: K4 accumulates into a context-owned ring slot, the all-reduce reads the
+    // slot and writes the caller's buffer.  A slot comes round again SGPMP_COMM_RING steps later, so the
+    // check that its all-reduce has finished is a host-side event query (practically always true) and the
+    // main stream carries no wait; the "statistics complete" event rides on K4's own dispatch packet.
+    double* ring;                                            // [SGPMP_COMM_RING][SGPMP_STAT_SHARDS][4]
+    hipEvent_t ring_produced[SGPMP_COMM_RING], ring_reduced[SGPMP_COMM_RING];
+    bool ring_used[SGPMP_COMM_RING];
+    unsigned long long step;
 };
+
+// The events only ever order streams of this device (hipStreamWaitEvent), never the host: a device-scope
+// release is enough and spares the system-scope cache flush of a default event record.
+static const unsigned kEventFlags = hipEventDisableTiming | hipEventReleaseToDevice;
 
 static hipEvent_t* reduced_event(SgpmpComm* c, double* stats, bool create) {
     for (auto& p : c->reduced)
@@ -71,7 +84,7 @@ static hipEvent_t* reduced_event(SgpmpComm* c, double* stats, bool create) {
         c->reduced.clear();
     }
     hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e, kEventFlags) != hipSuccess) return nullptr;
     c->reduced.emplace_back(stats, e);
     return &c->reduced.back().second;
 }
@@ -93,11 +106,19 @@ const char* comm_create(const unsigned char* id128, int world, int rank, SgpmpCo
     c->rank = rank; c->world = world; c->comm = nullptr;
     const ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
     if (r != ncclSuccess) { delete c; return g_rccl.GetErrorString(r); }
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->produced, hipEventDisableTiming) != hipSuccess) {
+    bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->produced, kEventFlags) == hipSuccess &&
+              hipMalloc(&c->ring, sizeof(double) * SGPMP_COMM_RING * SGPMP_STAT_SHARDS * 4) == hipSuccess;
+    for (int i = 0; ok && i < SGPMP_COMM_RING; ++i) {
+        ok = hipEventCreateWithFlags(&c->ring_produced[i], kEventFlags) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ring_reduced[i], kEventFlags) == hipSuccess;
+        c->ring_used[i] = false;
+    }
+    c->step = 0;
+    if (!ok) {
         g_rccl.CommDestroy(c->comm);
         delete c;
-        return "comm_create: cannot create the side stream / event";
+        return "comm_create: cannot create the side stream / events / ring";
     }
     *out = c;
     return nullptr;
@@ -108,6 +129,8 @@ void comm_destroy(SgpmpComm* c) {
     hipStreamSynchronize(c->side);
     for (auto& p : c->reduced) hipEventDestroy(p.second);
     hipEventDestroy(c->produced);
+    for (int i = 0; i < SGPMP_COMM_RING; ++i) { hipEventDestroy(c->ring_produced[i]); hipEventDestroy(c->ring_reduced[i]); }
+    hipFree(c->ring);
     hipStreamDestroy(c->side);
     if (c->comm) g_rccl.CommDestroy(c->comm);
     delete c;
@@ -129,12 +152,44 @@ const char* comm_allreduce_stats(SgpmpComm* c, double* stats, hipStream_t stream
     return nullptr;
 }
 
+// ---- the per-step path of sgpmp_step ------------------------------------------------------------------
+// Begin a step: the ring slot K5 will zero and K4 will accumulate into, and the event to attach to K4's
+// dispatch.  If the slot's previous all-reduce (SGPMP_COMM_RING steps ago) were still running, `stream`
+// is made to wait for it -- never observed, the query is the common path.
+const char* comm_step_begin(SgpmpComm* c, hipStream_t stream, double** slot, hipEvent_t* k4_done) {
+    const int r = (int)(c->step % SGPMP_COMM_RING);
+    if (c->ring_used[r] && hipEventQuery(c->ring_reduced[r]) != hipSuccess)
+        if (hipStreamWaitEvent(stream, c->ring_reduced[r], 0) != hipSuccess) return "hipStreamWaitEvent failed";
+    *slot = c->ring + (size_t)r * SGPMP_STAT_SHARDS * 4;
+    *k4_done = c->ring_produced[r];
+    return nullptr;
+}
+
+// End a step (K4 launched with ring_produced[r] as its stop event): sum the slot over all ranks into the
+// caller's `stats` on the side stream.
+const char* comm_step_end(SgpmpComm* c, double* stats) {
+    const int r = (int)(c->step % SGPMP_COMM_RING);
+    if (hipStreamWaitEvent(c->side, c->ring_produced[r], 0) != hipSuccess) return "hipStreamWaitEvent failed";
+    const ncclResult_t rc = g_rccl.AllReduce(c->ring + (size_t)r * SGPMP_STAT_SHARDS * 4, stats,
+                                             (size_t)SGPMP_STAT_SHARDS * 4, ncclDouble, ncclSum, c->comm, c->side);
+    if (rc != ncclSuccess) return g_rccl.GetErrorString(rc);
+    if (hipEventRecord(c->ring_reduced[r], c->side) != hipSuccess) return "hipEventRecord failed";
+    c->ring_used[r] = true;
+    ++c->step;
+    return nullptr;
+}
+
 // Before `stream` touches `stats` again (K5 zeroes it; a reader copies it): wait -- on the stream, not
 // on the host -- for the all-reduce that may still be using it.  stats == NULL: every pending one.
 const char* comm_stats_wait(SgpmpComm* c, double* stats, hipStream_t stream) {
     for (auto& p : c->reduced)
         if (!stats || p.first == stats)
             if (hipStreamWaitEvent(stream, p.second, 0) != hipSuccess) return "hipStreamWaitEvent failed";
+    // the steps' own all-reduces complete in order on the side stream: the newest one covers them all
+    if (c->step > 0) {
+        const int r = (int)((c->step - 1) % SGPMP_COMM_RING);
+        if (hipStreamWaitEvent(stream, c->ring_reduced[r], 0) != hipSuccess) return "hipStreamWaitEvent failed";
+    }
     return nullptr;
 }
 

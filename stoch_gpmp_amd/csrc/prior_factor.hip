@@ -49,9 +49,13 @@ __device__ __forceinline__ void mm16(double* C, const double* A, const double* B
     __syncthreads();
 }
 
+// Dblk / Eblk non-null: PER-MODE precisions given by their blocks (MultiMPPrior.set_Sigma_invs,
+// mp_priors_multi.py:125-128): workgroup m factors the block-tridiagonal matrix with diagonal blocks
+// Dblk[m][t] and sub-diagonal blocks Eblk[m][t] = Sigma_m^-1[t+1, t]; outputs are indexed [m][t].
 __global__ void __launch_bounds__(64)
 prior_factor_kernel(int n, int T, double c11, double c12, double c22, double dt, double ks, double kg,
-                    const double* __restrict__ qc_inv, int isotropic, PriorDev out) {
+                    const double* __restrict__ qc_inv, int isotropic, const double* __restrict__ Dblk,
+                    const double* __restrict__ Eblk, PriorDev out) {
     __shared__ double Phi[TS * TS], Qi[TS * TS], W[TS * TS], PQP[TS * TS];
     __shared__ double Dm[TS * TS], S[TS * TS], B[TS * TS], C[TS * TS], G[TS * TS], Hh[TS * TS];
     __shared__ double tmp[TS];
@@ -59,12 +63,26 @@ prior_factor_kernel(int n, int T, double c11, double c12, double c22, double dt,
     const int l = threadIdx.x;
     const int d = 2 * n;
     if (l == 0) bad = 0;
+    const bool given = Dblk != nullptr;
+    const size_t mode = blockIdx.x;
+    if (given) {
+        Dblk += mode * (size_t)T * d * d;
+        Eblk += mode * (size_t)(T > 1 ? T - 1 : 0) * d * d;
+        out.G += mode * (size_t)T * d * d; out.H += mode * (size_t)T * d * d;
+        out.G32 += mode * (size_t)T * d * d; out.H32 += mode * (size_t)T * d * d;
+    }
+    auto load_block = [&](double* dst, const double* src) {      // [d][d] global -> zero-padded 16x16 LDS tile
+        for (int e = l; e < TS * TS; e += 64) {
+            const int r = e / TS, c = e % TS;
+            dst[e] = (r < d && c < d) ? src[r * d + c] : 0.;
+        }
+    };
 
     // ---- assemble Phi and Q^-1 (gp_factor.py:36-52), zero padded to 16x16
     for (int e = l; e < TS * TS; e += 64) {
         const int r = e / TS, c = e % TS;
         double phi = 0., q = 0.;
-        if (r < d && c < d) {
+        if (!given && r < d && c < d) {
             phi = (r == c) ? 1. : 0.;
             if (r < n && c == r + n) phi = dt;
             const double qc = qc_inv[(r % n) * n + (c % n)];
@@ -80,7 +98,7 @@ prior_factor_kernel(int n, int T, double c11, double c12, double c22, double dt,
     mm16(PQP, Phi, W, true, false, 1., nullptr, 0.);        // Phi^T Q^-1 Phi
 
     // ---- the four distinct blocks of Sigma^-1 (mp_priors_multi.py:170-202, closed form)
-    for (int e = l; e < d * d; e += 64) {
+    for (int e = l; e < (given ? 0 : d * d); e += 64) {
         const int r = e / d, c = e % d;
         const double eye = (r == c) ? 1. : 0.;
         const double pqp = PQP[r * TS + c], q = Qi[r * TS + c];
@@ -104,6 +122,7 @@ prior_factor_kernel(int n, int T, double c11, double c12, double c22, double dt,
         S[e] = v;
     }
     __syncthreads();
+    if (given) { load_block(S, Dblk + (size_t)(T - 1) * d * d); __syncthreads(); }
 
     for (int t = T - 1; t >= 0; --t) {
         // ---- reverse Cholesky: B lower triangular with B^T B = S
@@ -132,6 +151,7 @@ prior_factor_kernel(int n, int T, double c11, double c12, double c22, double dt,
             __syncthreads();
         }
         if (t >= 1) {
+            if (given) { load_block(W, Eblk + (size_t)(t - 1) * d * d); __syncthreads(); }
             // ---- C = B^-T E (back substitution on the upper-triangular B^T)
             for (int i = d - 1; i >= 0; --i) {
                 if (l < d) {
@@ -155,7 +175,7 @@ prior_factor_kernel(int n, int T, double c11, double c12, double c22, double dt,
             out.G32[(size_t)t * d * d + e] = (float)g;
             out.H32[(size_t)t * d * d + e] = (float)h;
         }
-        if (l < 8) {
+        if (l < 8 && !given) {
             double v = 0.;
             switch (l) {
                 case 0: v = G[0]; break;                 // g11
@@ -182,10 +202,11 @@ prior_factor_kernel(int n, int T, double c11, double c12, double c22, double dt,
                 Dm[e] = v;
             }
             __syncthreads();
+            if (given) { load_block(Dm, Dblk + (size_t)(t - 1) * d * d); __syncthreads(); }
             mm16(S, C, C, true, false, -1., Dm, 1.);
         }
     }
-    if (l == 0) *out.status = bad;
+    if (l == 0 && (bad || !given)) *out.status = bad;        // (per-mode launch: the host zeroes status first)
 }
 
 hipError_t launch_prior_factor(int n, int T, double dt, double ks, double kg, const double* d_qc_inv,
@@ -193,6 +214,64 @@ hipError_t launch_prior_factor(int n, int T, double dt, double ks, double kg, co
     // coefficients exactly as gp_factor.py:45-47 evaluates them in Python floats
     const double c11 = 12. * pow(dt, -3.), c12 = -6. * pow(dt, -2.), c22 = 4. * pow(dt, -1.);
     hipLaunchKernelGGL(prior_factor_kernel, dim3(1), dim3(64), 0, stream, n, T, c11, c12, c22, dt,
-                       ks, kg, d_qc_inv, isotropic, out);
+                       ks, kg, d_qc_inv, isotropic, (const double*)nullptr, (const double*)nullptr, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_prior_factor_blocks(int n, int T, int n_modes, const double* d_D, const double* d_E,
+                                      PriorDev out, hipStream_t stream) {
+    hipLaunchKernelGGL(prior_factor_kernel, dim3(n_modes), dim3(64), 0, stream, n, T, 0., 0., 0., 0., 0., -1.,
+                       (const double*)nullptr, 0, d_D, d_E, out);
+    return hipGetLastError();
+}
+
+// MultiMPPrior.log_prob (mp_priors_multi.py:209-210 -> torch MultivariateNormal.log_prob): the quadratic
+// form (x - mu)^T Sigma^-1 (x - mu) on the block-tridiagonal precision, fp64, one wave per row
+// (row r belongs to mode r % n_modes, the layout of a [.., modes, M] batch).
+template <typename real>
+__global__ void __launch_bounds__(64)
+prior_quadform_kernel(int d, int T, long long rows, int n_modes, const real* __restrict__ x,
+                      const real* __restrict__ means, const double* __restrict__ blocks4,
+                      const double* __restrict__ Dblk, const double* __restrict__ Eblk, double* __restrict__ out) {
+    const long long r = blockIdx.x;
+    if (r >= rows) return;
+    const int m = (int)(r % n_modes);
+    const size_t M = (size_t)T * d, dd = (size_t)d * d;
+    const real* xr = x + (size_t)r * M;
+    const real* mu = means + (size_t)m * M;
+    double acc = 0.;
+    for (int t = threadIdx.x; t < T; t += 64) {
+        const double* Dt = Dblk ? Dblk + ((size_t)m * T + t) * dd
+                                : blocks4 + (t == 0 ? 0 : (t == T - 1 ? 2 : 1)) * dd;
+        double y[SGPMP_MAX_D], yn[SGPMP_MAX_D];
+        for (int i = 0; i < d; ++i) y[i] = (double)xr[(size_t)t * d + i] - (double)mu[(size_t)t * d + i];
+        for (int i = 0; i < d; ++i) {
+            double v = 0.;
+            for (int j = 0; j < d; ++j) v += Dt[i * d + j] * y[j];
+            acc += y[i] * v;
+        }
+        if (t + 1 < T) {                                  // 2 y_{t+1}^T E_t y_t,  E_t = Sigma^-1[t+1, t]
+            const double* Et = Dblk ? Eblk + ((size_t)m * (T - 1) + t) * dd : blocks4 + 3 * dd;
+            for (int i = 0; i < d; ++i) yn[i] = (double)xr[(size_t)(t + 1) * d + i] - (double)mu[(size_t)(t + 1) * d + i];
+            for (int i = 0; i < d; ++i) {
+                double v = 0.;
+                for (int j = 0; j < d; ++j) v += Et[i * d + j] * y[j];
+                acc += 2. * yn[i] * v;
+            }
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (threadIdx.x == 0) out[r] = acc;
+}
+
+hipError_t launch_prior_quadform(int dtype, int n, int T, long long rows, int n_modes, const void* x,
+                                 const void* means, const PriorDev& prior, double* out, hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    if (dtype == SGPMP_F64)
+        hipLaunchKernelGGL((prior_quadform_kernel<double>), dim3((unsigned)rows), dim3(64), 0, stream, 2 * n, T, rows,
+                           n_modes, (const double*)x, (const double*)means, prior.blocks, prior.Dm, prior.Em, out);
+    else
+        hipLaunchKernelGGL((prior_quadform_kernel<float>), dim3((unsigned)rows), dim3(64), 0, stream, 2 * n, T, rows,
+                           n_modes, (const float*)x, (const float*)means, prior.blocks, prior.Dm, prior.Em, out);
     return hipGetLastError();
 }

@@ -223,12 +223,14 @@ sample_iso_small_kernel(int n, int T, int S, const real* __restrict__ coef, cons
 
 template <typename real, int N>
 __global__ void __launch_bounds__(128)
-sample_dense_kernel(int T, int S, const real* __restrict__ G, const real* __restrict__ H,
+sample_dense_kernel(int T, int S, const real* __restrict__ G, const real* __restrict__ H, size_t mode_stride,
                     const real* __restrict__ means, const real* __restrict__ eps, int eps_modes,
                     int eps_mode_offset, int mode_offset, uint64_t seed, uint64_t draw,
                     real* __restrict__ out) {
     constexpr int D = 2 * N;
     const int m = blockIdx.y;
+    G += (size_t)m * mode_stride;                        // per-mode factors (set_Sigma_invs) or 0: shared
+    H += (size_t)m * mode_stride;
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     const size_t M = (size_t)T * D;
@@ -308,11 +310,13 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
     }
     const real* G = f64 ? (const real*)prior.G : (const real*)prior.G32;
     const real* H = f64 ? (const real*)prior.H : (const real*)prior.H32;
+    if (prior.n_factor_modes > 0 && n_modes > prior.n_factor_modes) return hipErrorInvalidValue;
+    const size_t mode_stride = prior.n_factor_modes > 0 ? (size_t)T * 4 * n * n : 0;
     dim3 grid((S + 127) / 128, n_modes), block(128);
 #define DENSE(NN)                                                                                  \
     case NN:                                                                                       \
         hipLaunchKernelGGL((sample_dense_kernel<real, NN>), grid, block, 0, stream, T, S, G, H,    \
-                           means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, out);  \
+                           mode_stride, means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, out);  \
         break;
     switch (n) {
         DENSE(1) DENSE(2) DENSE(3) DENSE(4) DENSE(5) DENSE(6) DENSE(7) DENSE(8)

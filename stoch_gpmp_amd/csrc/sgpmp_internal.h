@@ -26,6 +26,11 @@ struct PriorDev {
     double dt;
     int isotropic;
     int valid;
+    // per-mode precisions (MultiMPPrior.set_Sigma_invs): n_factor_modes > 0 -> G/H/G32/H32 are
+    // [modes][T][d][d] and Dm/Em hold the given blocks; 0 -> one shared closed-form factor
+    int n_factor_modes;
+    double* Dm;        // [modes][T][d][d]
+    double* Em;        // [modes][T-1][d][d]
 };
 
 // ---------------------------------------------------------------------------------- cost program
@@ -112,6 +117,8 @@ void comm_destroy(SgpmpComm* c);
 int comm_rank(const SgpmpComm* c);
 int comm_world(const SgpmpComm* c);
 const char* comm_allreduce_stats(SgpmpComm* c, double* stats, hipStream_t stream);
+const char* comm_step_begin(SgpmpComm* c, hipStream_t stream, double** slot, hipEvent_t* k4_done);
+const char* comm_step_end(SgpmpComm* c, double* stats);
 const char* comm_stats_wait(SgpmpComm* c, double* stats, hipStream_t stream);
 const char* comm_allgather(SgpmpComm* c, const void* send, void* recv, size_t bytes, hipStream_t stream);
 
@@ -119,6 +126,11 @@ const char* comm_allgather(SgpmpComm* c, const void* send, void* recv, size_t by
 // (defined in the .hip files; all asynchronous on `stream`)
 hipError_t launch_prior_factor(int n, int T, double dt, double ks, double kg, const double* d_qc_inv,
                                int isotropic, PriorDev out, hipStream_t stream);
+
+hipError_t launch_prior_factor_blocks(int n, int T, int n_modes, const double* d_D, const double* d_E,
+                                      PriorDev out, hipStream_t stream);
+hipError_t launch_prior_quadform(int dtype, int n, int T, long long rows, int n_modes, const void* x,
+                                 const void* means, const PriorDev& prior, double* out, hipStream_t stream);
 
 hipError_t launch_sample(int dtype, int n, int T, const PriorDev& prior, uint64_t seed, uint64_t draw,
                          const void* means, int n_modes, int mode_offset, int n_samples,
@@ -145,7 +157,7 @@ hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& prior, con
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int costs_dtype,
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
-                         hipStream_t stream);
+                         hipStream_t stream, hipEvent_t done = nullptr);
 
 hipError_t launch_ee_goal(int dtype, int n, int T, const CostTerm& term, const ChainDev* d_chain,
                           const void* trajs, long long batch, void* costs, double* costs64,

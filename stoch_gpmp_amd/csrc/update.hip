@@ -14,6 +14,8 @@
 // fp64 once per particle per iteration and consumed by the cost sweep (K3).  The last block
 // (x_{T-1} . K_g mu_{T-1}) is re-expressed on (x_0, e_0, ..) and folded into the first T blocks, so
 // K3 needs exactly one weight vector per waypoint.
+#include <hip/hip_ext.h>
+
 #include "sgpmp_internal.h"
 
 template <typename T> __device__ __forceinline__ T block_reduce(T v, T* scratch, bool is_min) {
@@ -165,15 +167,17 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int costs_dtype,
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
-                         hipStream_t stream) {
+                         hipStream_t stream, hipEvent_t done) {
     const int M = T * 2 * n;
     const size_t lds = (size_t)S * (sizeof(double) + sizeof(int));
     if (P <= 0) return hipSuccess;
     dim3 grid(P), block(256);
+    // `done` (multi-GPU statistics): the event is signalled by this kernel's own dispatch packet
+    // (hipExtLaunchKernelGGL stop event) instead of a separate barrier packet behind it
 #define UPD(REAL, COST, VW)                                                                          \
-    hipLaunchKernelGGL((update_kernel<REAL, COST, VW>), grid, block, lds, stream, M, S,             \
-                       (const COST*)costs, (const REAL*)samples, (REAL*)means, temperature, step_size, \
-                       (REAL*)weights, (REAL*)grad, (REAL*)means_prev, stats)
+    hipExtLaunchKernelGGL((update_kernel<REAL, COST, VW>), grid, block, (unsigned)lds, stream, (hipEvent_t) nullptr, \
+                          done, 0u, M, S, (const COST*)costs, (const REAL*)samples, (REAL*)means, temperature, \
+                          step_size, (REAL*)weights, (REAL*)grad, (REAL*)means_prev, stats)
     if (dtype == SGPMP_F64) {
         if (M % 4 == 0) UPD(double, double, 4); else UPD(double, double, 2);
     } else if (costs_dtype == SGPMP_F64) {

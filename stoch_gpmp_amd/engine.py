@@ -100,16 +100,43 @@ class Engine:
                 float(sigma_goal) if sigma_goal is not None else -1.0, qc, L.stream_ptr()))
         self._prior_key[which] = key
 
-    def get_prior(self, which):
-        """-> (blocks [4,d,d], G [T,d,d], H [T,d,d]) as fp64 CPU tensors (inspection/tests)."""
+    def get_prior(self, which, n_modes=None):
+        """-> (blocks [4,d,d], G [T,d,d], H [T,d,d]) as fp64 CPU tensors (inspection/tests); after
+        set_prior_blocks pass n_modes: G, H are [n_modes,T,d,d] and blocks is None."""
         d, T = self.d, self.T
+        m = 1 if n_modes is None else n_modes
         blocks = (C.c_double * (4 * d * d))()
-        G = (C.c_double * (T * d * d))()
-        H = (C.c_double * (T * d * d))()
+        G = (C.c_double * (m * T * d * d))()
+        H = (C.c_double * (m * T * d * d))()
         with torch.cuda.device(self.device):
             L.check(self.lib.sgpmp_get_prior(self._ctx, which, blocks, G, H))
         to_t = lambda a, shape: torch.tensor(list(a), dtype=torch.float64).reshape(shape)
-        return to_t(blocks, (4, d, d)), to_t(G, (T, d, d)), to_t(H, (T, d, d))
+        if n_modes is None:
+            return to_t(blocks, (4, d, d)), to_t(G, (T, d, d)), to_t(H, (T, d, d))
+        return None, to_t(G, (m, T, d, d)), to_t(H, (m, T, d, d))
+
+    def set_prior_blocks(self, which, D, E):
+        """Per-mode block-tridiagonal precisions: D [modes,T,d,d], E [modes,T-1,d,d] (fp64 host tensors)."""
+        D = torch.as_tensor(D, dtype=torch.float64).contiguous().cpu()
+        E = torch.as_tensor(E, dtype=torch.float64).contiguous().cpu()
+        modes = D.shape[0]
+        assert D.shape == (modes, self.T, self.d, self.d) and E.shape == (modes, self.T - 1, self.d, self.d)
+        self._prior_key.pop(which, None)
+        Dp = C.cast(D.data_ptr(), C.POINTER(C.c_double))
+        Ep = C.cast(E.data_ptr(), C.POINTER(C.c_double))
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_set_prior_blocks(self._ctx, which, modes, Dp, Ep, L.stream_ptr()))
+
+    def prior_quadform(self, which, x, means):
+        """(x_r - mu_m)^T Sigma_m^-1 (x_r - mu_m), m = r % modes: x [rows, M], means [modes, M] -> fp64 [rows]."""
+        self._chk(x, "x")
+        self._chk(means, "means")
+        rows, modes = x.shape[0], means.shape[0]
+        out = torch.empty(rows, device=self.device, dtype=torch.float64)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_prior_quadform(self._ctx, which, L.ptr(x), rows, L.ptr(means), modes,
+                                                  L.ptr(out), L.stream_ptr()))
+        return out
 
     def set_costs(self, descs):
         """descs: list of dicts produced by the Cost classes' `descriptor()`."""

@@ -565,6 +565,71 @@ def test_update_with_fp32_costs_tensor():
     close(m_dev, means.double() + 0.25 * grad, 1e-6, atol=1e-7)
 
 
+# ------------------------------------------------------------------------------- MultiMPPrior API
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+def test_multi_mp_prior_log_prob_and_per_mode_precisions_match_torch(dtype, rtol):
+    """MultiMPPrior (reference mp_priors_multi.py): `log_prob` (:209-210) against torch's
+    MultivariateNormal on the dense precision, and `set_Sigma_invs` (:125-128) -- one block-tridiagonal
+    precision per mode, factored by K1 per mode -- through `sample` (same eps -> loc + scale_tril @ eps of
+    the dense torch distribution) and `log_prob`; malformed matrices raise ValueError like torch does."""
+    from torch.distributions import MultivariateNormal
+    from stoch_gpmp_amd.costs.factors.mp_priors_multi import MultiMPPrior
+    n, T, dt, modes, S = 3, 7, 0.1, 3, 5
+    d, M = 2 * n, 2 * n * T
+    ta = TA(dtype)
+    g = torch.Generator().manual_seed(11)
+    start = torch.randn(d, generator=g, dtype=torch.float64)
+    goals = torch.randn(modes, d, generator=g, dtype=torch.float64)
+    ss, sg, sgoal = 0.3, 0.8, 0.5
+    K_s, K_g = R.unary_K(d, ss, torch.float64), R.unary_K(d, sgoal, torch.float64)
+    Q = R.q_inv_matrix(n, dt, sg, torch.float64)
+    pr = MultiMPPrior(T - 1, dt, d, n, K_s.to(**ta), Q.to(**ta), start.to(**ta), K_g_inv=K_g.to(**ta),
+                      goal_states=goals.to(**ta), tensor_args=ta)
+    ora = R.TrajPrior(T, n, dt, K_s, Q, start, K_g=K_g, goals=goals)
+    close(pr.Sigma_inv, ora.Sigma_inv, 1e-6 if dtype == torch.float32 else 1e-12, atol=1e-9)
+    x = ora.means.unsqueeze(0) + 0.3 * torch.randn(S, modes, M, generator=g, dtype=torch.float64)
+    want = MultivariateNormal(ora.means, precision_matrix=ora.Sigma_invs).log_prob(x)
+    got = pr.log_prob(x.to(**ta))
+    assert got.shape == (S, modes)
+    close(got, want, rtol, atol=rtol * float(want.abs().max()))
+
+    # ---- per-mode precisions: scaled + block-diagonally perturbed copies (still block tridiagonal, SPD)
+    new = torch.zeros(modes, M, M, dtype=torch.float64)
+    for m in range(modes):
+        A = torch.randn(T, d, d, generator=g, dtype=torch.float64) * 0.7
+        bump = torch.block_diag(*[a @ a.t() for a in A])
+        new[m] = ora.Sigma_inv * (1. + 0.4 * m) + bump
+    pr.set_Sigma_invs(new.to(**ta))
+    close(pr.Sigma_invs, new, 1e-6 if dtype == torch.float32 else 0)
+    mvn = MultivariateNormal(ora.means, precision_matrix=new)
+    eps = torch.randn(S, modes, M, generator=g, dtype=torch.float64)
+    want_x = (mvn.loc + torch.matmul(mvn._unbroadcasted_scale_tril, eps.unsqueeze(-1)).squeeze(-1)) \
+        .view(S, modes, T, d).transpose(0, 1)
+    got_x = pr.sample(S, eps=eps.to(**ta).contiguous())
+    close(got_x, want_x, rtol, atol=rtol * float(want_x.abs().max()))
+    got = pr.log_prob(x.to(**ta))
+    want = mvn.log_prob(x)
+    close(got, want, rtol, atol=rtol * float(want.abs().max()))
+    # native noise with per-mode factors: finite, right shape, mode-dependent spread
+    xs = pr.sample(64)
+    assert xs.shape == (modes, 64, T, d) and bool(torch.isfinite(xs).all())
+    # ---- refusals
+    bad = new.clone()
+    bad[1, 0, M - 1] = bad[1, M - 1, 0] = 0.5                      # weight outside the band
+    with pytest.raises(ValueError):
+        pr.set_Sigma_invs(bad.to(**ta))
+    notpd = new.clone()
+    notpd[2] = -notpd[2]
+    with pytest.raises(ValueError):
+        pr.set_Sigma_invs(notpd.to(**ta))
+    with pytest.raises(AssertionError):
+        pr.set_Sigma_invs(new[:2].to(**ta))
+    # a closed-form prior can be restored afterwards and the planner-side calls still refuse per-mode factors
+    pr.set_Sigma_invs(new.to(**ta))
+    with pytest.raises(RuntimeError):
+        pr._engine.step(0, 0, pr.means.view(modes, T, d), torch.empty(modes, 1, T, d, **ta), 1., 1.)
+
+
 # ------------------------------------------------------------------------------- edge cases of K3
 @pytest.mark.parametrize("S,T,n_sph,field_type", [
     (7, 20, 6, "rbf"),          # odd rows per particle -> single-trajectory sweep with IS weights

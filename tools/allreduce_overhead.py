@@ -1,4 +1,7 @@
-"""Where the ~5 % of the per-iteration statistics all-reduce goes (1-rank RCCL group on one GPU)."""
+"""Cost of the per-iteration statistics all-reduce at one rank (1-rank RCCL group on one GPU):
+off   -- no communicator
+rccl  -- the C-ABI path: sgpmp_step enqueues ncclAllReduce on the context's side stream (event-chained)
+torch -- collective='torch': torch.distributed.all_reduce(async_op=True) from Python (round-1 path)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
@@ -9,19 +12,32 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
 ta = {"device": torch.device("cuda:0"), "dtype": torch.float32}
 sph = torch.as_tensor(W.panda_spheres()).to(**ta)
-def run(mode):
-    pl = W.hip_panda_planner(W.PANDA, 64, 1024, 128, ta, seed=0, rank=0, world_size=1, force_stats_allreduce=(mode != "off"))
-    if mode == "nowait":
-        orig = pl._reduce_stats
-        def rs(slot):
-            pl._pending_reduce.append(dist.all_reduce(pl._stats[slot], async_op=True))
-            if len(pl._pending_reduce) > 64: pl._pending_reduce = pl._pending_reduce[-2:]
-        pl._reduce_stats = rs
-    for _ in range(30): pl.optimize(obstacle_spheres=sph)
+
+
+def build(mode):
+    kw = {} if mode == "off" else dict(force_stats_allreduce=True, collective=mode)
+    pl = W.hip_panda_planner(W.PANDA, 64, 1024, 128, ta, seed=0, rank=0, world_size=1, **kw)
+    assert pl._comm_attached == (mode == "rccl")
+    for _ in range(30):
+        pl.optimize(obstacle_spheres=sph)
+    return pl
+
+
+def timeit(pl, n=300):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(300): pl.optimize(obstacle_spheres=sph)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 300
-    print(f"{mode:7s}: {dt*1e6:.1f} us per iteration ({1/dt:.0f} it/s)")
-for m in ("off", "on", "nowait", "off", "on"):
-    run(m)
+    for _ in range(n):
+        pl.optimize(obstacle_spheres=sph)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+pls = {m: build(m) for m in ("off", "rccl", "torch")}
+res = {m: [] for m in pls}
+for rnd in range(5):                       # interleaved rounds in one process
+    for m, pl in pls.items():
+        res[m].append(timeit(pl))
+base = min(res["off"])
+for m, v in res.items():
+    print(f"{m:6s}: min {min(v)*1e6:7.1f} us  median {sorted(v)[len(v)//2]*1e6:7.1f} us per iteration "
+          f"(+{(min(v)-base)*1e6:5.1f} us vs off)")
 dist.destroy_process_group()
