@@ -201,7 +201,8 @@ int sgpmp_update(sgpmp_ctx* ctx, const void* costs, int costs_dtype, const void*
                  void* means_prev, double* stats, void* stream);
 
 /* One body of the loop at planner.py:289-299 for the context's particle shard:
- * K5 -> K2 -> K3 -> K4 on `stream`.  samples [P,S,T,d] is written (state_samples of the iteration);
+ * K5 -> K2 -> K3 -> K4 on `stream` (K2 + K3 as ONE launch when the configuration qualifies, see
+ * csrc/fused_step.inc; K5 folded into the previous step's K4 under SGPMP_STEP_MEANS_KEPT).  samples [P,S,T,d] is written (state_samples of the iteration);
  * costs [P,S] ctx dtype may be NULL. means updated in place. stats (DEVICE
  * double[SGPMP_STAT_SHARDS][4] or NULL) is zeroed at the start of the step and holds this step's
  * sharded sums afterwards; with a communicator attached (sgpmp_comm_init) the step also enqueues
@@ -210,7 +211,12 @@ int sgpmp_update(sgpmp_ctx* ctx, const void* costs, int costs_dtype, const void*
 int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, int eps_modes,
                int eps_mode_offset, void* means, void* samples, void* costs, void* weights,
                void* grad, void* means_prev, const void* spheres, int n_spheres, double temperature,
-               double step_size, double* stats, void* stream);
+               double step_size, double* stats, int flags, void* stream);
+/* flags of sgpmp_step: */
+#define SGPMP_STEP_MEANS_KEPT 1    /* the caller guarantees that `means` still holds exactly what this context's
+                                      previous sgpmp_step left there: the importance-sampling weights that step's
+                                      update kernel prepared for them are then used, and the K5 launch is skipped.
+                                      Without the flag (or after anything else wrote the means) K5 runs. */
 
 /* ---- multi-GPU (one process per GPU; RCCL over xGMI) -------------------------------------------- */
 /* The reference is single-process and has no counterpart; these calls carry out SURVEY.md 8(e):

@@ -18,6 +18,7 @@ FLAG_GP_START, FLAG_SDF_CLAMP, FLAG_EE_SQUARE = 1, 16, 32
 MAX_TERMS, MAX_JOINTS, MAX_DOF, MAX_INTERP = 8, 16, 8, 8
 STAT_SHARDS = 64
 OK, EINVAL, ENOTPD, EHIP, ESTATE = 0, -1, -2, -3, -4
+STEP_MEANS_KEPT = 1
 
 
 class Dims(C.Structure):
@@ -67,7 +68,7 @@ SIGNATURES = {
     "sgpmp_cost_eval": (_I, [_P, _P, _I64, _I64, _P, _I, _P, _I, _P, _P, _P]),
     "sgpmp_is_weights": (_I, [_P, _P, _I, _D, _P, _P]),
     "sgpmp_update": (_I, [_P, _P, _I, _P, _P, _D, _D, _P, _P, _P, _P, _P]),
-    "sgpmp_step": (_I, [_P, _U64, _U64, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _D, _D, _P, _P]),
+    "sgpmp_step": (_I, [_P, _U64, _U64, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _D, _D, _P, _I, _P]),
     "sgpmp_fk": (_I, [_P, _P, _I64, _P, _P]),
     "sgpmp_grid_lookup": (_I, [_P, _I, _P, _I64, _P, _P]),
     "sgpmp_field_eval": (_I, [_P, _I, _P, _I64, _I, _P, _I, _P, _P]),

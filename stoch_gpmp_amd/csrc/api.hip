@@ -53,6 +53,10 @@ struct sgpmp_ctx {
     std::vector<StepEvents> events;
     SgpmpToggles tg;              // development switches, read from the environment at creation
     SgpmpComm* comm;              // RCCL communicator (multi-GPU runs), or null
+    // importance-sampling weights prepared by the previous step's update kernel for the means it wrote
+    bool isw_ready;
+    const void* isw_means;        // the means buffer they belong to
+    double isw_temperature;
     const char* last_cost_kernel; // name of the cost-sweep kernel the dispatcher picked last
 };
 
@@ -127,6 +131,7 @@ extern "C" int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out) {
     toggles_from_env(c->tg);
     c->last_cost_kernel = "";
     c->comm = nullptr;
+    c->isw_ready = false; c->isw_means = nullptr; c->isw_temperature = 0.;
     int rc;
     if ((rc = alloc_prior(c, c->prior[0])) != SGPMP_OK) return rc;
     if ((rc = alloc_prior(c, c->prior[1])) != SGPMP_OK) return rc;
@@ -228,6 +233,7 @@ extern "C" int sgpmp_set_prior(sgpmp_ctx* c, int which, double dt, double sigma_
     else for (int i = 0; i < n; ++i) qc[(size_t)i * n + i] = 1. / (sigma_gp * sigma_gp);   // gp_factor.py:25-26
     HIPCHK(hipMemcpyAsync(c->d_qc, qc.data(), sizeof(double) * n * n, hipMemcpyHostToDevice, st));
     PriorDev& p = c->prior[which];
+    c->isw_ready = false;                                        // prepared IS weights belong to the old prior
     p.ks = 1. / (sigma_start * sigma_start);                     // unary_factor.py:19
     p.kg = sigma_goal > 0. ? 1. / (sigma_goal * sigma_goal) : -1.;
     p.dt = dt;
@@ -254,6 +260,7 @@ extern "C" int sgpmp_set_prior_blocks(sgpmp_ctx* c, int which, int n_modes, cons
     hipStream_t st = (hipStream_t)stream;
     PriorDev& p = c->prior[which];
     p.valid = 0;
+    c->isw_ready = false;
     HIPCHK(hipStreamSynchronize(st));
     hipFree(p.G); hipFree(p.H); hipFree(p.G32); hipFree(p.H32); hipFree(p.Dm); hipFree(p.Em);
     p.G = p.H = p.Dm = p.Em = nullptr; p.G32 = p.H32 = nullptr;
@@ -608,6 +615,7 @@ extern "C" int sgpmp_is_weights(sgpmp_ctx* c, const void* means, int n_particles
 extern "C" int sgpmp_update(sgpmp_ctx* c, const void* costs, int costs_dtype, const void* samples, void* means,
                             double temperature, double step_size, void* weights, void* grad, void* means_prev,
                             double* stats, void* stream) {
+    if (c) c->isw_ready = false;                                 // the means change behind the prepared IS weights
     if (!c || !costs || !samples || !means) return fail(SGPMP_EINVAL, "sgpmp_update: null argument");
     if (costs_dtype != SGPMP_F64 && costs_dtype != c->dims.dtype)
         return fail(SGPMP_EINVAL, "sgpmp_update: costs must be fp64 or the context dtype");
@@ -621,7 +629,7 @@ extern "C" int sgpmp_update(sgpmp_ctx* c, const void* costs, int costs_dtype, co
 extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void* eps, int eps_modes,
                           int eps_mode_offset, void* means, void* samples, void* costs, void* weights,
                           void* grad, void* means_prev, const void* spheres, int n_spheres, double temperature,
-                          double step_size, double* stats, void* stream) {
+                          double step_size, double* stats, int flags, void* stream) {
     if (!c || !means || !samples) return fail(SGPMP_EINVAL, "sgpmp_step: null argument");
     if (!c->prior[SGPMP_PRIOR_SAMPLE].valid) return fail(SGPMP_ESTATE, "sgpmp_step: sampling prior not set");
     if (c->prior[SGPMP_PRIOR_SAMPLE].n_factor_modes > 0)
@@ -649,15 +657,24 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     double* acc_stats = stats;
     hipEvent_t k4_done = nullptr;
     if (c->comm && stats) COMMCHK(comm_step_begin(c->comm, st, &acc_stats, &k4_done));
-    HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, means, P, temperature, c->d_isw, acc_stats, st));
+    // One fused launch (importance-sampling weights + sampler + cost sweep) when the step qualifies
+    // (in-kernel noise, fp32 Panda-type program); else K5, the sampler and the sweep one after the other
+    bool fused = !eps && samples &&
+                 fused_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P, D.particle_offset, S,
+                                     n_spheres, c->tg);
+    // K5 is skipped when the previous step's update kernel already prepared the weights for exactly these
+    // means (the caller vouches with SGPMP_STEP_MEANS_KEPT that nothing else wrote them since); the fused
+    // launch then zeroes the statistics itself
+    const bool prepared = fused && (flags & SGPMP_STEP_MEANS_KEPT) && c->isw_ready && c->isw_means == means &&
+                          c->isw_temperature == temperature;
+    c->isw_ready = false;
+    if (!prepared)
+        HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, means, P, temperature, c->d_isw, acc_stats, st));
     if (se) HIPCHK(hipEventRecord(se->ev[1], st));
-    // K2 + K3: one fused launch when the step qualifies (in-kernel noise, fp32 Panda-type program), else
-    // the sampler followed by the sweep
-    bool fused = false;
-    if (!eps) {
-        if (se) HIPCHK(hipEventRecord(se->ev[2], st));   // (fused: all of K2 + K3 is booked on the sweep)
+    if (fused) {
+        if (se) HIPCHK(hipEventRecord(se->ev[2], st));   // (fused: the whole launch is booked on the sweep)
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, means, P,
-                                 D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, costs,
+                                 D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, acc_stats, costs,
                                  c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused));
         for (int i = 0; fused && i < c->h_prog.n_terms; ++i)
             if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL)
@@ -673,8 +690,11 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
                            c->d_isw, S, pr.dt, costs, c->d_costs64, st, c->tg, &c->last_cost_kernel));
     }
     if (se) HIPCHK(hipEventRecord(se->ev[3], st));
+    // (a fused step also has its update kernel prepare the NEXT step's importance-sampling weights)
     HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
-                         temperature, step_size, weights, grad, means_prev, acc_stats, st, k4_done));
+                         temperature, step_size, weights, grad, means_prev, acc_stats, st, k4_done,
+                         fused ? &pr : nullptr, fused ? c->d_isw : nullptr));
+    if (fused) { c->isw_ready = true; c->isw_means = means; c->isw_temperature = temperature; }
     if (se) HIPCHK(hipEventRecord(se->ev[4], st));
     // multi-GPU: sum the statistics over all ranks on the side stream (never gates the next step)
     if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats));
@@ -822,6 +842,7 @@ extern "C" int sgpmp_gpmp_linearize(sgpmp_ctx* c, const void* means, const void*
 
 extern "C" int sgpmp_gpmp_solve(sgpmp_ctx* c, void* means, const double* diag_sum, double delta,
                                 double step_size, void* d_theta, void* costs, void* stream) {
+    if (c) c->isw_ready = false;
     if (!c || !means || !(delta >= 0.)) return fail(SGPMP_EINVAL, "sgpmp_gpmp_solve: bad argument");
     int rc;
     if ((rc = finalize_program(c)) != SGPMP_OK) return rc;

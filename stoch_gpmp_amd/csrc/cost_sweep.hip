@@ -495,28 +495,39 @@ static bool make_flat(const CostProgram& p, FlatProg<real>& f) {
 #include "cost_sweep_dual.inc"
 #include "fused_step.inc"
 
-// K2 + K3 in one launch (fused_step.inc) when the step qualifies; *launched says whether it did.
-hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
-                             const ChainDev& h_chain, uint64_t seed, uint64_t draw, const void* means, int P,
-                             int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
-                             const void* isw, void* costs, double* costs64, hipStream_t stream,
-                             const SgpmpToggles& tg, const char** picked, bool* launched) {
-    *launched = false;
+// Does a step qualify for the fused launch (fused_step.inc)?
+bool fused_step_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
+                         const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
+                         const SgpmpToggles& tg) {
     using CCp = ChainCode_panda;
     if (dtype != SGPMP_F32 || tg.no_fused_step || tg.no_dual_sweep || tg.no_chain_codegen || tg.force_generic_fk ||
         tg.no_flat_program)
-        return hipSuccess;
-    if (!prior.isotropic || n != CCp::N || !h_chain.plan.fast || h_chain.plan.codegen_id != 1) return hipSuccess;
-    if (S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0 || n_spheres > SGPMP_FUSED_SPH || !isw || !samples || P < 1)
+        return false;
+    if (!prior.isotropic || n != CCp::N || !h_chain.plan.fast || h_chain.plan.codegen_id != 1) return false;
+    if (S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0 || n_spheres > SGPMP_FUSED_SPH || P < 1) return false;
+    FlatProg<float> F;
+    if (!make_flat<float>(h_prog, F) || F.has_grid) return false;
+    for (int i = 0; i < h_prog.n_terms; ++i)
+        if (h_prog.terms[i].n_interp > 0) return false;
+    if (F.has_goal && (F.goal.rows_per_goal % SGPMP_FUSED_SPW != 0 || F.goal.dim0 > SGPMP_FUSED_GOALS)) return false;
+    if (F.has_gp && (float)prior.dt != F.gp.dt) return false;             // IS term and GP factors share Phi
+    if ((long long)P * S + (long long)mode_offset * S >= (1LL << 31)) return false;
+    return true;
+}
+
+// K2 + K3 in one launch when the step qualifies; *launched says whether it did.
+hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
+                             const ChainDev& h_chain, uint64_t seed, uint64_t draw, const void* means, int P,
+                             int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
+                             const void* isw, double* zero_stats, void* costs, double* costs64,
+                             hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched) {
+    *launched = false;
+    using CCp = ChainCode_panda;
+    if (!samples || !isw || !fused_step_eligible(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg))
         return hipSuccess;
     FlatProg<float> F;
-    if (!make_flat<float>(h_prog, F) || F.has_grid) return hipSuccess;
-    for (int i = 0; i < h_prog.n_terms; ++i)
-        if (h_prog.terms[i].n_interp > 0) return hipSuccess;
-    if (F.has_goal && (F.goal.rows_per_goal % SGPMP_FUSED_SPW != 0 || F.goal.dim0 > SGPMP_FUSED_GOALS)) return hipSuccess;
-    if (F.has_gp && (float)prior.dt != F.gp.dt) return hipSuccess;       // IS term and GP factors share Phi
+    make_flat<float>(h_prog, F);
     const long long batch = (long long)P * S, batch_offset = (long long)mode_offset * S;
-    if (batch + batch_offset >= (1LL << 31)) return hipSuccess;
     auto log2_exact = [](long long v) { int s = 0; while ((1LL << s) < v && s < 62) ++s; return (1LL << s) == v ? s : -1; };
     CostArgs<float> a;
     a.T = T; a.chain = nullptr; a.n_links = h_chain.n_links; a.trajs = (const float*)samples;
@@ -529,6 +540,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     fs.coef = prior.iso32; fs.means = (const float*)means; fs.samples = (float*)samples;
     fs.seed = seed; fs.draw = draw; fs.mode_offset = mode_offset; fs.S = S;
     fs.gpp = S / SGPMP_FUSED_SPW; fs.gpp_shift = log2_exact(fs.gpp);
+    fs.zero_stats = zero_stats;
     const long long nitems = batch / SGPMP_FUSED_SPW;
     long long blocks = (nitems + 3) / 4;
     // one item per wave measured fastest at config 3 (4096 workgroups 0.216 ms/iteration, 2048: 0.219,

@@ -147,8 +147,12 @@ hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const
 hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                              const ChainDev& h_chain, uint64_t seed, uint64_t draw, const void* means, int P,
                              int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
-                             const void* isw, void* costs, double* costs64, hipStream_t stream,
-                             const SgpmpToggles& tg, const char** picked, bool* launched);
+                             const void* isw, double* zero_stats, void* costs, double* costs64,
+                             hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched);
+// does the step qualify for the fused launch? (same conditions, no launch)
+bool fused_step_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
+                         const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
+                         const SgpmpToggles& tg);
 
 hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& prior, const void* means,
                              int n_particles, double temperature, void* out, double* zero_stats,
@@ -157,7 +161,8 @@ hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& prior, con
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int costs_dtype,
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
-                         hipStream_t stream, hipEvent_t done = nullptr);
+                         hipStream_t stream, hipEvent_t done = nullptr, const PriorDev* isw_prior = nullptr,
+                         void* isw_next = nullptr);
 
 hipError_t launch_ee_goal(int dtype, int n, int T, const CostTerm& term, const ChainDev* d_chain,
                           const void* trajs, long long batch, void* costs, double* costs64,

@@ -34,13 +34,59 @@ template <typename T> __device__ __forceinline__ T block_reduce(T v, T* scratch,
     return r;
 }
 
+// K5 element: component e = t * d + i of one particle's importance-sampling weight vector [T+1][d], from that
+// particle's means mu [T][d] (fp64 arithmetic on the context-dtype means).
+template <typename real>
+__device__ __forceinline__ real is_weight_elem(int n, int T, const real* __restrict__ mu, const double* __restrict__ Qinv,
+                                               double ks, double kg, double dt, double temperature, int isotropic, int e) {
+    const int d = 2 * n;
+    const int t = e / d, i = e - t * d;
+    if (t == T) return (real)0;         // spare block (kept for layout stability): unused by K3
+    double v;
+    if (t == 0) {
+        v = ks * (double)mu[i];
+    } else {
+        const real* a = mu + (size_t)(t - 1) * d;      // mu_{t-1}
+        const real* b = mu + (size_t)t * d;            // mu_t
+        v = 0.;
+        if (isotropic) {                                // Q^-1 = q (x) I_n: two non-zeros per row
+            const int k = i < n ? i : i - n;
+            const double ep = (double)b[k] - ((double)a[k] + dt * (double)a[n + k]);
+            const double ev = (double)b[n + k] - (double)a[n + k];
+            v = Qinv[i * d + k] * ep + Qinv[i * d + n + k] * ev;
+        } else {
+            for (int j = 0; j < d; ++j) {
+                double ej;                              // e_{t-1}(mu)_j = (mu_t - Phi mu_{t-1})_j
+                if (j < n) ej = (double)b[j] - ((double)a[j] + dt * (double)a[n + j]);
+                else ej = (double)b[j] - (double)a[j];
+                v += Qinv[i * d + j] * ej;
+            }
+        }
+    }
+    // goal block b = K_g mu_{T-1} of A x = (x_0, e_0.., x_{T-1}) folded into the per-waypoint weights:
+    // x_{T-1} = sum_j Phi^{T-2-j} e_j + Phi^{T-1} x_0 and (Phi^T)^k (b_p, b_v) = (b_p, k dt b_p + b_v)
+    if (kg >= 0.) {
+        const real* last = mu + (size_t)(T - 1) * d;
+        const double k = (double)(T - 1 - t);
+        v += (i < n) ? kg * (double)last[i] : kg * (k * dt * (double)last[i - n] + (double)last[i]);
+    }
+    return (real)(temperature * v);
+}
+
+template <typename real> struct IswNext {            // K4's optional tail (next step's IS weights)
+    real* out;               // [P][T+1][d] or null
+    const double* Qinv;
+    double ks, kg, dt;
+    int n, isotropic;
+};
+
 // VW = elements per thread and load (4 when M % 4 == 0, else 2; M = T * 2n is always even).
 template <typename real, typename cost_t, int VW>
 __global__ void __launch_bounds__(256)
 update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __restrict__ samples,
               real* __restrict__ means, double temperature, double step_size,
               real* __restrict__ weights, real* __restrict__ grad, real* __restrict__ means_prev,
-              double* __restrict__ stats) {
+              double* __restrict__ stats, IswNext<real> nx) {
     typedef real vec __attribute__((ext_vector_type(VW)));
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double* w = reinterpret_cast<double*>(lds_raw);                  // [S] weights
@@ -162,12 +208,23 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
         if (means_prev) *reinterpret_cast<vec*>(means_prev + (size_t)p * M + m) = mu_m;
         *reinterpret_cast<vec*>(mu + m) = mn;
     }
+    // The NEXT iteration's importance-sampling weights, from the means just written (K5's arithmetic, same
+    // function): sgpmp_step then starts with the sampler + sweep launch instead of a K5 launch, provided the
+    // caller vouches that nobody touched the means in between (SGPMP_STEP_MEANS_KEPT).
+    if (nx.out) {
+        __syncthreads();                                  // this workgroup's mean stores are visible to it
+        const int d = 2 * nx.n, Tn = M / d;
+        const real* mu_new = mu;
+        for (int e = threadIdx.x; e < (Tn + 1) * d; e += blockDim.x)
+            nx.out[(size_t)p * (Tn + 1) * d + e] = is_weight_elem<real>(nx.n, Tn, mu_new, nx.Qinv, nx.ks, nx.kg, nx.dt,
+                                                                         temperature, nx.isotropic, e);
+    }
 }
 
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int costs_dtype,
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
-                         hipStream_t stream, hipEvent_t done) {
+                         hipStream_t stream, hipEvent_t done, const PriorDev* isw_prior, void* isw_next) {
     const int M = T * 2 * n;
     const size_t lds = (size_t)S * (sizeof(double) + sizeof(int));
     if (P <= 0) return hipSuccess;
@@ -177,7 +234,10 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
 #define UPD(REAL, COST, VW)                                                                          \
     hipExtLaunchKernelGGL((update_kernel<REAL, COST, VW>), grid, block, (unsigned)lds, stream, (hipEvent_t) nullptr, \
                           done, 0u, M, S, (const COST*)costs, (const REAL*)samples, (REAL*)means, temperature, \
-                          step_size, (REAL*)weights, (REAL*)grad, (REAL*)means_prev, stats)
+                          step_size, (REAL*)weights, (REAL*)grad, (REAL*)means_prev, stats,          \
+                          IswNext<REAL>{isw_prior ? (REAL*)isw_next : nullptr, isw_prior ? isw_prior->Qinv : nullptr, \
+                                        isw_prior ? isw_prior->ks : 0., isw_prior ? isw_prior->kg : -1., \
+                                        isw_prior ? isw_prior->dt : 0., n, isw_prior ? isw_prior->isotropic : 1})
     if (dtype == SGPMP_F64) {
         if (M % 4 == 0) UPD(double, double, 4); else UPD(double, double, 2);
     } else if (costs_dtype == SGPMP_F64) {
@@ -201,42 +261,8 @@ __global__ void is_weights_kernel(int n, int T, int P, const real* __restrict__ 
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (zero_stats && p == 0 && e < SGPMP_STAT_SHARDS * 4) zero_stats[e] = 0.;   // this step's statistics start from zero
     if (e >= (T + 1) * d) return;
-    const int t = e / d, i = e - t * d;
-    const size_t idx = (size_t)p * (T + 1) * d + e;
-    const real* mu = means + (size_t)p * T * d;
-    double v;
-    if (t == T) {                       // spare block (kept for layout stability): unused by K3
-        out[idx] = (real)0;
-        return;
-    }
-    if (t == 0) {
-        v = ks * (double)mu[i];
-    } else {
-        const real* a = mu + (size_t)(t - 1) * d;      // mu_{t-1}
-        const real* b = mu + (size_t)t * d;            // mu_t
-        v = 0.;
-        if (isotropic) {                                // Q^-1 = q (x) I_n: two non-zeros per row
-            const int k = i < n ? i : i - n;
-            const double ep = (double)b[k] - ((double)a[k] + dt * (double)a[n + k]);
-            const double ev = (double)b[n + k] - (double)a[n + k];
-            v = Qinv[i * d + k] * ep + Qinv[i * d + n + k] * ev;
-        } else {
-            for (int j = 0; j < d; ++j) {
-                double e;                               // e_{t-1}(mu)_j = (mu_t - Phi mu_{t-1})_j
-                if (j < n) e = (double)b[j] - ((double)a[j] + dt * (double)a[n + j]);
-                else e = (double)b[j] - (double)a[j];
-                v += Qinv[i * d + j] * e;
-            }
-        }
-    }
-    // goal block b = K_g mu_{T-1} of A x = (x_0, e_0.., x_{T-1}) folded into the per-waypoint weights:
-    // x_{T-1} = sum_j Phi^{T-2-j} e_j + Phi^{T-1} x_0 and (Phi^T)^k (b_p, b_v) = (b_p, k dt b_p + b_v)
-    if (kg >= 0.) {
-        const real* last = mu + (size_t)(T - 1) * d;
-        const double k = (double)(T - 1 - t);
-        v += (i < n) ? kg * (double)last[i] : kg * (k * dt * (double)last[i - n] + (double)last[i]);
-    }
-    out[idx] = (real)(temperature * v);
+    out[(size_t)p * (T + 1) * d + e] = is_weight_elem<real>(n, T, means + (size_t)p * T * d, Qinv, ks, kg, dt,
+                                                             temperature, isotropic, e);
 }
 
 hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& prior, const void* means,

@@ -249,7 +249,7 @@ class Engine:
                                           L.stream_ptr()))
 
     def step(self, seed, draw, means, samples, temperature, step_size, costs=None, weights=None,
-             grad=None, means_prev=None, spheres=None, eps=None, eps_mode_offset=0, stats=None):
+             grad=None, means_prev=None, spheres=None, eps=None, eps_mode_offset=0, stats=None, flags=0):
         n_sph = 0
         if spheres is not None:
             n_sph = spheres.shape[0]
@@ -259,7 +259,7 @@ class Engine:
                                         eps_mode_offset, L.ptr(means), L.ptr(samples), L.ptr(costs),
                                         L.ptr(weights), L.ptr(grad), L.ptr(means_prev),
                                         L.ptr(spheres), n_sph,
-                                        float(temperature), float(step_size), L.ptr(stats),
+                                        float(temperature), float(step_size), L.ptr(stats), int(flags),
                                         L.stream_ptr()))
 
     def prepare_step(self, seed, means, samples, temperature, step_size, costs=None, weights=None,
@@ -275,10 +275,10 @@ class Engine:
         seed = int(seed)
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
-        def call(draw):
+        def call(draw, flags=0):
             if torch.cuda.current_device() != dev_index:
                 torch.cuda.set_device(dev_index)
-            L.check(fn(ctx, seed, draw, None, 0, 0, *fixed,
+            L.check(fn(ctx, seed, draw, None, 0, 0, *fixed, flags,
                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return call
 

@@ -241,6 +241,7 @@ class StochGPMP:
         self._costs64_fresh = False
         self._stats_slot = 0
         self._step_calls = {}
+        self._pm_obj, self._pm_version = None, -1       # means tensor / version after our last fused step
         self._Sigma_inv = None
         self._obs_src = None        # strong reference to the caller's obstacle tensor (see _spheres)
         self._obs_ver = -1
@@ -386,7 +387,12 @@ class StochGPMP:
                         self.step_size, costs=self._costs, weights=self._weights_buf, grad=self._grad,
                         means_prev=self._means_prev, spheres=sph, stats=self._stats[slot])
                     self._step_calls[key] = call
-                call(self._draw)
+                # torch bumps a tensor's version counter on every in-place edit; the kernels do not: if the
+                # means are the same tensor at the version recorded after our last step, only we wrote them
+                pm = self.particle_means
+                kept = pm is self._pm_obj and pm._version == self._pm_version
+                call(self._draw, L.STEP_MEANS_KEPT if kept else 0)
+                self._pm_obj, self._pm_version = pm, pm._version
             else:
                 self._engine.step(self.seed, self._draw, self.particle_means, self.state_samples,
                                   self.temperature, self.step_size, costs=self._costs,

@@ -379,6 +379,40 @@ def test_fused_step_corners_match_the_two_launch_path(nppg, G, S, T, field_type,
         b.particle_means.copy_(a.particle_means)
 
 
+def test_prepared_is_weights_follow_every_edit_of_the_means():
+    """A fused step has its update kernel prepare the next step's importance-sampling weights, and the next
+    sgpmp_step skips K5 when the caller vouches (SGPMP_STEP_MEANS_KEPT) that the means are untouched.  The
+    planner vouches only while the tensor's version counter stands still; a twin that NEVER vouches (it bumps
+    the counter before every step, so K5 always runs) must stay bit-identical through plain steps, in-place
+    edits of the means, and a `sample_and_eval` + `_update_distribution` detour."""
+    T, nppg, S = 32, 6, 16
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
+    a = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=23)
+    b = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=23)
+
+    def both(fn):
+        fn(a)
+        b.particle_means.add_(0)                         # version bump: b never claims "means kept"
+        fn(b)
+        assert a._engine.last_cost_kernel() == b._engine.last_cost_kernel() == "fused_step_kernel"
+        assert torch.equal(a._costs, b._costs) and torch.equal(a.particle_means, b.particle_means)
+
+    step = lambda pl: pl.optimize(obstacle_spheres=sph)          # noqa: E731
+    for _ in range(3):
+        both(step)
+    for pl in (a, b):
+        pl.particle_means.mul_(1.0005)                   # an outside edit: the prepared weights are stale now
+    both(step)
+    both(step)
+    for pl in (a, b):                                    # K4 on its own moves the means without a version bump
+        _, _, _, _, costs = pl.sample_and_eval(obstacle_spheres=sph)
+        pl._update_distribution(costs, pl.state_samples)
+    both(step)
+    a.temperature = b.temperature = 2.0                  # the weights carry the temperature
+    both(step)
+    both(step)
+
+
 # --------------------------------------------------------------------------- live observations / edits
 def test_moving_obstacles_are_seen_on_every_call():
     """optimize(obstacle_spheres=...) must use THIS call's spheres (reference fields.py:63-76 reads the
