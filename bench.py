@@ -337,6 +337,7 @@ def main():
     # Pass 1: per-kernel device times (HIP events between the kernels; feeds `roofline`).  It runs first so
     # that the wall-clock pass below starts on a GPU that is already at its working clock: with a cold
     # device the first ~100 iterations run 10-20 % slow, which a 5-step warm-up does not cover.
+    kernel_profile(torch, pl, obs, 100)                   # (device warm-up for the pass itself)
     kms = kernel_profile(torch, pl, obs, 100)
     # Pass 2: W untimed warm-up steps, then EXACTLY K timed steps between barriers (the reported value)
     elapsed = time_loop(torch, pl, obs, args.steps, args.warmup, barrier)
@@ -384,8 +385,11 @@ def main():
                 traffic_src = f"profiles/{PROFILE_ROUND}/traffic.json@{prof.get('tag', '?')} (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)"
                 if "valu_floor_ms" in k:
                     compute = {"valu_wave_insts_per_launch": k.get("valu_insts"),
+                               "valu_busy_cycles_per_simd": k.get("valu_busy_cycles_per_simd"),
                                "valu_floor_ms": k["valu_floor_ms"],
                                "frac_of_valu_floor": k["valu_floor_ms"] / dom_ms,
+                               "valu_busy_frac_under_profiler": k.get("valu_busy_frac_under_profiler"),
+                               "profiled_clock_ghz": k.get("clock_ghz"),
                                "how": k.get("valu_floor_how")}
         out = {
             "metric": "planner iterations/sec (and ms/iter) at fixed particles x samples x T",
@@ -412,7 +416,8 @@ def main():
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
                          "compute": compute},
             "kernel_ms_per_step": kms,
-            "passes": "1: 100 iterations with HIP events between the kernels (kernel_ms_per_step, roofline); "
+            "passes": "1: 100 + 100 iterations with HIP events between the kernels, the second hundred kept "
+                      "(kernel_ms_per_step, roofline); "
                       "2: warm-up + timed steps (value, ms_per_step)",
             "iteration_roofline": {"algorithmic_bytes": iter_alg, "moved_bytes": iter_moved,
                                    "k4_rows_read": nnz_rows,

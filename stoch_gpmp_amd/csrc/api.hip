@@ -26,7 +26,7 @@ static int fail(int code, const std::string& msg) {
             return fail(SGPMP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
 
-struct StepEvents { hipEvent_t ev[5]; };
+struct StepEvents { hipEvent_t ev[5]; bool has[4]; };    // has[k]: a kernel runs between ev[k] and ev[k+1]
 
 struct sgpmp_ctx {
     sgpmp_dims dims;
@@ -649,6 +649,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         c->events.emplace_back();
         se = &c->events.back();
         for (auto& e : se->ev) HIPCHK(hipEventCreate(&e));
+        for (bool& h : se->has) h = true;
         HIPCHK(hipEventRecord(se->ev[0], st));
     }
     const PriorDev& pr = c->prior[SGPMP_PRIOR_SAMPLE];
@@ -670,9 +671,9 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     c->isw_ready = false;
     if (!prepared)
         HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, means, P, temperature, c->d_isw, acc_stats, st));
-    if (se) HIPCHK(hipEventRecord(se->ev[1], st));
+    if (se) { HIPCHK(hipEventRecord(se->ev[1], st)); se->has[0] = !prepared; }
     if (fused) {
-        if (se) HIPCHK(hipEventRecord(se->ev[2], st));   // (fused: the whole launch is booked on the sweep)
+        if (se) { HIPCHK(hipEventRecord(se->ev[2], st)); se->has[1] = false; }   // (fused: the whole launch is booked on the sweep)
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, means, P,
                                  D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, acc_stats, costs,
                                  c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused));
@@ -897,6 +898,7 @@ extern "C" int sgpmp_profile_read(sgpmp_ctx* c, double* ms4, int64_t* launches) 
     for (auto& se : c->events) {
         HIPCHK(hipEventSynchronize(se.ev[4]));
         for (int k = 0; k < 4; ++k) {
+            if (!se.has[k]) continue;                    // (an interval without a kernel only holds event latency)
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, se.ev[k], se.ev[k + 1]));
             ms4[k] += ms;

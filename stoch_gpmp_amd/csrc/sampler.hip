@@ -21,6 +21,7 @@
 //   * tiles are flushed as whole row segments with VW-wide stores (16 B per lane when the row pitch
 //     allows), so a wave writes contiguous spans instead of 4-byte fragments 3.5 KB apart.
 #define SGPMP_SAMPLE_TC 16
+#define SGPMP_SAMPLE_PAD(n) ((n) > 4 ? 8 : 4)
 
 template <typename real, int VW>
 __global__ void __launch_bounds__(256)
@@ -41,7 +42,10 @@ sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*
     const int s = s0 + slw;
     const bool active = slw < spw && s < S;
     const int d = 2 * n;
-    const int pitch = TC * d + 4;                        // reals per tile row (padded, VW-aligned)
+    // reals per tile row: 16 d = 32 n is a multiple of the 32 banks, so the pad alone places consecutive sample
+    // rows in bank space -- n lanes wide each: 4 banks apart for n <= 4, 8 apart beyond (with 4, the rows of a
+    // 7-dof wave overlapped on 3 of their 7 banks: SQ_LDS_BANK_CONFLICT 3.8 M of 4.5 M LDS cycles in round 1)
+    const int pitch = TC * d + SGPMP_SAMPLE_PAD(n);
     real* tile = reinterpret_cast<real*>(lds_raw) + (size_t)wv * spw * pitch;     // this wave's rows
     const size_t M = (size_t)T * d;
     const real* mu = means + (size_t)m * M;
@@ -293,7 +297,7 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
         }
         const int wpb = waves < 4 ? waves : 4;
         dim3 grid((waves + wpb - 1) / wpb, n_modes), block(64 * wpb);
-        const size_t lds = (size_t)wpb * spw * (SGPMP_SAMPLE_TC * d + 4) * sizeof(real);
+        const size_t lds = (size_t)wpb * spw * (SGPMP_SAMPLE_TC * d + SGPMP_SAMPLE_PAD(n)) * sizeof(real);
         // widest store that every row segment start is aligned to: rows are T*d reals apart and
         // tiles start every 16*d reals; d is even
         const bool v16 = ((size_t)T * d * sizeof(real)) % 16 == 0;

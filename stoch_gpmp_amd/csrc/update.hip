@@ -91,6 +91,7 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double* w = reinterpret_cast<double*>(lds_raw);                  // [S] weights
     int* idx = reinterpret_cast<int*>(lds_raw + (size_t)S * 8);      // [S] samples with weight != 0
+    real* mu_lds = reinterpret_cast<real*>(lds_raw + (((size_t)S * 12 + 15) & ~(size_t)15));   // [M] new means (tail)
     __shared__ double scratch[8];
     __shared__ int nnz_s;
     const int p = blockIdx.x;
@@ -207,14 +208,15 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
         if (grad) *reinterpret_cast<vec*>(grad + (size_t)p * M + m) = g;
         if (means_prev) *reinterpret_cast<vec*>(means_prev + (size_t)p * M + m) = mu_m;
         *reinterpret_cast<vec*>(mu + m) = mn;
+        if (nx.out) *reinterpret_cast<vec*>(mu_lds + m) = mn;
     }
     // The NEXT iteration's importance-sampling weights, from the means just written (K5's arithmetic, same
     // function): sgpmp_step then starts with the sampler + sweep launch instead of a K5 launch, provided the
     // caller vouches that nobody touched the means in between (SGPMP_STEP_MEANS_KEPT).
     if (nx.out) {
-        __syncthreads();                                  // this workgroup's mean stores are visible to it
+        __syncthreads();                                  // the new means of this particle are in LDS
         const int d = 2 * nx.n, Tn = M / d;
-        const real* mu_new = mu;
+        const real* mu_new = mu_lds;
         for (int e = threadIdx.x; e < (Tn + 1) * d; e += blockDim.x)
             nx.out[(size_t)p * (Tn + 1) * d + e] = is_weight_elem<real>(nx.n, Tn, mu_new, nx.Qinv, nx.ks, nx.kg, nx.dt,
                                                                          temperature, nx.isotropic, e);
@@ -226,7 +228,8 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                          void* weights, void* grad, void* means_prev, double* stats,
                          hipStream_t stream, hipEvent_t done, const PriorDev* isw_prior, void* isw_next) {
     const int M = T * 2 * n;
-    const size_t lds = (size_t)S * (sizeof(double) + sizeof(int));
+    size_t lds = (size_t)S * (sizeof(double) + sizeof(int));
+    if (isw_prior) lds = ((lds + 15) & ~(size_t)15) + (size_t)M * (dtype == SGPMP_F64 ? 8 : 4);   // + the new means
     if (P <= 0) return hipSuccess;
     dim3 grid(P), block(256);
     // `done` (multi-GPU statistics): the event is signalled by this kernel's own dispatch packet

@@ -56,10 +56,14 @@ def main(d):
             if ns and "SQ_ACTIVE_INST_VALU" in a and "GRBM_GUI_ACTIVE" in a:
                 clock_hz = a["GRBM_GUI_ACTIVE"] / 8.0 / (ns * 1e-9)
                 busy_s = a["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / clock_hz
+                cyc = a["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0
                 e.update({"avg_ns_under_stats": ns, "clock_ghz": clock_hz / 1e9, "valu_insts": a.get("SQ_INSTS_VALU"),
-                          "valu_floor_ms": busy_s * 1e3,
-                          "valu_floor_how": "SQ_ACTIVE_INST_VALU (quad-cycles, all SIMDs) x 4 / 1024 SIMDs / shader clock "
-                                            "(GRBM_GUI_ACTIVE / 8 / duration): the launch time at 100 % VALU issue"})
+                          "valu_busy_cycles_per_simd": cyc, "valu_busy_frac_under_profiler": busy_s / (ns * 1e-9),
+                          "valu_floor_ms": cyc / 2.4e9 * 1e3,
+                          "valu_floor_how": "SQ_ACTIVE_INST_VALU (quad-cycles, all SIMDs) x 4 / 1024 SIMDs = cycles each SIMD "
+                                            "spends issuing vector ALU work per launch; / 2.4 GHz (the MI355X maximum clock) = "
+                                            "the launch time at 100 % VALU issue and full clock -- a box-independent floor "
+                                            "(under the profiler the shader ran at clock_ghz = GRBM_GUI_ACTIVE / 8 / duration)"})
             kernels[base(k)] = e
     json.dump({"note": "HBM traffic per launch from rocprofv3 --pmc passes on MI355X (separate passes: "
                        "FETCH_SIZE, WRITE_SIZE; KiB as reported). gfx950 correction per MI355X_MICROARCH.md: "
