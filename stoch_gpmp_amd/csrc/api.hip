@@ -66,6 +66,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"no_chain_codegen", &SgpmpToggles::no_chain_codegen}, {"no_dual_sweep", &SgpmpToggles::no_dual_sweep},
     {"k3_no_one", &SgpmpToggles::k3_no_one}, {"k3_no_lds_prefetch", &SgpmpToggles::k3_no_lds_prefetch},
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
+    {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {

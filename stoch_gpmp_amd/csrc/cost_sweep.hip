@@ -610,6 +610,35 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
                                   (!F.has_goal || F.goal.rows_per_goal % 2 == 0);
             const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
             const bool sph_ok = !F.has_sph || n_spheres <= SGPMP_SPH_LDS;
+            // chunked sweep (fused_step.inc, phase C alone on existing samples): 8 rows of one particle and goal
+            // per wave, 16 waypoints per chunk -- fewer instructions per waypoint than the 64-lane passes below
+            const bool chunk_ok = flat && !F.has_grid && sph_ok && !tg.no_dual_sweep && !tg.no_chunked_sweep &&
+                                  batch % SGPMP_FUSED_SPW == 0 && batch_offset % SGPMP_FUSED_SPW == 0 &&
+                                  T % SGPMP_FUSED_TC == 0 && n_spheres <= SGPMP_FUSED_SPH &&
+                                  (!isw || a.rows_per_particle % SGPMP_FUSED_SPW == 0) &&
+                                  (!F.has_goal || (F.goal.rows_per_goal % SGPMP_FUSED_SPW == 0 && F.goal.dim0 <= SGPMP_FUSED_GOALS)) &&
+                                  (!F.has_gp || a.is_dt == F.gp.dt || !isw);
+            if (chunk_ok) {
+                FusedArgs fs;
+                std::memset(&fs, 0, sizeof(fs));
+                fs.gpp = 1; fs.gpp_shift = 0;
+                long long cblocks = (batch / SGPMP_FUSED_SPW + 3) / 4;
+                long long ccap = 1LL << 18;
+                if (tg.k3_blocks > 0) ccap = tg.k3_blocks;
+                if (cblocks > ccap) cblocks = ccap;
+                const int cft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
+                if (cft == SGPMP_FIELD_RBF)
+                    hipLaunchKernelGGL((cost_sweep_chunked_kernel<ChainCode_panda::N, ChainCode_panda, SGPMP_FIELD_RBF>),
+                                       dim3((unsigned)cblocks), dim3(256), 0, stream, a, F, fs);
+                else if (cft == SGPMP_FIELD_SDF)
+                    hipLaunchKernelGGL((cost_sweep_chunked_kernel<ChainCode_panda::N, ChainCode_panda, SGPMP_FIELD_SDF>),
+                                       dim3((unsigned)cblocks), dim3(256), 0, stream, a, F, fs);
+                else
+                    hipLaunchKernelGGL((cost_sweep_chunked_kernel<ChainCode_panda::N, ChainCode_panda, SGPMP_FIELD_OCCUPANCY>),
+                                       dim3((unsigned)cblocks), dim3(256), 0, stream, a, F, fs);
+                *picked = "cost_sweep_chunked_kernel";
+                return hipGetLastError();
+            }
             if (flat && !F.has_grid && pairs_ok && sph_ok && !tg.no_dual_sweep) {
                 long long pblocks = ((batch + 1) / 2 + 3) / 4;
                 long long pcap = 256LL * 20;          // 20 workgroups per CU (4 resident): measured optimum (tools/k3_grid_sweep.sh)

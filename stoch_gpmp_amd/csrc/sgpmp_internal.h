@@ -105,6 +105,7 @@ struct SgpmpToggles {
     int k3_no_lds_prefetch;   // SGPMP_K3_NO_LDS_PREFETCH   register-held prefetch
     int no_small_sampler;     // SGPMP_NO_SMALL_SAMPLER     standard sampler for tiny launches
     int no_fused_step;        // SGPMP_NO_FUSED_STEP        K2 and K3 as separate kernels inside sgpmp_step
+    int no_chunked_sweep;     // SGPMP_NO_CHUNKED_SWEEP     64-lane-pass two-trajectory sweeps instead of the chunked one
     long long k3_blocks;      // SGPMP_K3_BLOCKS            workgroup cap of the dual sweep (0: default)
 };
 

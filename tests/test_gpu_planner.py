@@ -209,8 +209,10 @@ def _fp32_panda_run(T, nppg, S, iters, goals=None, field_type='rbf', n_sph=5, se
     eps0 = torch.from_numpy(native_eps(seed, 0, range(G), nppg, T, n, "float32")).double()
     ora = SC.oracle_panda_planner(c, T, nppg, S, seed=seed, eps_init=eps0, goals=goals, field_type=field_type)
     pl = hip_panda_planner(c, T, nppg, S, F32, seed=seed, goals=goals, field_type=field_type)
-    if not fused:
+    if fused != True:
         pl._engine.set_option("no_fused_step", 1)        # sampler and sweep as two launches
+    if fused == "dual":
+        pl._engine.set_option("no_chunked_sweep", 1)     # ... and the 64-lane-pass two-trajectory sweep
     assert rel_err(pl.particle_means, ora.particle_means) < 2e-5
     pl.particle_means.copy_(ora.particle_means.to(**F32))
     scale = float(ora.particle_means.abs().max())
@@ -251,7 +253,8 @@ def _report(tag, recs):
     return frac
 
 
-@pytest.mark.parametrize("fused,kernel", [(True, "fused_step_kernel"), (False, "cost_sweep_dual_pf_kernel")])
+@pytest.mark.parametrize("fused,kernel", [(True, "fused_step_kernel"), ("chunked", "cost_sweep_chunked_kernel"),
+                                          ("dual", "cost_sweep_dual_pf_kernel")])
 def test_panda_fp32_headline_kernel_means_match_fp64_oracle(fused, kernel):
     """north_star: fp32 trajectory means within 1e-3 of the reference CPU path.  The headline kernels
     (the fused sampler + sweep launch, and cost_sweep_dual_pf_kernel behind the separate sampler: even
@@ -264,7 +267,8 @@ def test_panda_fp32_headline_kernel_means_match_fp64_oracle(fused, kernel):
     assert frac >= 0.99, frac                          # measured on MI355X: 1.0000 (arg-min identical for every particle)
 
 
-@pytest.mark.parametrize("fused,kernel", [(True, "fused_step_kernel"), (False, "cost_sweep_dual_pf_multi_kernel")])
+@pytest.mark.parametrize("fused,kernel", [(True, "fused_step_kernel"), ("chunked", "cost_sweep_chunked_kernel"),
+                                          ("dual", "cost_sweep_dual_pf_multi_kernel")])
 def test_panda_fp32_config5_kernel_means_match_fp64_oracle(fused, kernel):
     """BASELINE config 5 in its stated precision and in miniature: 2 goals, T = 128 (eight 16-waypoint
     chunks of the fused launch / two passes of cost_sweep_dual_pf_multi_kernel with the carried
@@ -602,6 +606,9 @@ def test_config5_share_fast_sweep_equals_generic_sweep(field_type):
     w = pl._engine.is_weights(pl._means_prev, pl.temperature)     # weights of the PRE-update means, as in the step
     sphc = sph.reshape(-1, 4).contiguous()
     kw = dict(batch_offset=pl.p0 * S, spheres=sphc, is_weights=w, rows_per_particle=S)
+    chunked = pl._engine.cost_eval(samples, **kw).clone()
+    assert pl._engine.last_cost_kernel() == "cost_sweep_chunked_kernel"
+    pl._engine.set_option("no_chunked_sweep", 1)
     fast = pl._engine.cost_eval(samples, **kw).clone()
     assert pl._engine.last_cost_kernel() == "cost_sweep_dual_pf_multi_kernel"
     pl._engine.set_option("no_dual_sweep", 1)
@@ -610,9 +617,11 @@ def test_config5_share_fast_sweep_equals_generic_sweep(field_type):
     assert pl._engine.last_cost_kernel() == "cost_sweep_kernel<f32, generic FK>"
     rel = ((fast.double() - slow.double()).abs() / slow.double().abs().clamp_min(1.0)).max()
     assert fast.shape == (512 * S,) and bool(torch.isfinite(fast).all()) and float(rel) < 2e-5, float(rel)
-    # ... and the fused launch (sampler + sweep in one kernel) agrees with both on every trajectory
+    # ... and the fused launch (sampler + sweep in one kernel) and the chunked sweep agree with both on
+    # every trajectory (the chunked sweep IS the fused launch's phase C: bit-identical costs)
     rel = ((step_costs.reshape(-1).double() - slow.double()).abs() / slow.double().abs().clamp_min(1.0)).max()
     assert float(rel) < 2e-5, float(rel)
+    assert torch.equal(chunked, step_costs.reshape(-1))
 
 
 def test_full_size_planar_fused_step_equals_separate_calls(golden):
@@ -650,6 +659,10 @@ def test_full_size_fast_sweep_equals_generic_sweep(field_type):
     samples = pl.state_samples
     w = pl._engine.is_weights(pl._means_prev, pl.temperature)     # weights of the PRE-update means, as in the step
     sphc = sph.reshape(-1, 4).contiguous()
+    chunked = pl._engine.cost_eval(samples, spheres=sphc, is_weights=w, rows_per_particle=S).clone()
+    assert pl._engine.last_cost_kernel() == "cost_sweep_chunked_kernel"
+    assert torch.equal(chunked, step_costs.reshape(-1))      # the chunked sweep IS the fused launch's phase C
+    pl._engine.set_option("no_chunked_sweep", 1)
     fast = pl._engine.cost_eval(samples, spheres=sphc, is_weights=w, rows_per_particle=S).clone()
     assert pl._engine.last_cost_kernel() == "cost_sweep_dual_pf_kernel"
     pl._engine.set_option("no_dual_sweep", 1)
