@@ -494,25 +494,39 @@ static bool make_flat(const CostProgram& p, FlatProg<real>& f) {
 #include "cost_sweep_kernel.inc"
 #include "cost_sweep_dual.inc"
 #include "fused_step.inc"
+#include "fused_planar.inc"
 
-// Does a step qualify for the fused launch (fused_step.inc)?
+// Does a step qualify for a fused launch?  1: chain-code program (fused_step.inc), 2: program without forward
+// kinematics (fused_planar.inc), 0: no.
+static int fused_step_kind(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
+                           const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
+                           const SgpmpToggles& tg) {
+    using CCp = ChainCode_panda;
+    if (dtype != SGPMP_F32 || tg.no_fused_step || !prior.isotropic) return 0;
+    if (S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0 || P < 1) return 0;
+    if ((long long)P * S + (long long)mode_offset * S >= (1LL << 31)) return 0;
+    FlatProg<float> F;
+    if (tg.no_flat_program || !make_flat<float>(h_prog, F)) return 0;
+    if (F.has_goal && (F.goal.rows_per_goal % SGPMP_FUSED_SPW != 0 || F.goal.dim0 > SGPMP_FUSED_GOALS)) return 0;
+    if (F.has_gp && (float)prior.dt != F.gp.dt) return 0;                 // IS term and GP factors share Phi
+    if (!h_prog.needs_fk && h_prog.n_ee == 0) {
+        // no link fields: GP / goal prior / occupancy grid on the positions themselves
+        if (F.has_self || F.has_sph || (n != 2 && n != 3) || T > SGPMP_PLANAR_TMAX) return 0;
+        if (F.has_grid && n < 2) return 0;
+        return 2;
+    }
+    if (tg.no_dual_sweep || tg.no_chain_codegen || tg.force_generic_fk) return 0;
+    if (n != CCp::N || !h_chain.plan.fast || h_chain.plan.codegen_id != 1 || F.has_grid) return 0;
+    if (n_spheres > SGPMP_FUSED_SPH) return 0;
+    for (int i = 0; i < h_prog.n_terms; ++i)
+        if (h_prog.terms[i].n_interp > 0) return 0;
+    return 1;
+}
+
 bool fused_step_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                          const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
                          const SgpmpToggles& tg) {
-    using CCp = ChainCode_panda;
-    if (dtype != SGPMP_F32 || tg.no_fused_step || tg.no_dual_sweep || tg.no_chain_codegen || tg.force_generic_fk ||
-        tg.no_flat_program)
-        return false;
-    if (!prior.isotropic || n != CCp::N || !h_chain.plan.fast || h_chain.plan.codegen_id != 1) return false;
-    if (S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0 || n_spheres > SGPMP_FUSED_SPH || P < 1) return false;
-    FlatProg<float> F;
-    if (!make_flat<float>(h_prog, F) || F.has_grid) return false;
-    for (int i = 0; i < h_prog.n_terms; ++i)
-        if (h_prog.terms[i].n_interp > 0) return false;
-    if (F.has_goal && (F.goal.rows_per_goal % SGPMP_FUSED_SPW != 0 || F.goal.dim0 > SGPMP_FUSED_GOALS)) return false;
-    if (F.has_gp && (float)prior.dt != F.gp.dt) return false;             // IS term and GP factors share Phi
-    if ((long long)P * S + (long long)mode_offset * S >= (1LL << 31)) return false;
-    return true;
+    return fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg) != 0;
 }
 
 // K2 + K3 in one launch when the step qualifies; *launched says whether it did.
@@ -523,8 +537,8 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                              hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched) {
     *launched = false;
     using CCp = ChainCode_panda;
-    if (!samples || !isw || !fused_step_eligible(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg))
-        return hipSuccess;
+    const int kind = (!samples || !isw) ? 0 : fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
+    if (kind == 0) return hipSuccess;
     FlatProg<float> F;
     make_flat<float>(h_prog, F);
     const long long batch = (long long)P * S, batch_offset = (long long)mode_offset * S;
@@ -549,6 +563,13 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     long long cap = 1LL << 18;
     if (tg.k3_blocks > 0) cap = tg.k3_blocks;
     if (blocks > cap) blocks = cap;
+    if (kind == 2) {
+        if (n == 2) hipLaunchKernelGGL((fused_planar_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);
+        else hipLaunchKernelGGL((fused_planar_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);
+        if (picked) *picked = "fused_planar_kernel";
+        *launched = true;
+        return hipGetLastError();
+    }
     const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
     if (ft == SGPMP_FIELD_RBF)
         hipLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_RBF>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);

@@ -383,6 +383,30 @@ def test_fused_step_corners_match_the_two_launch_path(nppg, G, S, T, field_type,
         b.particle_means.copy_(a.particle_means)
 
 
+@pytest.mark.parametrize("nppg,G,S,T,fused", [
+    (2, 2, 8, 16, True), (3, 2, 24, 48, True), (5, 1, 16, 128, True), (1, 4, 8, 32, True),
+    (2, 2, 12, 32, False),                    # S not a multiple of 8
+    (2, 2, 8, 24, False),                     # T not a multiple of 16
+])
+def test_planar_fused_corners_match_the_two_launch_path(golden, nppg, G, S, T, fused):
+    """The planar fused launch (fused_planar.inc) at its dispatch corners against sampler + generic sweep."""
+    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]][:G]
+    om = planar_map(golden, F32)
+    a = hip_planar_planner(SC.PLANAR, T, goals, nppg, S, om, F32, seed=31)
+    b = hip_planar_planner(SC.PLANAR, T, goals, nppg, S, om, F32, seed=31)
+    b._engine.set_option("no_fused_step", 1)
+    for it in range(3):
+        a.optimize()
+        b.optimize()
+        assert (a._engine.last_cost_kernel() == "fused_planar_kernel") == fused, a._engine.last_cost_kernel()
+        assert b._engine.last_cost_kernel() == "cost_sweep_kernel<f32, no FK>"
+        scale = float(b.state_samples.abs().max())
+        assert float((a.state_samples - b.state_samples).abs().max()) <= 4e-7 * scale
+        assert rel_err(a._costs, b._costs) < 2e-5
+        assert torch.equal(a._costs.argmin(1), b._costs.argmin(1))
+        b.particle_means.copy_(a.particle_means)
+
+
 def test_prepared_is_weights_follow_every_edit_of_the_means():
     """A fused step has its update kernel prepare the next step's importance-sampling weights, and the next
     sgpmp_step skips K5 when the caller vouches (SGPMP_STEP_MEANS_KEPT) that the means are untouched.  The
@@ -625,20 +649,33 @@ def test_config5_share_fast_sweep_equals_generic_sweep(field_type):
 
 
 def test_full_size_planar_fused_step_equals_separate_calls(golden):
-    """BASELINE config 2 shape (planar, 256 x 64 x 128, fp32): sgpmp_step == K5,K2,K3,K4 called one
-    by one through the reference-shaped methods (sample_and_eval + _update_distribution)."""
+    """BASELINE config 2 shape (planar, 256 x 64 x 128, fp32): sgpmp_step -- here the planar fused launch
+    (fused_planar.inc: noise, recurrence, GP / goal / grid / IS terms in one kernel) -- against K5, K2, K3, K4
+    called one by one through the reference-shaped methods (sample_and_eval + _update_distribution): same
+    noise keys, so the samples agree to the last bit or two, the costs to fp32 rounding and the arg-min
+    exactly; with the fused launch switched off the two routes are bit-identical."""
     goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
     om = planar_map(golden, F32)
     a = hip_planar_planner(SC.PLANAR, 128, goals, 64, 64, om, F32, seed=4)
     b = hip_planar_planner(SC.PLANAR, 128, goals, 64, 64, om, F32, seed=4)
+    c = hip_planar_planner(SC.PLANAR, 128, goals, 64, 64, om, F32, seed=4)
+    c._engine.set_option("no_fused_step", 1)
     assert torch.equal(a.particle_means, b.particle_means)
     for _ in range(3):
         a.optimize()
+        c.optimize()
         _, _, _, _, costs = b.sample_and_eval()
         b._update_distribution(costs, b.state_samples)
-    assert torch.equal(a.state_samples, b.state_samples)
-    assert torch.equal(a._costs, b._costs)
-    assert torch.equal(a.particle_means, b.particle_means)
+        assert a._engine.last_cost_kernel() == "fused_planar_kernel"
+        assert torch.equal(c.state_samples, b.state_samples) and torch.equal(c._costs, b._costs)
+        assert torch.equal(c.particle_means, b.particle_means)
+        scale = float(b.state_samples.abs().max())
+        assert float((a.state_samples - b.state_samples).abs().max()) <= 4e-7 * scale
+        assert rel_err(a._costs, b._costs) < 2e-5
+        assert torch.equal(a._costs.argmin(1), b._costs.argmin(1))
+        assert float((a.particle_means - b.particle_means).abs().max()) <= 1e-6 * scale
+        b.particle_means.copy_(a.particle_means)
+        c.particle_means.copy_(a.particle_means)
     # goal-directedness: every particle's last waypoint stays near its own goal (sigma_goal 1e-3)
     end = a.particle_means[:, -1, :2].reshape(4, 64, 2).cpu()
     assert float((end - torch.tensor(goals)[:, None, :2]).abs().max()) < 0.05
