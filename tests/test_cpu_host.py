@@ -264,3 +264,21 @@ def test_dense_linear_systems_match_the_oracle():
     e, H = gp.start_prior.get_error(trajs[:, [0]], calc_jacobian=True)
     assert e.shape == (4, 2 * n, 1) and torch.equal(H[0], torch.eye(2 * n, dtype=torch.float64))
 
+
+
+def test_bench_multi_gpu_launch_starts_ranks_and_relays_failure():
+    """`python bench.py --gpus 2` with no launcher around it starts its own ranks (torch.distributed.run)
+    from a parent that never touches the GPU, and relays the outcome: in this GPU-less container both
+    ranks fail at device selection, so the parent must come back (no hang) with a non-zero exit code and
+    without printing a JSON line."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert p.returncode == 0 and '"n_gpus": 2' in p.stdout
+    else:
+        assert p.returncode != 0
+        assert '"metric"' not in p.stdout
