@@ -14,8 +14,32 @@ struct Philox4 { uint32_t x, y, z, w; };
 
 __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                  uint32_t k0, uint32_t k1) {
+    // Rounds 1 and 2 are written with plain xors grouped so that everything WAVE-UNIFORM folds on the scalar
+    // unit: the callers key the noise with c2 = particle and c3 = draw, uniform per wave like the key, so in
+    // round 1 the product M1 * c2 and the terms (hi1 ^ k0), (c3 ^ k1) are scalar work (s_mul_hi_u32 / s_mul_i32 /
+    // s_xor), and in round 2 c1 = lo1 still is.  v_bitop3_b32 takes one scalar operand only: with two uniform
+    // inputs the compiler spent a v_mov per round on top of a v_mad_u64_u32 whose result every lane shared.
+    // Same integers as the textbook rounds below (Random123 known-answer vectors: tests/test_oracle_golden.py).
+    {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = (hi1 ^ k0) ^ c1;
+        const uint32_t n2 = (c3 ^ k1) ^ hi0;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = (c1 ^ k0) ^ hi1;
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 2; r < 10; ++r) {
         // one 32x32->64 multiply (v_mad_u64_u32) per product instead of separate lo / hi multiplies
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;

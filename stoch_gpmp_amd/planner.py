@@ -23,6 +23,7 @@ Additions over the reference API (all optional keyword arguments):
                              (what the gloo CPU tests exercise).
   step()                     one loop body, public (the reference only has it inline).
 """
+import itertools
 import time
 
 import torch
@@ -32,6 +33,9 @@ from .costs.factors.gp_factor import GPFactor
 from .costs.factors.unary_factor import UnaryFactor
 from .dist import allgather_means, allreduce_stats_async, shard_range
 from .engine import Engine
+
+
+_UNSEEDED = itertools.count()
 
 
 class StochGPMP:
@@ -76,8 +80,12 @@ class StochGPMP:
         if seed is not None:
             torch.manual_seed(seed)              # same global side effect as planner.py:48-49
         # unseeded planners must not all replay one stream: like the reference (which keeps drawing
-        # from torch's global generator) they take their key from that generator's current seed
-        self.seed = int(torch.initial_seed()) & ((1 << 63) - 1) if seed is None else int(seed)
+        # from torch's global generator) they take their key from that generator's current seed, and a
+        # process-wide counter keeps two unseeded planners of one process apart
+        if seed is None:
+            self.seed = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * next(_UNSEEDED)) & ((1 << 63) - 1)
+        else:
+            self.seed = int(seed)
 
         self.n_dof = n_dof
         self.d_state_opt = 2 * self.n_dof
