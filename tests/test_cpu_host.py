@@ -284,7 +284,7 @@ def test_bench_multi_gpu_launch_starts_ranks_and_relays_failure():
         assert '"metric"' not in p.stdout
 
 
-def test_hand_placed_lds_reads_are_not_touched_before_their_wait():
+def test_hand_placed_loads_are_not_touched_before_their_wait():
     """hipcc treats an inline-asm load's destination as written at the statement; the audit compiles the cost
     kernels to gfx950 assembly and checks that nothing reads or copies such a register before the wait."""
     import shutil
@@ -295,4 +295,4 @@ def test_hand_placed_lds_reads_are_not_touched_before_their_wait():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "6 kernels audited, 0 offending" in r.stdout
+    assert re.search(r"8 kernels audited, \d+ hand-placed loads, 0 offending", r.stdout), r.stdout

@@ -1,12 +1,12 @@
-"""Audit of the hand-placed LDS reads of the chunked kernels (fused_step.inc).
+"""Audit of the hand-placed loads of the chunked kernels (fused_step.inc, fused_planar.inc).
 
-Their destinations count as written at the asm statement, so hipcc may read or copy them before the data has
-landed (MI355X guide 5.7: "forms (ii)/(iii) pin order, not register allocation").  This script compiles
-cost_sweep.hip to assembly and checks, for every fused_step_kernel / cost_sweep_chunked_kernel variant, that
-between the first hand-placed `ds_read2_b32` of a chunk and the hand-placed `s_waitcnt lgkmcnt(0)` that covers
-them no instruction reads or writes one of their destination registers (a copy made there would capture the
-register before the data has landed -- seen once with global loads, see the sphere-loop comment in
-fused_step.inc).  Exit code 0 = clean.   usage: audit_asm_loads.py [file.s]"""
+An inline-asm load's destination counts as written at the asm statement, so hipcc may read or copy it before
+the data has landed (MI355X guide 5.7: "forms (ii)/(iii) pin order, not register allocation"; seen once with
+global loads, see the sphere-loop comment in fused_step.inc).  This script compiles cost_sweep.hip to gfx950
+assembly and, for every fused_step_kernel / cost_sweep_chunked_kernel / fused_planar_kernel variant, walks the
+control-flow graph from each hand-placed `ds_read2_b32` / `global_load_dword` to the hand-placed `s_waitcnt`
+that covers it (lgkmcnt resp. vmcnt) on every path, and reports any instruction on the way that reads or writes
+the load's destination registers.  Exit code 0 = clean.   usage: audit_asm_loads.py [file.s]"""
 import os
 import re
 import subprocess
@@ -14,6 +14,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = r"fused_step_kernel|cost_sweep_chunked_kernel|fused_planar_kernel"
 
 
 def listing():
@@ -26,47 +27,78 @@ def listing():
     return open(out).read()
 
 
+def vregs(operands):
+    used = {int(x) for x in re.findall(r"\bv(\d+)\b", operands)}
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", operands):
+        used.update(range(int(a), int(b) + 1))
+    return used
+
+
+def parse(body):
+    """-> instructions [(text, in_asm)], label -> instruction index"""
+    ins, labels, in_asm = [], {}, False
+    for l in body:
+        t = l.strip()
+        if "#ASMSTART" in t:
+            in_asm = True
+        elif "#ASMEND" in t:
+            in_asm = False
+        elif re.match(r"^\.?\w+:", l):
+            labels[l.split(":")[0]] = len(ins)
+        elif l.startswith("\t") and t and not t.startswith((";", ".")):
+            ins.append((t.split(";")[0].strip(), in_asm))
+    return ins, labels
+
+
+def successors(ins, labels, i):
+    op, _, rest = ins[i][0].partition(" ")
+    if op == "s_endpgm":
+        return []
+    if op == "s_branch":
+        return [labels[rest.strip()]]
+    if op.startswith("s_cbranch"):
+        return [labels[rest.strip()], i + 1]
+    return [i + 1] if i + 1 < len(ins) else []
+
+
+def audit(name, body):
+    ins, labels = parse(body)
+    bad = groups = 0
+    for i, (t, in_asm) in enumerate(ins):
+        if not in_asm:
+            continue
+        m = re.match(r"(ds_read2_b32|global_load_dword)\s+(v\[\d+:\d+\]|v\d+)", t)
+        if not m:
+            continue
+        counter = "lgkmcnt" if m.group(1).startswith("ds_") else "vmcnt"
+        dest = vregs(m.group(2))
+        groups += 1
+        seen, todo = set(), successors(ins, labels, i)
+        while todo:
+            j = todo.pop()
+            if j in seen:
+                continue
+            seen.add(j)
+            u, u_asm = ins[j]
+            if u_asm and u.startswith("s_waitcnt") and counter in u:
+                continue                                    # covered on this path
+            op, _, rest = u.partition(" ")
+            if vregs(rest) & dest and not (u_asm and u == t):
+                print(f"{name}: '{u}' touches the destination of '{t}' before its wait")
+                bad += 1
+                continue
+            todo.extend(successors(ins, labels, j))
+    return groups, bad
+
+
 def main():
     text = listing()
-    bad = 0
-    kernels = 0
-    for m in re.finditer(r"^(_Z\w*(?:fused_step_kernel|cost_sweep_chunked_kernel)\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
-        name, body = m.group(1), m.group(2).split("\n")
-        # the hand-placed statements sit between ;;#ASMSTART / ;;#ASMEND markers
-        in_asm, asm_loads, asm_wait = False, [], None
-        for i, l in enumerate(body):
-            if "#ASMSTART" in l:
-                in_asm = True
-            elif "#ASMEND" in l:
-                in_asm = False
-            elif in_asm and "ds_read2_b32" in l:
-                asm_loads.append(i)
-            elif in_asm and "s_waitcnt lgkmcnt(0)" in l and asm_loads and asm_wait is None:
-                asm_wait = i
-        assert asm_loads and asm_wait is not None and asm_wait > asm_loads[-1], name
-        kernels += 1
-        # registers the hand-placed loads write: touching one before the wait is the bug
-        dest = set()
-        for i in asm_loads:
-            m = re.search(r"ds_read2_b32\s+v\[(\d+):(\d+)\]", body[i])
-            assert m, body[i]
-            dest.update(range(int(m.group(1)), int(m.group(2)) + 1))
-        for l in body[asm_loads[0]:asm_wait + 1]:
-            t = l.strip()
-            if not l.startswith("\t") or t.startswith((";", ".")):
-                continue
-            op, _, rest = t.partition(" ")
-            if op.startswith("s_") or "ds_read2_b32" in op and l in [body[i] for i in asm_loads]:
-                continue
-            used = set()
-            for m in re.finditer(r"\bv(\d+)\b", rest):
-                used.add(int(m.group(1)))
-            for m in re.finditer(r"\bv\[(\d+):(\d+)\]", rest):
-                used.update(range(int(m.group(1)), int(m.group(2)) + 1))
-            if used & dest:
-                print(f"{name}: '{t}' touches a pair-load destination before its wait")
-                bad += 1
-    print(f"{kernels} kernels audited, {bad} offending instructions")
+    kernels = groups = bad = 0
+    for m in re.finditer(r"^(_Z\w*(?:%s)\w*):[^\n]*\n(.*?)^\.Lfunc_end" % KERNELS, text, re.S | re.M):
+        g, b = audit(m.group(1), m.group(2).split("\n"))
+        assert g, m.group(1)
+        kernels, groups, bad = kernels + 1, groups + g, bad + b
+    print(f"{kernels} kernels audited, {groups} hand-placed loads, {bad} offending instructions")
     return 1 if bad or kernels == 0 else 0
 
 
