@@ -72,6 +72,18 @@ def main(d):
                "workload": "panda P=1024 S=128 T=64 f32 rbf", "kernels": kernels},
               open(os.path.join(d, "traffic.json"), "w"), indent=1)
     print(json.dumps(kernels, indent=1))
+    # Matrix-core use per kernel (north_star: MFMA only inside the GP factor): every kernel with its MFMA
+    # instruction count and busy cycles per launch, zeros included.
+    mf = [(short(k), a) for k, a in avg.items() if any("MFMA" in c for c in a)]
+    if mf:
+        rows = ["kernel | SQ_INSTS_MFMA | SQ_VALU_MFMA_BUSY_CYCLES | SQ_INSTS_VALU_MFMA_F64 | SQ_INSTS_VALU_MFMA_MOPS_F64 | SQ_INSTS_VALU_MFMA_F32"]
+        for name, a in sorted(mf):
+            rows.append(" | ".join([name] + [f"{a[c]:.6g}" if c in a else "-" for c in
+                                            ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_F64",
+                                             "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_INSTS_VALU_MFMA_F32")]))
+        open(os.path.join(d, "mfma_summary.txt"), "w").write("\n".join(rows) + "\n")
+        print("== MFMA counters per launch ==")
+        print("\n".join(rows))
 
 
 if __name__ == "__main__":
