@@ -150,6 +150,8 @@ def other_configs(torch, dev):
         ("config 1: planar 4 x 16 x 64, fp64", dict(workload="planar", P_local=4, S=16, T=64, dtype=f64, goals=2), 300),
         ("config 2: planar 256 x 64 x 128, fp32", dict(workload="planar", P_local=256, S=64, T=128, dtype=f32, goals=4), 300),
         ("config 3 with the sdf sphere field", dict(workload="panda", P_local=1024, S=128, T=64, dtype=f32, field="sdf"), 100),
+        ("config 3 with 64 sphere obstacles (SURVEY 8d stress variant)",
+         dict(workload="panda", P_local=1024, S=128, T=64, dtype=f32, spheres=64), 40),
         ("config 5 share: Panda 4 goals, 512 of 4096 particles x 256 x 128, fp32 (shard 3 of 8)",
          dict(workload="panda", P_local=512, S=256, T=128, dtype=f32, goals=4, shard_of=(3, 8)), 60),
     ]

@@ -354,8 +354,9 @@ def test_api_surface_and_errors(golden):
     (3, 1, 8, 16, "rbf", 5, True),            # smallest: one item per particle, one chunk
     (3, 2, 24, 48, "sdf", 9, True),           # two goals, three items per particle (not a power of two), three chunks
     (5, 1, 16, 32, "occupancy", 1, True),
-    (2, 1, 8, 80, "rbf", 32, True),           # five chunks, the sphere-staging limit of the fused launch
-    (2, 1, 8, 32, "rbf", 33, False),          # one sphere too many -> sampler + two-trajectory sweep
+    (2, 1, 8, 80, "rbf", 64, True),           # five chunks, the sphere-staging limit of the fused launch
+    (2, 1, 8, 32, "sdf", 64, True),
+    (2, 1, 8, 32, "rbf", 65, False),          # one sphere too many -> sampler + two-trajectory sweep
     (2, 1, 12, 32, "rbf", 5, False),          # S not a multiple of 8
     (2, 1, 8, 24, "rbf", 5, False),           # T not a multiple of 16
 ])
