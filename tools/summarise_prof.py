@@ -77,7 +77,7 @@ def main(d):
     mf = [(short(k), a) for k, a in avg.items() if any("MFMA" in c for c in a)]
     if mf:
         rows = ["kernel | SQ_INSTS_MFMA | SQ_VALU_MFMA_BUSY_CYCLES | SQ_INSTS_VALU_MFMA_F64 | SQ_INSTS_VALU_MFMA_MOPS_F64 | SQ_INSTS_VALU_MFMA_F32"]
-        for name, a in sorted(mf):
+        for name, a in sorted(mf, key=lambda t: t[0]):
             rows.append(" | ".join([name] + [f"{a[c]:.6g}" if c in a else "-" for c in
                                             ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_F64",
                                              "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_INSTS_VALU_MFMA_F32")]))
