@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--field", default="rbf", choices=["rbf", "sdf", "occupancy"])
     ap.add_argument("--spheres", type=int, default=5, help="number of sphere obstacles (panda; 64 = stress variant)")
     ap.add_argument("--goals", type=int, default=1, help="panda: number of goals (config 5: 4)")
+    ap.add_argument("--single-iteration-calls", action="store_true",
+                    help="time K calls of optimize(opt_iters=1) instead of one optimize(opt_iters=K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=4)
@@ -130,13 +132,24 @@ def kernel_profile(torch, pl, obs, steps):
     return {k: v / launches for k, v in kms.items()}
 
 
-def time_loop(torch, pl, obs, steps, warmup, barrier=None):
-    for _ in range(warmup):
-        pl.optimize(opt_iters=1, **obs)
+def time_loop(torch, pl, obs, steps, warmup, barrier=None, one_call=True):
+    """W warm-up iterations, then exactly `steps` timed iterations between two barriers.  one_call: the loop of
+    the reference itself, `optimize(opt_iters=steps)` (planner.py:289-299) -- nobody looks at the buffers between
+    its iterations, so the context may run them as two particle-half chains; else `steps` calls of
+    optimize(opt_iters=1), each returning its own tensors (one chain by construction)."""
+    if one_call:
+        if warmup:
+            pl.optimize(opt_iters=warmup, **obs)
+    else:
+        for _ in range(warmup):
+            pl.optimize(opt_iters=1, **obs)
     (barrier or torch.cuda.synchronize)()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        pl.optimize(opt_iters=1, **obs)
+    if one_call:
+        pl.optimize(opt_iters=steps, **obs)
+    else:
+        for _ in range(steps):
+            pl.optimize(opt_iters=1, **obs)
     (barrier or torch.cuda.synchronize)()
     return time.perf_counter() - t0
 
@@ -158,10 +171,13 @@ def other_configs(torch, dev):
     out = []
     for label, spec, steps in specs:
         pl, obs, name = build_planner(torch, dev=dev, **spec)
+        time_loop(torch, pl, obs, steps, 10, one_call=False)     # (clock warm-up: the first loop on a config runs slow)
         el = time_loop(torch, pl, obs, steps, 10)
+        el1 = time_loop(torch, pl, obs, steps, 10, one_call=False)
         kms = kernel_profile(torch, pl, obs, min(steps, 30))
         out.append({"config": label, "workload": name, "iterations_per_s": steps / el,
-                    "ms_per_step": 1e3 * el / steps, "steps": steps, "kernel_ms_per_step": kms,
+                    "ms_per_step": 1e3 * el / steps, "steps": steps,
+                    "iterations_per_s_single_iteration_calls": steps / el1, "kernel_ms_per_step": kms,
                     "cost_kernel": pl._engine.last_cost_kernel(),
                     "dtype": "f32" if spec["dtype"] == f32 else "f64"})
         del pl
@@ -342,11 +358,15 @@ def main():
     kernel_profile(torch, pl, obs, 100)                   # (device warm-up for the pass itself)
     kms = kernel_profile(torch, pl, obs, 100)
     # Pass 2: W untimed warm-up steps, then EXACTLY K timed steps between barriers (the reported value)
-    elapsed = time_loop(torch, pl, obs, args.steps, args.warmup, barrier)
+    split0 = pl._engine.pipeline_split_steps()
+    elapsed = time_loop(torch, pl, obs, args.steps, args.warmup, barrier, one_call=not args.single_iteration_calls)
+    split_steps = pl._engine.pipeline_split_steps() - split0
+    # Pass 3 (reported beside it): the same K iterations as K optimize(opt_iters=1) calls
+    elapsed_calls = time_loop(torch, pl, obs, args.steps, args.warmup, barrier, one_call=False)
     if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_calls], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+        elapsed, elapsed_calls = float(t[0]), float(t[1])
     mean_cost, mean_min_cost = pl.global_stats()
 
     if rank == 0:
@@ -420,7 +440,17 @@ def main():
             "kernel_ms_per_step": kms,
             "passes": "1: 100 + 100 iterations with HIP events between the kernels, the second hundred kept "
                       "(kernel_ms_per_step, roofline); "
-                      "2: warm-up + timed steps (value, ms_per_step)",
+                      "2: optimize(opt_iters=W) untimed, then optimize(opt_iters=K) -- the reference's own loop, "
+                      "planner.py:289-299 -- between barriers (value, ms_per_step); "
+                      "3: the same as W + K calls of optimize(opt_iters=1) (single_iteration_calls)",
+            "loop": {"call": "optimize(opt_iters=1) x K" if args.single_iteration_calls else "optimize(opt_iters=K)",
+                     "steps_run_as_two_particle_half_chains": split_steps,
+                     "note": "inside one optimize() call nobody reads the buffers between iterations, so the context "
+                             "runs the call's iterations as two particle-half launch sequences on two streams of "
+                             "its own (sgpmp_pipeline_begin/_end): one half's update kernel runs under the other "
+                             "half's sampler + sweep launch; bit-identical results"},
+            "single_iteration_calls": {"iterations_per_s": world * args.steps / elapsed_calls,
+                                       "ms_per_step": 1e3 * elapsed_calls / args.steps},
             "iteration_roofline": {"algorithmic_bytes": iter_alg, "moved_bytes": iter_moved,
                                    "k4_rows_read": nnz_rows,
                                    "achieved_GBs": iter_alg / (ms_step * 1e-3) / 1e9,

@@ -118,7 +118,7 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
 /* Development switches (kernel-variant A/B, tests of the fallback paths).  Every switch has an
  * environment variable SGPMP_<NAME> that is read ONCE, in sgpmp_create; this call changes a switch
  * on a live context.  Names: force_generic_fk, no_flat_program, no_chain_codegen, no_dual_sweep,
- * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep (0/1) and k3_blocks
+ * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline (0/1) and k3_blocks
  * (count).
  * No reference counterpart. */
 int sgpmp_set_option(sgpmp_ctx* ctx, const char* name, long long value);
@@ -218,6 +218,22 @@ int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, in
                                       previous sgpmp_step left there: the importance-sampling weights that step's
                                       update kernel prepared for them are then used, and the K5 launch is skipped.
                                       Without the flag (or after anything else wrote the means) K5 runs. */
+
+/* The loop of planner.py:289-299 itself (`for opt_step in range(opt_iters)`), when its iterations follow each
+ * other without the caller looking at the buffers in between: bracket the sgpmp_step calls of one optimize() with
+ *     sgpmp_pipeline_begin(ctx, stream);  K x sgpmp_step(..., stream);  sgpmp_pipeline_end(ctx, stream);
+ * Particles are independent (every reduction of planner.py:263-275 runs over the samples of ONE particle), so
+ * inside the bracket the context runs each step as TWO launch sequences, one per half of its particle range, on two
+ * streams of its own: while one half's update kernel (latency-bound) runs, the other half's sampler + sweep launch
+ * keeps the chip busy, across iterations.  Every buffer passed to the steps belongs to the context until
+ * sgpmp_pipeline_end has returned, which makes `stream` wait for both sequences (stream-ordered like any other
+ * call: no host synchronisation); results are those of unbracketed steps, bit for bit.  Steps that do not qualify
+ * (not the fused launch, parity-mode noise, a communicator attached, fewer than 2 x 8192 trajectories) run as
+ * usual inside the bracket.  Switch: SGPMP_NO_STEP_PIPELINE / "no_step_pipeline". */
+int sgpmp_pipeline_begin(sgpmp_ctx* ctx, void* stream);
+int sgpmp_pipeline_end(sgpmp_ctx* ctx, void* stream);
+/* how many steps of this context ran as two chains so far (tests and bench.py report it) */
+long long sgpmp_pipeline_split_steps(sgpmp_ctx* ctx);
 
 /* ---- multi-GPU (one process per GPU; RCCL over xGMI) -------------------------------------------- */
 /* The reference is single-process and has no counterpart; these calls carry out SURVEY.md 8(e):

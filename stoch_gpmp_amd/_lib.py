@@ -58,6 +58,9 @@ SIGNATURES = {
     "sgpmp_stats_wait": (_I, [_P, _P, _P]),
     "sgpmp_allgather_means": (_I, [_P, _P, _P, _P]),
     "sgpmp_last_cost_kernel": (C.c_char_p, [_P]),
+    "sgpmp_pipeline_begin": (_I, [_P, _P]),
+    "sgpmp_pipeline_end": (_I, [_P, _P]),
+    "sgpmp_pipeline_split_steps": (C.c_longlong, [_P]),
     "sgpmp_set_prior": (_I, [_P, _I, _D, _D, _D, _D, C.POINTER(_D), _P]),
     "sgpmp_get_prior": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
     "sgpmp_set_prior_blocks": (_I, [_P, _I, _I, C.POINTER(_D), C.POINTER(_D), _P]),

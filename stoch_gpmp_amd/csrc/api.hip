@@ -28,6 +28,23 @@ static int fail(int code, const std::string& msg) {
 
 struct StepEvents { hipEvent_t ev[5]; bool has[4]; };    // has[k]: a kernel runs between ev[k] and ev[k+1]
 
+// Consecutive steps of one optimize() call as TWO chains (sgpmp_pipeline_begin .. sgpmp_pipeline_end): the particles
+// are independent (planner.py:263-275 reduces over the samples of one particle only), so the two halves of the
+// particle range each run their own launch sequence -- sampler + sweep, update, sampler + sweep, ... -- on a stream
+// of their own.  One chain leaves the chip idle while its update kernel runs (13.9 us of latency-bound work plus
+// two launch gaps in a 210 us iteration at config 3); with two chains the other half's sampler + sweep launch
+// fills that time (tools/two_chain_probe.py: 0.2161 -> 0.1975 ms per iteration).  Results are those of the
+// unsplit step bit for bit: the kernels see the same particles with the same global indices.
+struct StepPipe {
+    bool active = false;          // between _begin and _end
+    bool forked = false;          // the chains are ahead of the caller's stream
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
+    double* stats2 = nullptr;     // statistics slot of the second half [SGPMP_STAT_SHARDS][4]
+    double* last_stats = nullptr; // the caller's buffer the last split step accumulated half 0 into
+    long long split_steps = 0;    // steps run as two chains so far (tests, bench)
+};
+
 struct sgpmp_ctx {
     sgpmp_dims dims;
     int d, M;
@@ -58,6 +75,7 @@ struct sgpmp_ctx {
     const void* isw_means;        // the means buffer they belong to
     double isw_temperature;
     const char* last_cost_kernel; // name of the cost-sweep kernel the dispatcher picked last
+    StepPipe pipe;                // two-chain execution of consecutive steps (sgpmp_pipeline_begin / _end)
 };
 
 // name -> field of SgpmpToggles (environment variable = "SGPMP_" + upper-case name)
@@ -66,7 +84,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"no_chain_codegen", &SgpmpToggles::no_chain_codegen}, {"no_dual_sweep", &SgpmpToggles::no_dual_sweep},
     {"k3_no_one", &SgpmpToggles::k3_no_one}, {"k3_no_lds_prefetch", &SgpmpToggles::k3_no_lds_prefetch},
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
-    {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep},
+    {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {
@@ -219,6 +237,12 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     for (void* p : c->owned) hipFree(p);
     for (auto& se : c->events)
         for (auto& e : se.ev) hipEventDestroy(e);
+    for (int h = 0; h < 2; ++h) {
+        if (c->pipe.side[h]) { hipStreamSynchronize(c->pipe.side[h]); hipStreamDestroy(c->pipe.side[h]); }
+        if (c->pipe.join_ev[h]) hipEventDestroy(c->pipe.join_ev[h]);
+    }
+    if (c->pipe.fork_ev) hipEventDestroy(c->pipe.fork_ev);
+    hipFree(c->pipe.stats2);
     delete c;
 }
 
@@ -627,6 +651,99 @@ extern "C" int sgpmp_update(sgpmp_ctx* c, const void* costs, int costs_dtype, co
     return SGPMP_OK;
 }
 
+// ---- two-chain steps (StepPipe) ----------------------------------------------------------------------------
+static int pipe_fork(sgpmp_ctx* c, hipStream_t st) {
+    StepPipe& q = c->pipe;
+    if (q.forked) return SGPMP_OK;
+    HIPCHK(hipEventRecord(q.fork_ev, st));                       // everything the caller enqueued so far ...
+    for (int h = 0; h < 2; ++h) HIPCHK(hipStreamWaitEvent(q.side[h], q.fork_ev, 0));   // ... precedes both chains
+    q.forked = true;
+    return SGPMP_OK;
+}
+
+static int pipe_join(sgpmp_ctx* c, hipStream_t st) {
+    StepPipe& q = c->pipe;
+    if (!q.forked) return SGPMP_OK;
+    for (int h = 0; h < 2; ++h) {
+        HIPCHK(hipEventRecord(q.join_ev[h], q.side[h]));
+        HIPCHK(hipStreamWaitEvent(st, q.join_ev[h], 0));
+    }
+    if (q.last_stats) HIPCHK(launch_stats_add(q.last_stats, q.stats2, st));   // the step's statistics: both halves
+    q.last_stats = nullptr;
+    q.forked = false;
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_pipeline_begin(sgpmp_ctx* c, void* stream) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_pipeline_begin: null context");
+    StepPipe& q = c->pipe;
+    if (q.active) return fail(SGPMP_ESTATE, "sgpmp_pipeline_begin: already begun");
+    (void)stream;
+    if (!q.side[0]) {
+        for (int h = 0; h < 2; ++h) {
+            HIPCHK(hipStreamCreateWithFlags(&q.side[h], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&q.join_ev[h], hipEventDisableTiming));
+        }
+        HIPCHK(hipEventCreateWithFlags(&q.fork_ev, hipEventDisableTiming));
+        HIPCHK(hipMalloc(&q.stats2, sizeof(double) * SGPMP_STAT_SHARDS * 4));
+    }
+    q.active = true;
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_pipeline_end(sgpmp_ctx* c, void* stream) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_pipeline_end: null context");
+    if (!c->pipe.active) return SGPMP_OK;
+    c->pipe.active = false;
+    return pipe_join(c, (hipStream_t)stream);
+}
+
+// One step as two half-range launch sequences on the chains' own streams (see StepPipe).  The caller has checked
+// that both halves qualify for the fused launch.
+static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, char* samples, char* costs,
+                      char* weights, char* grad, char* means_prev, const void* spheres, int n_spheres,
+                      double temperature, double step_size, double* stats, int flags, hipStream_t st) {
+    const sgpmp_dims& D = c->dims;
+    const int P = D.num_particles, S = D.num_samples, P0 = P / 2;
+    const PriorDev& pr = c->prior[SGPMP_PRIOR_SAMPLE];
+    const size_t w = c->esz, M = (size_t)c->M, W = (size_t)(D.traj_len + 1) * c->d;
+    int rc;
+    if ((rc = pipe_fork(c, st)) != SGPMP_OK) return rc;
+    const bool prepared = (flags & SGPMP_STEP_MEANS_KEPT) && c->isw_ready && c->isw_means == (const void*)means &&
+                          c->isw_temperature == temperature;
+    c->isw_ready = false;
+    for (int h = 0; h < 2; ++h) {
+        const size_t off = h ? (size_t)P0 : 0;
+        const int Ph = h ? P - P0 : P0;
+        hipStream_t sh = c->pipe.side[h];
+        double* slot = stats ? (h ? c->pipe.stats2 : stats) : nullptr;
+        char* mu = means + off * M * w;
+        char* X = samples + off * S * M * w;
+        char* isw = (char*)c->d_isw + off * W * w;
+        char* cs = costs ? costs + off * S * w : nullptr;
+        double* c64 = c->d_costs64 + off * S;
+        if (!prepared) HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, mu, Ph, temperature, isw, slot, sh));
+        bool launched = false;
+        HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, mu, Ph,
+                                 D.particle_offset + (int)off, S, X, spheres, n_spheres, isw, slot, cs, c64, sh, c->tg,
+                                 &c->last_cost_kernel, &launched));
+        if (!launched) return fail(SGPMP_ESTATE, "sgpmp_step: a half of a pipelined step did not qualify for the fused launch");
+        for (int i = 0; i < c->h_prog.n_terms; ++i)
+            if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL)
+                HIPCHK(launch_ee_goal(D.dtype, D.n_dof, D.traj_len, c->h_prog.terms[i], c->d_chain, X,
+                                      (long long)Ph * S, cs, c64, sh));
+        HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, Ph, S, c64, SGPMP_F64, X, mu, temperature, step_size,
+                             weights ? weights + off * S * w : nullptr, grad ? grad + off * M * w : nullptr,
+                             means_prev ? means_prev + off * M * w : nullptr, slot, sh, nullptr, &pr, isw));
+    }
+    c->isw_ready = true; c->isw_means = means; c->isw_temperature = temperature;
+    c->pipe.last_stats = stats;
+    c->pipe.split_steps += 1;
+    return SGPMP_OK;
+}
+
+extern "C" long long sgpmp_pipeline_split_steps(sgpmp_ctx* c) { return c ? c->pipe.split_steps : 0; }
+
 extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void* eps, int eps_modes,
                           int eps_mode_offset, void* means, void* samples, void* costs, void* weights,
                           void* grad, void* means_prev, const void* spheres, int n_spheres, double temperature,
@@ -645,6 +762,21 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     if (eps && (eps_modes < 1 || eps_mode_offset < 0 || eps_mode_offset + P > eps_modes))
         return fail(SGPMP_EINVAL, "sgpmp_step: eps particle window out of range");
     hipStream_t st = (hipStream_t)stream;
+    const PriorDev& pr = c->prior[SGPMP_PRIOR_SAMPLE];
+    if (c->pipe.active) {
+        // both halves big enough to fill the chip on their own (256 workgroups of 4 items of 8 rows) and fused
+        const int P0 = P / 2;
+        const bool split = !eps && !c->comm && !c->profiling && !c->tg.no_step_pipeline &&
+                           (long long)P0 * S >= 256 * 4 * 8 &&
+                           fused_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P0, D.particle_offset,
+                                               S, n_spheres, c->tg) &&
+                           fused_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P - P0,
+                                               D.particle_offset + P0, S, n_spheres, c->tg);
+        if (split)
+            return step_split(c, seed, draw, (char*)means, (char*)samples, (char*)costs, (char*)weights, (char*)grad,
+                              (char*)means_prev, spheres, n_spheres, temperature, step_size, stats, flags, st);
+        if ((rc = pipe_join(c, st)) != SGPMP_OK) return rc;      // an ordinary step: after the chains
+    }
     StepEvents* se = nullptr;
     if (c->profiling) {
         c->events.emplace_back();
@@ -653,7 +785,6 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         for (bool& h : se->has) h = true;
         HIPCHK(hipEventRecord(se->ev[0], st));
     }
-    const PriorDev& pr = c->prior[SGPMP_PRIOR_SAMPLE];
     // multi-GPU: the step's statistics accumulate in a context-owned ring slot; their all-reduce (side
     // stream, enqueued at the end of the step) writes the sums over all ranks into the caller's `stats`
     double* acc_stats = stats;

@@ -106,6 +106,7 @@ struct SgpmpToggles {
     int no_small_sampler;     // SGPMP_NO_SMALL_SAMPLER     standard sampler for tiny launches
     int no_fused_step;        // SGPMP_NO_FUSED_STEP        K2 and K3 as separate kernels inside sgpmp_step
     int no_chunked_sweep;     // SGPMP_NO_CHUNKED_SWEEP     64-lane-pass two-trajectory sweeps instead of the chunked one
+    int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
     long long k3_blocks;      // SGPMP_K3_BLOCKS            workgroup cap of the dual sweep (0: default)
 };
 
@@ -165,6 +166,7 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                          hipStream_t stream, hipEvent_t done = nullptr, const PriorDev* isw_prior = nullptr,
                          void* isw_next = nullptr);
 
+hipError_t launch_stats_add(double* dst, const double* src, hipStream_t stream);
 hipError_t launch_ee_goal(int dtype, int n, int T, const CostTerm& term, const ChainDev* d_chain,
                           const void* trajs, long long batch, void* costs, double* costs64,
                           hipStream_t stream);

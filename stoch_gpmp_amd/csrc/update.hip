@@ -252,6 +252,16 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
     return hipGetLastError();
 }
 
+// statistics of the second particle half of a pipelined step (api.hip, StepPipe) added to the first half's
+__global__ void stats_add_kernel(double* __restrict__ dst, const double* __restrict__ src) {
+    if (threadIdx.x < SGPMP_STAT_SHARDS * 4) dst[threadIdx.x] += src[threadIdx.x];
+}
+
+hipError_t launch_stats_add(double* dst, const double* src, hipStream_t stream) {
+    hipLaunchKernelGGL(stats_add_kernel, dim3(1), dim3(SGPMP_STAT_SHARDS * 4), 0, stream, dst, src);
+    return hipGetLastError();
+}
+
 // K5: one thread per (particle, block row t in [0,T], component i).
 template <typename real>
 __global__ void is_weights_kernel(int n, int T, int P, const real* __restrict__ means,

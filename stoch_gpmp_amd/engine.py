@@ -46,6 +46,18 @@ class Engine:
         """Flip a development switch of this context (include/sgpmp.h: sgpmp_set_option)."""
         L.check(self.lib.sgpmp_set_option(self._ctx, name.encode(), int(value)))
 
+    def pipeline_begin(self):
+        """The steps that follow, up to pipeline_end(), may run as two particle-half chains on the context's own
+        streams (include/sgpmp.h: sgpmp_pipeline_begin); nothing else may touch their buffers meanwhile."""
+        L.check(self.lib.sgpmp_pipeline_begin(self._ctx, L.stream_ptr()))
+
+    def pipeline_end(self):
+        L.check(self.lib.sgpmp_pipeline_end(self._ctx, L.stream_ptr()))
+
+    def pipeline_split_steps(self):
+        """Steps of this context that ran as two chains so far."""
+        return int(self.lib.sgpmp_pipeline_split_steps(self._ctx))
+
     def last_cost_kernel(self):
         """Name of the cost-sweep kernel the dispatcher picked at the last launch."""
         return self.lib.sgpmp_last_cost_kernel(self._ctx).decode()

@@ -22,6 +22,9 @@ Additions over the reference API (all optional keyword arguments):
                              collective='torch' keeps the torch.distributed all-reduce instead
                              (what the gloo CPU tests exercise).
   step()                     one loop body, public (the reference only has it inline).
+  pipeline_steps=True        optimize(opt_iters >= 2) lets the context run the iterations of the call as two
+                             particle-half chains on streams of its own (one half's update kernel under the
+                             other half's sampler + sweep launch); same results, bit for bit.
 """
 import itertools
 import time
@@ -136,6 +139,8 @@ class StochGPMP:
         if self._collective not in ('rccl', 'torch'):
             raise ValueError("collective must be 'rccl' or 'torch'")
         self._comm_attached = False
+        # optimize(opt_iters >= 2) runs its iterations as two particle-half chains (sgpmp_pipeline_begin)
+        self.pipeline_steps = bool(kwargs.get('pipeline_steps', True))
 
         self.reset(start_state, multi_goal_states, initial_particle_means=initial_particle_means)
 
@@ -474,11 +479,24 @@ class StochGPMP:
             opt_iters = self.opt_iters
         start_time = time.time()
         costs = approx_grad = None
-        for opt_step in range(opt_iters):
-            start_time_iter = time.time()
-            costs, approx_grad = self.step(**observation)
-            if debug and opt_step % 50 == 0:
-                print_info(opt_step, opt_iters, start_time_iter, start_time, costs)
+        # Nobody looks at the buffers between the iterations of one call (the reference returns the last
+        # iteration's tensors only), so the context may run them as two particle-half chains on streams of its
+        # own -- one half's update kernel under the other half's sampler + sweep launch (include/sgpmp.h:
+        # sgpmp_pipeline_begin).  `debug` prints costs in between and therefore keeps the single chain.
+        piped = (opt_iters >= 2 and not debug and self._native_cost and self.noise == 'philox'
+                 and self.num_particles_local > 0 and self.pipeline_steps)
+        if piped:
+            self._spheres(observation)                   # (a first use copies on THIS stream: before the chains fork)
+            self._engine.pipeline_begin()
+        try:
+            for opt_step in range(opt_iters):
+                start_time_iter = time.time()
+                costs, approx_grad = self.step(**observation)
+                if debug and opt_step % 50 == 0:
+                    print_info(opt_step, opt_iters, start_time_iter, start_time, costs)
+        finally:
+            if piped:
+                self._engine.pipeline_end()
         state_particles, control_particles, state_trajectories, control_samples = self._views
         self._recent_control_samples = control_samples
         self._recent_control_particles = control_particles

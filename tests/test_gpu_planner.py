@@ -408,6 +408,65 @@ def test_planar_fused_corners_match_the_two_launch_path(golden, nppg, G, S, T, f
         b.particle_means.copy_(a.particle_means)
 
 
+@pytest.mark.parametrize("kind", ["panda", "panda_two_goals_sdf", "planar"])
+def test_pipelined_optimize_equals_single_steps_bitwise(golden, kind):
+    """optimize(opt_iters=K) runs its iterations as two particle-half chains on the context's own streams
+    (sgpmp_pipeline_begin / _end); a twin that takes the same iterations one optimize(opt_iters=1) at a time -- one
+    chain, every step on the caller's stream -- must end with the same bits in every buffer, through several calls,
+    a single-iteration call in between, moved obstacles and an edit of the means between two calls."""
+    if kind == "planar":
+        goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
+        om = planar_map(golden, F32)
+        mk = lambda **kw: hip_planar_planner(SC.PLANAR, 64, goals, 64, 64, om, F32, seed=41, **kw)   # noqa: E731
+        obs1 = obs2 = {}
+        name = "fused_planar_kernel"
+    else:
+        c, n = SC.PANDA, 7
+        two = kind != "panda"
+        g = [c["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n] if two else None
+        mk = lambda **kw: hip_panda_planner(c, 32, 64 if two else 129, 128, F32, seed=41, goals=g,   # noqa: E731
+                                            field_type="sdf" if two else "rbf", **kw)
+        obs1 = {"obstacle_spheres": torch.as_tensor(SC.panda_spheres(num=5, seed=3)).to(**F32)}
+        obs2 = {"obstacle_spheres": torch.as_tensor(SC.panda_spheres(num=9, seed=4)).to(**F32)}
+        name = "fused_step_kernel"
+    a, b = mk(), mk(pipeline_steps=False)
+
+    def same():
+        torch.cuda.synchronize()
+        for x, y in ((a.particle_means, b.particle_means), (a.state_samples, b.state_samples), (a._costs, b._costs),
+                     (a._weights_buf, b._weights_buf), (a._grad, b._grad), (a._means_prev, b._means_prev)):
+            assert torch.equal(x, y)
+        sa, sb = a.global_stats(), b.global_stats()
+        assert abs(sa[0] - sb[0]) <= 1e-12 * abs(sb[0]) and abs(sa[1] - sb[1]) <= 1e-12 * abs(sb[1])
+
+    def both(k, obs):
+        ra = a.optimize(opt_iters=k, **obs)
+        for _ in range(k):
+            rb = b.optimize(opt_iters=1, **obs)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y)
+
+    both(5, obs1)
+    assert a._engine.last_cost_kernel() == name
+    assert a._engine.pipeline_split_steps() == 5 and b._engine.pipeline_split_steps() == 0
+    same()
+    both(1, obs1)                                        # a single iteration: the ordinary step
+    assert a._engine.pipeline_split_steps() == 5
+    same()
+    both(4, obs2)                                        # other obstacles
+    same()
+    for pl in (a, b):                                    # the caller edits the means between two calls
+        pl.particle_means.mul_(0.999)
+    both(3, obs1)
+    assert a._engine.pipeline_split_steps() == 12
+    same()
+    # the switch: same planner, chains off
+    a._engine.set_option("no_step_pipeline", 1)
+    both(3, obs1)
+    assert a._engine.pipeline_split_steps() == 12
+    same()
+
+
 def test_prepared_is_weights_follow_every_edit_of_the_means():
     """A fused step has its update kernel prepare the next step's importance-sampling weights, and the next
     sgpmp_step skips K5 when the caller vouches (SGPMP_STEP_MEANS_KEPT) that the means are untouched.  The
