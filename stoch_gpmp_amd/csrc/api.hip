@@ -712,11 +712,18 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
     const bool prepared = (flags & SGPMP_STEP_MEANS_KEPT) && c->isw_ready && c->isw_means == (const void*)means &&
                           c->isw_temperature == temperature;
     c->isw_ready = false;
+    // multi-GPU: each chain accumulates into its block of a ring slot; the all-reduce (communicator's stream) waits
+    // for both update kernels, adds the blocks and writes the sums over all ranks into the caller's `stats`
+    const bool reduce = c->comm && stats;
+    double* slots[2] = {stats, stats ? c->pipe.stats2 : nullptr};
+    hipEvent_t k4_done[2] = {nullptr, nullptr};
+    if (reduce)
+        COMMCHK(comm_step_begin2(c->comm, c->pipe.side[0], c->pipe.side[1], &slots[0], &slots[1], &k4_done[0], &k4_done[1]));
     for (int h = 0; h < 2; ++h) {
         const size_t off = h ? (size_t)P0 : 0;
         const int Ph = h ? P - P0 : P0;
         hipStream_t sh = c->pipe.side[h];
-        double* slot = stats ? (h ? c->pipe.stats2 : stats) : nullptr;
+        double* slot = slots[h];
         char* mu = means + off * M * w;
         char* X = samples + off * S * M * w;
         char* isw = (char*)c->d_isw + off * W * w;
@@ -734,10 +741,11 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
                                       (long long)Ph * S, cs, c64, sh));
         HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, Ph, S, c64, SGPMP_F64, X, mu, temperature, step_size,
                              weights ? weights + off * S * w : nullptr, grad ? grad + off * M * w : nullptr,
-                             means_prev ? means_prev + off * M * w : nullptr, slot, sh, nullptr, &pr, isw));
+                             means_prev ? means_prev + off * M * w : nullptr, slot, sh, k4_done[h], &pr, isw));
     }
     c->isw_ready = true; c->isw_means = means; c->isw_temperature = temperature;
-    c->pipe.last_stats = stats;
+    if (reduce) COMMCHK(comm_step_end(c->comm, stats, true));
+    c->pipe.last_stats = reduce ? nullptr : stats;
     c->pipe.split_steps += 1;
     return SGPMP_OK;
 }
@@ -766,7 +774,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     if (c->pipe.active) {
         // both halves big enough to fill the chip on their own (256 workgroups of 4 items of 8 rows) and fused
         const int P0 = P / 2;
-        const bool split = !eps && !c->comm && !c->profiling && !c->tg.no_step_pipeline &&
+        const bool split = !eps && !c->profiling && !c->tg.no_step_pipeline &&
                            (long long)P0 * S >= 256 * 4 * 8 &&
                            fused_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P0, D.particle_offset,
                                                S, n_spheres, c->tg) &&
@@ -830,7 +838,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     if (fused) { c->isw_ready = true; c->isw_means = means; c->isw_temperature = temperature; }
     if (se) HIPCHK(hipEventRecord(se->ev[4], st));
     // multi-GPU: sum the statistics over all ranks on the side stream (never gates the next step)
-    if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats));
+    if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats, false));
     return SGPMP_OK;
 }
 

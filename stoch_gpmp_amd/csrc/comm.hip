@@ -65,8 +65,9 @@ struct SgpmpComm {
     // slot and writes the caller's buffer.  A slot comes round again SGPMP_COMM_RING steps later, so the
     // check that its all-reduce has finished is a host-side event query (practically always true) and the
     // main stream carries no wait; the "statistics complete" event rides on K4's own dispatch packet.
-    double* ring;                                            // [SGPMP_COMM_RING][SGPMP_STAT_SHARDS][4]
-    hipEvent_t ring_produced[SGPMP_COMM_RING], ring_reduced[SGPMP_COMM_RING];
+    double* ring;                                            // [SGPMP_COMM_RING][2][SGPMP_STAT_SHARDS][4]
+    // (second block of a slot, second event: the other particle half of a two-chain step, api.hip StepPipe)
+    hipEvent_t ring_produced[SGPMP_COMM_RING], ring_produced2[SGPMP_COMM_RING], ring_reduced[SGPMP_COMM_RING];
     bool ring_used[SGPMP_COMM_RING];
     unsigned long long step;
 };
@@ -108,9 +109,10 @@ const char* comm_create(const unsigned char* id128, int world, int rank, SgpmpCo
     if (r != ncclSuccess) { delete c; return g_rccl.GetErrorString(r); }
     bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&c->produced, kEventFlags) == hipSuccess &&
-              hipMalloc(&c->ring, sizeof(double) * SGPMP_COMM_RING * SGPMP_STAT_SHARDS * 4) == hipSuccess;
+              hipMalloc(&c->ring, sizeof(double) * SGPMP_COMM_RING * 2 * SGPMP_STAT_SHARDS * 4) == hipSuccess;
     for (int i = 0; ok && i < SGPMP_COMM_RING; ++i) {
         ok = hipEventCreateWithFlags(&c->ring_produced[i], kEventFlags) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ring_produced2[i], kEventFlags) == hipSuccess &&
              hipEventCreateWithFlags(&c->ring_reduced[i], kEventFlags) == hipSuccess;
         c->ring_used[i] = false;
     }
@@ -129,7 +131,9 @@ void comm_destroy(SgpmpComm* c) {
     hipStreamSynchronize(c->side);
     for (auto& p : c->reduced) hipEventDestroy(p.second);
     hipEventDestroy(c->produced);
-    for (int i = 0; i < SGPMP_COMM_RING; ++i) { hipEventDestroy(c->ring_produced[i]); hipEventDestroy(c->ring_reduced[i]); }
+    for (int i = 0; i < SGPMP_COMM_RING; ++i) {
+        hipEventDestroy(c->ring_produced[i]); hipEventDestroy(c->ring_produced2[i]); hipEventDestroy(c->ring_reduced[i]);
+    }
     hipFree(c->ring);
     hipStreamDestroy(c->side);
     if (c->comm) g_rccl.CommDestroy(c->comm);
@@ -160,17 +164,37 @@ const char* comm_step_begin(SgpmpComm* c, hipStream_t stream, double** slot, hip
     const int r = (int)(c->step % SGPMP_COMM_RING);
     if (c->ring_used[r] && hipEventQuery(c->ring_reduced[r]) != hipSuccess)
         if (hipStreamWaitEvent(stream, c->ring_reduced[r], 0) != hipSuccess) return "hipStreamWaitEvent failed";
-    *slot = c->ring + (size_t)r * SGPMP_STAT_SHARDS * 4;
+    *slot = c->ring + (size_t)r * 2 * SGPMP_STAT_SHARDS * 4;
     *k4_done = c->ring_produced[r];
+    return nullptr;
+}
+
+// The same for a step that runs as two particle-half chains (api.hip, StepPipe): each chain gets its own block
+// of the slot and its own "statistics complete" event.
+const char* comm_step_begin2(SgpmpComm* c, hipStream_t s0, hipStream_t s1, double** slot0, double** slot1,
+                             hipEvent_t* done0, hipEvent_t* done1) {
+    const int r = (int)(c->step % SGPMP_COMM_RING);
+    if (c->ring_used[r] && hipEventQuery(c->ring_reduced[r]) != hipSuccess)
+        if (hipStreamWaitEvent(s0, c->ring_reduced[r], 0) != hipSuccess ||
+            hipStreamWaitEvent(s1, c->ring_reduced[r], 0) != hipSuccess) return "hipStreamWaitEvent failed";
+    *slot0 = c->ring + (size_t)r * 2 * SGPMP_STAT_SHARDS * 4;
+    *slot1 = *slot0 + SGPMP_STAT_SHARDS * 4;
+    *done0 = c->ring_produced[r];
+    *done1 = c->ring_produced2[r];
     return nullptr;
 }
 
 // End a step (K4 launched with ring_produced[r] as its stop event): sum the slot over all ranks into the
 // caller's `stats` on the side stream.
-const char* comm_step_end(SgpmpComm* c, double* stats) {
+const char* comm_step_end(SgpmpComm* c, double* stats, bool two_halves) {
     const int r = (int)(c->step % SGPMP_COMM_RING);
+    double* slot = c->ring + (size_t)r * 2 * SGPMP_STAT_SHARDS * 4;
     if (hipStreamWaitEvent(c->side, c->ring_produced[r], 0) != hipSuccess) return "hipStreamWaitEvent failed";
-    const ncclResult_t rc = g_rccl.AllReduce(c->ring + (size_t)r * SGPMP_STAT_SHARDS * 4, stats,
+    if (two_halves) {
+        if (hipStreamWaitEvent(c->side, c->ring_produced2[r], 0) != hipSuccess) return "hipStreamWaitEvent failed";
+        if (launch_stats_add(slot, slot + SGPMP_STAT_SHARDS * 4, c->side) != hipSuccess) return "statistics add failed";
+    }
+    const ncclResult_t rc = g_rccl.AllReduce(slot, stats,
                                              (size_t)SGPMP_STAT_SHARDS * 4, ncclDouble, ncclSum, c->comm, c->side);
     if (rc != ncclSuccess) return g_rccl.GetErrorString(rc);
     if (hipEventRecord(c->ring_reduced[r], c->side) != hipSuccess) return "hipEventRecord failed";

@@ -120,7 +120,9 @@ int comm_rank(const SgpmpComm* c);
 int comm_world(const SgpmpComm* c);
 const char* comm_allreduce_stats(SgpmpComm* c, double* stats, hipStream_t stream);
 const char* comm_step_begin(SgpmpComm* c, hipStream_t stream, double** slot, hipEvent_t* k4_done);
-const char* comm_step_end(SgpmpComm* c, double* stats);
+const char* comm_step_begin2(SgpmpComm* c, hipStream_t s0, hipStream_t s1, double** slot0, double** slot1,
+                             hipEvent_t* done0, hipEvent_t* done1);
+const char* comm_step_end(SgpmpComm* c, double* stats, bool two_halves);
 const char* comm_stats_wait(SgpmpComm* c, double* stats, hipStream_t stream);
 const char* comm_allgather(SgpmpComm* c, const void* send, void* recv, size_t bytes, hipStream_t stream);
 

@@ -483,8 +483,10 @@ class StochGPMP:
         # iteration's tensors only), so the context may run them as two particle-half chains on streams of its
         # own -- one half's update kernel under the other half's sampler + sweep launch (include/sgpmp.h:
         # sgpmp_pipeline_begin).  `debug` prints costs in between and therefore keeps the single chain.
+        torch_reduce = (self.world_size > 1 or self._force_reduce) and not self._comm_attached \
+            and self._collective == 'torch' and torch.distributed.is_initialized()   # (reads the statistics per step)
         piped = (opt_iters >= 2 and not debug and self._native_cost and self.noise == 'philox'
-                 and self.num_particles_local > 0 and self.pipeline_steps)
+                 and self.num_particles_local > 0 and self.pipeline_steps and not torch_reduce)
         if piped:
             self._spheres(observation)                   # (a first use copies on THIS stream: before the chains fork)
             self._engine.pipeline_begin()

@@ -36,6 +36,17 @@ def main():
     assert abs(gs[0] / gf[0] - 1) < 1e-12 and abs(gs[1] / gf[1] - 1) < 1e-12, (gs, gf)
     allm = shard.gather_particle_means()
     assert torch.equal(allm, full.particle_means), "all-gathered means differ"
+    # several iterations in one call: two particle-half chains per rank, statistics all-reduced per step from both
+    # blocks of the ring slot (big enough shards for the split: 128 particles x 128 samples per rank)
+    P2 = 128 * world
+    full2 = hip_panda_planner(SC.PANDA, T, P2, 128, ta, seed=6, pipeline_steps=False)
+    shard2 = hip_panda_planner(SC.PANDA, T, P2, 128, ta, seed=6, rank=rank, world_size=world)
+    full2.optimize(opt_iters=10, obstacle_spheres=sph)
+    shard2.optimize(opt_iters=10, obstacle_spheres=sph)
+    assert shard2._engine.pipeline_split_steps() == 10
+    assert torch.equal(shard2.particle_means, full2.particle_means[shard2.p0:shard2.p1]), "means differ (two chains)"
+    gs2, gf2 = shard2.global_stats(), full2.global_stats()
+    assert abs(gs2[0] / gf2[0] - 1) < 1e-12 and abs(gs2[1] / gf2[1] - 1) < 1e-12, (gs2, gf2)
     dist.barrier()
     if rank == 0:
         print(f"DIST_OK world={world} stats={gs}")

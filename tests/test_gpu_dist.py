@@ -73,6 +73,27 @@ def test_one_rank_rccl_statistics_allreduce_inside_the_step(one_rank_group):
     assert pl.global_stats()[0] > 0
 
 
+def test_two_chain_steps_with_the_rccl_statistics_allreduce(one_rank_group):
+    """optimize(opt_iters=K) with a communicator attached: the iterations run as two particle-half chains, each
+    accumulating into its own block of the statistics ring slot; the all-reduce waits for both update kernels
+    and adds the blocks.  Same buffers as single-iteration calls, same all-reduced statistics."""
+    T, P, S = 32, 128, 128
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
+    a = hip_panda_planner(SC.PANDA, T, P, S, F32, seed=8, force_stats_allreduce=True)
+    b = hip_panda_planner(SC.PANDA, T, P, S, F32, seed=8, force_stats_allreduce=True, pipeline_steps=False)
+    assert a._comm_attached and b._comm_attached
+    for k in (12, 1, 3):                                 # 12 > the ring of 8 slots: a slot comes round again
+        a.optimize(opt_iters=k, obstacle_spheres=sph)
+        for _ in range(k):
+            b.optimize(opt_iters=1, obstacle_spheres=sph)
+        sa, sb = a.global_stats(), b.global_stats()
+        assert abs(sa[0] / sb[0] - 1) < 1e-12 and abs(sa[1] / sb[1] - 1) < 1e-12
+        c = a._costs.double()
+        assert abs(sa[0] / float(c.sum(1).mean()) - 1) < 1e-6
+        assert torch.equal(a.particle_means, b.particle_means) and torch.equal(a._costs, b._costs)
+    assert a._engine.pipeline_split_steps() == 15 and b._engine.pipeline_split_steps() == 0
+
+
 def test_torch_collective_fallback_matches(one_rank_group):
     """collective='torch' (the path the gloo CPU tests exercise) on HIP tensors over the nccl backend."""
     T, P, S = 16, 8, 8
