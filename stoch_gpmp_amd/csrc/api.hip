@@ -96,6 +96,7 @@ static void toggles_from_env(SgpmpToggles& tg) {
         tg.*(t.flag) = (v && *v && std::strcmp(v, "0") != 0) ? 1 : 0;
     }
     if (const char* e = getenv("SGPMP_K3_BLOCKS")) tg.k3_blocks = atoll(e);
+    if (const char* e = getenv("SGPMP_PIPE_SPLIT")) tg.pipe_split = atoll(e);
 }
 
 extern "C" int sgpmp_abi_version(void) { return SGPMP_ABI_VERSION; }
@@ -167,6 +168,7 @@ extern "C" int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out) {
 extern "C" int sgpmp_set_option(sgpmp_ctx* c, const char* name, long long value) {
     if (!c || !name) return fail(SGPMP_EINVAL, "sgpmp_set_option: null argument");
     if (std::strcmp(name, "k3_blocks") == 0) { c->tg.k3_blocks = value; return SGPMP_OK; }
+    if (std::strcmp(name, "pipe_split") == 0) { c->tg.pipe_split = value; return SGPMP_OK; }
     for (const auto& t : kToggleNames)
         if (std::strcmp(name, t.name) == 0) { c->tg.*(t.flag) = value != 0; return SGPMP_OK; }
     return fail(SGPMP_EINVAL, std::string("sgpmp_set_option: unknown option ") + name);
@@ -652,6 +654,11 @@ extern "C" int sgpmp_update(sgpmp_ctx* c, const void* costs, int costs_dtype, co
 }
 
 // ---- two-chain steps (StepPipe) ----------------------------------------------------------------------------
+static int pipe_first_half(const sgpmp_ctx* c) {
+    const long long s = (c->tg.pipe_split >= 1 && c->tg.pipe_split <= 15) ? c->tg.pipe_split : 8;
+    return (int)((long long)c->dims.num_particles * s / 16);
+}
+
 static int pipe_fork(sgpmp_ctx* c, hipStream_t st) {
     StepPipe& q = c->pipe;
     if (q.forked) return SGPMP_OK;
@@ -704,7 +711,7 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
                       char* weights, char* grad, char* means_prev, const void* spheres, int n_spheres,
                       double temperature, double step_size, double* stats, int flags, hipStream_t st) {
     const sgpmp_dims& D = c->dims;
-    const int P = D.num_particles, S = D.num_samples, P0 = P / 2;
+    const int P = D.num_particles, S = D.num_samples, P0 = pipe_first_half(c);
     const PriorDev& pr = c->prior[SGPMP_PRIOR_SAMPLE];
     const size_t w = c->esz, M = (size_t)c->M, W = (size_t)(D.traj_len + 1) * c->d;
     int rc;
@@ -773,9 +780,9 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     const PriorDev& pr = c->prior[SGPMP_PRIOR_SAMPLE];
     if (c->pipe.active) {
         // both halves big enough to fill the chip on their own (256 workgroups of 4 items of 8 rows) and fused
-        const int P0 = P / 2;
+        const int P0 = pipe_first_half(c);
         const bool split = !eps && !c->profiling && !c->tg.no_step_pipeline &&
-                           (long long)P0 * S >= 256 * 4 * 8 &&
+                           (long long)(P0 < P - P0 ? P0 : P - P0) * S >= 256 * 4 * 8 &&
                            fused_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P0, D.particle_offset,
                                                S, n_spheres, c->tg) &&
                            fused_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P - P0,

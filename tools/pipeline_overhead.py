@@ -14,6 +14,9 @@ def main():
     dev = torch.device("cuda", 0)
     pl, obs, _ = bench.build_planner(torch, "panda", 1024, 128, 64, torch.float32, dev)
     bench.time_loop(torch, pl, obs, 200, 20)
+    if len(sys.argv) > 1:
+        pl._engine.set_option("pipe_split", int(sys.argv[1]))
+        print("first chain's share:", sys.argv[1], "/ 16")
     for K in (2, 5, 10, 20, 50, 100, 200):
         row = []
         for one_call in (True, False):
