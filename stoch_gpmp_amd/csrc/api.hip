@@ -715,6 +715,9 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
     const PriorDev& pr = c->prior[SGPMP_PRIOR_SAMPLE];
     const size_t w = c->esz, M = (size_t)c->M, W = (size_t)(D.traj_len + 1) * c->d;
     int rc;
+    // (Tried: chain 0's first launch as two quarter-range launches with chain 1 starting behind the first, so that the
+    // chains are out of phase from the first iteration on -- no gain; a call's fixed cost of ~0.1 ms is the fill
+    // and drain of the two-stage schedule itself, about half a sampler + sweep launch.)
     if ((rc = pipe_fork(c, st)) != SGPMP_OK) return rc;
     const bool prepared = (flags & SGPMP_STEP_MEANS_KEPT) && c->isw_ready && c->isw_means == (const void*)means &&
                           c->isw_temperature == temperature;

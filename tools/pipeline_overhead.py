@@ -16,7 +16,7 @@ def main():
     bench.time_loop(torch, pl, obs, 200, 20)
     if len(sys.argv) > 1:
         pl._engine.set_option("pipe_split", int(sys.argv[1]))
-        print("first chain's share:", sys.argv[1], "/ 16")
+        print("first chain's share:", sys.argv[1], "/ 16", " ".join(sys.argv[2:]))
     for K in (2, 5, 10, 20, 50, 100, 200):
         row = []
         for one_call in (True, False):
