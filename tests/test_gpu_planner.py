@@ -408,7 +408,7 @@ def test_planar_fused_corners_match_the_two_launch_path(golden, nppg, G, S, T, f
         b.particle_means.copy_(a.particle_means)
 
 
-@pytest.mark.parametrize("kind", ["panda", "panda_two_goals_sdf", "planar"])
+@pytest.mark.parametrize("kind", ["panda", "panda_two_goals_sdf", "panda_ee_goal", "planar"])
 def test_pipelined_optimize_equals_single_steps_bitwise(golden, kind):
     """optimize(opt_iters=K) runs its iterations as two particle-half chains on the context's own streams
     (sgpmp_pipeline_begin / _end); a twin that takes the same iterations one optimize(opt_iters=1) at a time -- one
@@ -422,10 +422,20 @@ def test_pipelined_optimize_equals_single_steps_bitwise(golden, kind):
         name = "fused_planar_kernel"
     else:
         c, n = SC.PANDA, 7
-        two = kind != "panda"
+        two = kind == "panda_two_goals_sdf"
         g = [c["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n] if two else None
-        mk = lambda **kw: hip_panda_planner(c, 32, 64 if two else 129, 128, F32, seed=41, goals=g,   # noqa: E731
-                                            field_type="sdf" if two else "rbf", **kw)
+
+        def mk(**kw):
+            pl = hip_panda_planner(c, 32, 64 if two else 129, 128, F32, seed=41, goals=g,
+                                   field_type="sdf" if two else "rbf", **kw)
+            if kind == "panda_ee_goal":          # CostGoal (end-effector term): its own kernel behind each half's launch
+                from stoch_gpmp_amd.costs.cost_functions import CostGoal
+                from stoch_gpmp_amd.costs.fields import EESE3DistanceField
+                from oracle.fk import fk_all_links
+                H = fk_all_links(torch.tensor([[0.3, -0.5, 0.2, -1.9, 0.1, 1.6, 0.4]], dtype=torch.float64))[0, -1].clone()
+                pl.cost.cost_list.append(CostGoal(n, 32, field=EESE3DistanceField(H, w_pos=1., w_rot=0.5, tensor_args=F32),
+                                                  sigma_goal=1e-2, tensor_args=F32))
+            return pl
         obs1 = {"obstacle_spheres": torch.as_tensor(SC.panda_spheres(num=5, seed=3)).to(**F32)}
         obs2 = {"obstacle_spheres": torch.as_tensor(SC.panda_spheres(num=9, seed=4)).to(**F32)}
         name = "fused_step_kernel"
