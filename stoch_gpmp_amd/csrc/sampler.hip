@@ -225,53 +225,92 @@ sample_iso_small_kernel(int n, int T, int S, const real* __restrict__ coef, cons
     }
 }
 
-template <typename real, int N>
-__global__ void __launch_bounds__(128)
-sample_dense_kernel(int T, int S, const real* __restrict__ G, const real* __restrict__ H, size_t mode_stride,
+// ---- dense d x d factors (user-supplied Q_c^-1: gp_factor.py:25-27 accepts any matrix; per-mode precisions of
+// MultiMPPrior.set_Sigma_invs): y_t = G_t eps_t + H_t y_{t-1} with full blocks, on the matrix cores.
+// One wave = 16 samples of one mode = the 16 columns of a [state x sample] tile; per waypoint the two d x d products
+// are eight MFMA 16x16x4 (fp32: v_mfma_f32_16x16x4_f32, fp64: v_mfma_f64_16x16x4_f64), the state block padded to
+// 16.  The K index a lane serves in MFMA call kb is chosen as the ROW its accumulator register kb holds, so the
+// tile y_{t-1} goes back in as the B operand of the next waypoint's H_t y_{t-1} without a single lane exchange,
+// and the noise is drawn directly in that layout.
+template <typename real> struct DenseTile;
+template <> struct DenseTile<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    // accumulator register r of lane (q = lane >> 4, j = lane & 15) holds element [4 q + r][j]
+    static __device__ __forceinline__ int row(int q, int r) { return 4 * q + r; }
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct DenseTile<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    // accumulator register r of lane (q, j) holds element [q + 4 r][j]
+    static __device__ __forceinline__ int row(int q, int r) { return q + 4 * r; }
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename real>
+__global__ void __launch_bounds__(256)
+sample_dense_kernel(int n, int T, int S, const real* __restrict__ G, const real* __restrict__ H, size_t mode_stride,
                     const real* __restrict__ means, const real* __restrict__ eps, int eps_modes,
                     int eps_mode_offset, int mode_offset, uint64_t seed, uint64_t draw,
                     real* __restrict__ out) {
-    constexpr int D = 2 * N;
+    using DT = DenseTile<real>;
+    const int D = 2 * n;
     const int m = blockIdx.y;
     G += (size_t)m * mode_stride;                        // per-mode factors (set_Sigma_invs) or 0: shared
     H += (size_t)m * mode_stride;
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;              // A operand: row i, K slot q;  B / accumulator: column i, slot q
+    const int s = (blockIdx.x * 4 + wave) * 16 + i;      // this lane's sample (tile column)
+    const bool live = s < S;
     const size_t M = (size_t)T * D;
     const real* mu = means + (size_t)m * M;
-    real* row = out + ((size_t)m * S + s) * M;
-    const real* erow = eps ? eps + ((size_t)s * eps_modes + eps_mode_offset + m) * M : nullptr;
-    NoiseGen<real> gen[N];
+    real* row_out = out + ((size_t)m * S + (live ? s : 0)) * M;
+    const real* erow = (eps && live) ? eps + ((size_t)s * eps_modes + eps_mode_offset + m) * M : nullptr;
+    int rows[4];                                         // state rows of the four accumulator registers (= K indices served)
+    NoiseGen<real> gen[4];
 #pragma unroll
-    for (int k = 0; k < N; ++k)
-        gen[k].init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)s, (uint32_t)k);
-    real y[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) y[i] = 0;
+    for (int r = 0; r < 4; ++r) {
+        rows[r] = DT::row(q, r);
+        const int k = rows[r] < n ? rows[r] : rows[r] - n;              // dof of that row (position or velocity part)
+        gen[r].init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)(live ? s : 0), (uint32_t)k);
+    }
+    typename DT::acc_t y = {0, 0, 0, 0};
     for (int t = 0; t < T; ++t) {
-        real e[D];
-        if (erow) {
+        real e[4];
 #pragma unroll
-            for (int i = 0; i < D; ++i) e[i] = erow[t * D + i];
-        } else {
-#pragma unroll
-            for (int k = 0; k < N; ++k) gen[k].get(t, e[k], e[N + k]);
+        for (int r = 0; r < 4; ++r) {
+            real v = 0;
+            if (rows[r] < D && live) {
+                if (erow) v = erow[(size_t)t * D + rows[r]];
+                else {
+                    real ep, ev;
+                    gen[r].get(t, ep, ev);
+                    v = rows[r] < n ? ep : ev;
+                }
+            }
+            e[r] = v;
         }
         const real* Gt = G + (size_t)t * D * D;
         const real* Ht = H + (size_t)t * D * D;
-        real yn[D];
+        typename DT::acc_t acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            real acc = 0;
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                if (j <= i) acc += Gt[i * D + j] * e[j];
-                acc += Ht[i * D + j] * y[j];
-            }
-            yn[i] = acc;
+        for (int kb = 0; kb < 4; ++kb) {
+            const int k = rows[kb];                      // K index of slot q in call kb: the row register kb holds
+            const bool in = i < D && k < D;
+            const real g = (in && k <= i) ? Gt[i * D + k] : (real)0;       // G_t = B_t^-1 is lower triangular
+            const real h = in ? Ht[i * D + k] : (real)0;
+            acc = DT::mma(g, e[kb], acc);
+            acc = DT::mma(h, y[kb], acc);
         }
+        y = acc;
+        if (live) {
 #pragma unroll
-        for (int i = 0; i < D; ++i) { y[i] = yn[i]; row[t * D + i] = mu[t * D + i] + yn[i]; }
+            for (int r = 0; r < 4; ++r)
+                if (rows[r] < D) row_out[(size_t)t * D + rows[r]] = mu[(size_t)t * D + rows[r]] + y[r];
+        }
     }
 }
 
@@ -316,17 +355,10 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
     const real* H = f64 ? (const real*)prior.H : (const real*)prior.H32;
     if (prior.n_factor_modes > 0 && n_modes > prior.n_factor_modes) return hipErrorInvalidValue;
     const size_t mode_stride = prior.n_factor_modes > 0 ? (size_t)T * 4 * n * n : 0;
-    dim3 grid((S + 127) / 128, n_modes), block(128);
-#define DENSE(NN)                                                                                  \
-    case NN:                                                                                       \
-        hipLaunchKernelGGL((sample_dense_kernel<real, NN>), grid, block, 0, stream, T, S, G, H,    \
-                           mode_stride, means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, out);  \
-        break;
-    switch (n) {
-        DENSE(1) DENSE(2) DENSE(3) DENSE(4) DENSE(5) DENSE(6) DENSE(7) DENSE(8)
-        default: return hipErrorInvalidValue;
-    }
-#undef DENSE
+    if (n < 1 || n > 8) return hipErrorInvalidValue;     // state block = one 16 x 16 tile
+    dim3 grid((S + 63) / 64, n_modes), block(256);       // 4 waves x 16 samples
+    hipLaunchKernelGGL((sample_dense_kernel<real>), grid, block, 0, stream, n, T, S, G, H, mode_stride, means, eps,
+                       eps_modes, eps_mode_offset, mode_offset, seed, draw, out);
     return hipGetLastError();
 }
 

@@ -112,12 +112,14 @@ def test_sampler_external_eps_matches_oracle(n, T, dt, ss, sg, sgoal, dtype, rto
     close(out, ref, rtol, atol=rtol * scale)
 
 
+@pytest.mark.parametrize("n,T,S", [(3, 12, 7), (7, 64, 70), (8, 16, 33)])
 @pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 1e-4)])
-def test_dense_sampler_equals_isotropic_sampler(dtype, rtol):
-    """A user-supplied full Q_c_inv takes the d x d block path; with Q_c_inv = I/sigma^2 it must
-    reproduce the per-DOF path."""
+def test_dense_sampler_equals_isotropic_sampler(dtype, rtol, n, T, S):
+    """A user-supplied full Q_c_inv takes the d x d block path (matrix cores: one wave = a [state x 16 samples]
+    tile; partially filled tiles, several waves, the Panda-size and the full 16 x 16 block); with
+    Q_c_inv = I/sigma^2 it must reproduce the per-DOF path."""
     from stoch_gpmp_amd import _lib as L
-    n, T, dt, ss, sg, sgoal, modes, S = 3, 12, 0.05, 0.01, 0.3, 0.05, 2, 7
+    dt, ss, sg, sgoal, modes = 0.05, 0.01, 0.3, 0.05, 2
     g = torch.Generator().manual_seed(2)
     means = torch.randn(modes, T, 2 * n, generator=g, dtype=torch.float64).to(**TA(dtype))
     eps = torch.randn(S, modes, T * 2 * n, generator=g, dtype=torch.float64).to(**TA(dtype))
@@ -134,9 +136,10 @@ def test_dense_sampler_equals_isotropic_sampler(dtype, rtol):
     close(yb, ya, rtol, atol=rtol)
 
 
-def test_dense_sampler_with_full_Qc_matches_oracle():
+@pytest.mark.parametrize("n,T,S", [(3, 10, 4), (7, 24, 37)])
+def test_dense_sampler_with_full_Qc_matches_oracle(n, T, S):
     from stoch_gpmp_amd import _lib as L
-    n, T, dt, ss, sgoal, modes, S = 3, 10, 0.1, 0.05, 0.2, 2, 4
+    dt, ss, sgoal, modes = 0.1, 0.05, 0.2, 2
     d = 2 * n
     g = torch.Generator().manual_seed(3)
     A = torch.randn(n, n, generator=g, dtype=torch.float64)
