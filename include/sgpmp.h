@@ -273,8 +273,10 @@ int sgpmp_field_eval(sgpmp_ctx* ctx, int term, const void* frames, int64_t batch
 /* FieldFactor.get_error(calc_jacobian=True) (factors/field_factor.py:28-38): value [B] (may be NULL) and
  * gradient d value / d q [B,n] of link-field term `term` at joint configurations q [B,n], with the
  * context's FK chain -- the analytic form of the reference's torch.autograd.grad through FK and the
- * field (the reference's H is MINUS this gradient).  Smooth fields only: SPHERES with the rbf type
- * and SELF; sdf / occupancy / EE_GOAL -> SGPMP_EINVAL.   */
+ * field (the reference's H is MINUS this gradient).  Smooth fields only: SPHERES with the rbf type,
+ * SELF and EE_GOAL (end-effector SE(3) distance: position part u . (z_j x (p - o_j)), rotation part
+ * z_j . axis; what CostGoal.get_linear_system needs, cost_functions.py:323-337); sdf / occupancy ->
+ * SGPMP_EINVAL.   */
 int sgpmp_field_grad(sgpmp_ctx* ctx, int term, const void* q, int64_t batch, const void* spheres,
                      int n_spheres, void* value, void* grad, void* stream);
 
@@ -284,7 +286,8 @@ int sgpmp_field_grad(sgpmp_ctx* ctx, int term, const void* q, int64_t batch, con
  * the context), and -- when `diag_sum` [T*d] is given -- the sum over THIS context's particles of the
  * field part of diag(A^T K A), which the trust-region damping averages over all particles
  * (planner.py:618-622; all-reduce it across ranks before sgpmp_gpmp_solve when particles are sharded).
- * The cost list may hold one CostGP, one CostGoalPrior and up to 4 rbf-sphere / self-distance fields. */
+ * The cost list may hold one CostGP, one CostGoalPrior and up to 4 rbf-sphere / self-distance /
+ * end-effector-goal fields (CostGoal: one row, on the last waypoint). */
 int sgpmp_gpmp_linearize(sgpmp_ctx* ctx, const void* means, const void* spheres, int n_spheres,
                          double* diag_sum, void* stream);
 /* Second half (planner.py:583-603): per particle, assemble the block-tridiagonal normal equations

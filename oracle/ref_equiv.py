@@ -282,6 +282,17 @@ def collision_linear_system(q_trajs, n, FK, field_fn, sigma):
     return A, err.unsqueeze(-1), K
 
 
+def goal_ee_linear_system(q_trajs, n, FK, field_fn, sigma):
+    """CostGoal.get_linear_system -- cost_functions.py:323-337: one row per trajectory, the field on the last
+    waypoint; Jacobian by autograd through FK as FieldFactor.get_error does (field_factor.py:34-38)."""
+    B, T, d = q_trajs.shape
+    err, H = field_error_and_jacobian(q_trajs, n, (T - 1, T), FK, field_fn)
+    A = torch.zeros(B, 1, d * T, dtype=q_trajs.dtype)
+    A[:, :, (T - 1) * d:(T - 1) * d + n] = H
+    K = (1. / sigma ** 2) * torch.ones(B, 1, 1, dtype=q_trajs.dtype)
+    return A, err.unsqueeze(-1), K
+
+
 class CompositeCost:
     """CostComposite.eval -- cost_functions.py:47-58.  `terms` is a list of callables
     term(trajs[B,T,d], x_trajs or None, **obs) -> [B], summed in list order."""

@@ -342,3 +342,18 @@ class CostGoal(Cost):
         if not hasattr(self.field, "descriptor"):
             raise TypeError(f"field {type(self.field).__name__} is not a stoch_gpmp_amd field")
         return [self.field.descriptor(self.sigma_goal)]
+
+    def get_linear_system(self, trajs, x_trajs=None, **observation):
+        """cost_functions.py:323-337: A [B,1,T*d] holds the field Jacobian H = -d field / d q of the LAST waypoint
+        in that waypoint's position columns, b = field value, K = 1 / sigma^2.  The Jacobian is analytic
+        (`ee_grad_kernel`: position part u . (z_j x (p - o_j)), rotation part z_j . axis) instead of autograd."""
+        if self.field is None:
+            return None, None, None
+        chain = getattr(self, "_chain", None)
+        trajs = trajs.reshape(-1, self.traj_len, self.dim)
+        B, T = trajs.shape[0], self.traj_len
+        err, H = self.goal_factor.get_error(trajs, self.field, calc_jacobian=True, fk_chain=chain)
+        A = torch.zeros(B, 1, self.dim * T, device=trajs.device, dtype=trajs.dtype)
+        A[:, :, (T - 1) * self.dim:(T - 1) * self.dim + self.n_dof] = H
+        K = self.goal_factor.K * torch.ones(B, 1, 1, device=trajs.device, dtype=trajs.dtype)
+        return A, err.unsqueeze(-1), K

@@ -905,6 +905,10 @@ extern "C" int sgpmp_field_grad(sgpmp_ctx* c, int term, const void* q, int64_t b
         if ((t.flags & 15) != SGPMP_FIELD_RBF)
             return fail(SGPMP_EINVAL, "sgpmp_field_grad: only the rbf sphere field is differentiable here");
         if (!spheres || n_spheres < 1) return fail(SGPMP_EINVAL, "LinkDistanceField cost needs obstacle_spheres");
+    } else if (t.kind == SGPMP_COST_EE_GOAL) {
+        HIPCHK(launch_ee_grad(c->dims.dtype, c->dims.n_dof, t, c->d_chain, q, batch, 0, 1, 0, value, grad,
+                              (hipStream_t)stream));
+        return SGPMP_OK;
     } else if (t.kind != SGPMP_COST_SELF) {
         return fail(SGPMP_EINVAL, "sgpmp_field_grad: term is not a smooth link field");
     }
@@ -939,6 +943,7 @@ static int gpmp_args(sgpmp_ctx* c, GpmpArgs& a, int* field_terms) {
                 if ((t.flags & 15) != SGPMP_FIELD_RBF)
                     return fail(SGPMP_EINVAL, "GPMP: only the rbf sphere field has a Jacobian");
                 /* fall through */
+            case SGPMP_COST_EE_GOAL:                      // (a field row on the last waypoint only)
             case SGPMP_COST_SELF:
                 if (a.n_fields == 4) return fail(SGPMP_EINVAL, "GPMP: more than 4 link-field terms");
                 field_terms[a.n_fields] = i;
@@ -946,7 +951,7 @@ static int gpmp_args(sgpmp_ctx* c, GpmpArgs& a, int* field_terms) {
                 a.n_fields += 1;
                 break;
             default:
-                return fail(SGPMP_EINVAL, "GPMP: cost term without a linear system (grid / end-effector goal)");
+                return fail(SGPMP_EINVAL, "GPMP: cost term without a linear system (occupancy grid)");
         }
     }
     if (!have_gp) return fail(SGPMP_EINVAL, "GPMP: the cost list needs a CostGP term");
@@ -982,6 +987,14 @@ extern "C" int sgpmp_gpmp_linearize(sgpmp_ctx* c, const void* means, const void*
         const CostTerm& t = c->h_prog.terms[ft[k]];
         if (t.kind == SGPMP_COST_SPHERES && (!spheres || n_spheres < 1))
             return fail(SGPMP_EINVAL, "LinkDistanceField cost needs obstacle_spheres");
+        if (t.kind == SGPMP_COST_EE_GOAL) {
+            // CostGoal (cost_functions.py:323-337): one row, on the last waypoint -- the other waypoints' entries
+            // of this term's value / gradient arrays are zero rows of the linear system
+            HIPCHK(hipMemsetAsync(c->d_fval[k], 0, (size_t)B * c->esz, st));
+            HIPCHK(hipMemsetAsync(c->d_fgrad[k], 0, (size_t)B * a.n * c->esz, st));
+            HIPCHK(launch_ee_grad(c->dims.dtype, a.n, t, c->d_chain, means, a.P, a.T, a.T - 1, a.T - 2, c->d_fval[k],
+                                  c->d_fgrad[k], st));
+        } else
         HIPCHK(launch_field_grad(c->dims.dtype, a.n, t, c->d_chain, c->h_chain.n_joints, means, B, a.T, spheres,
                                  n_spheres, c->d_fval[k], c->d_fgrad[k], st));
         a.f[k].val = c->d_fval[k];

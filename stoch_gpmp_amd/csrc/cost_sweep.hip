@@ -842,6 +842,96 @@ hipError_t launch_ee_goal(int dtype, int n, int T, const CostTerm& term, const C
     return hipGetLastError();
 }
 
+// Value and joint-space gradient of the end-effector field (EESE3DistanceField.compute_cost, fields.py:146-150, at
+// this build's SE(3) distance d = w_pos |p - p*| + w_rot theta, theta = angle(R*^T R)): what
+// FieldFactor.get_error(calc_jacobian=True) (field_factor.py:34-38) obtains with torch.autograd.grad for
+// CostGoal.get_linear_system (cost_functions.py:323-337).  For a revolute joint j (axis z_j through o_j, world frame)
+//   d|p - p*| / dq_j = u . (z_j x (p - o_j)),  u = (p - p*) / |p - p*|
+//   d theta / dq_j   = z_j . a,                a = axis of E = R R*^T = vee(E - E^T) / |vee(E - E^T)|
+// (dR/dq_j = [z_j]x R, tr([z]x E) = -z . vee(E - E^T), vee(E - E^T) = 2 sin(theta) a).  Both directions are taken as
+// 0 where they are undefined (|p - p*| = 0, theta = 0 or pi).  traj_T = 0: q is [B,n]; traj_T = T: q is a
+// trajectory batch [B,T,2n] and the configuration is its LAST waypoint.  value[b * out_stride + out_offset],
+// grad[(b * out_stride + out_offset) * n + k].
+template <typename real>
+__global__ void ee_grad_kernel(int n, int traj_T, const ChainDev* __restrict__ ch, const real* __restrict__ q,
+                               long long batch, EeTarget<real> tg, long long out_stride, long long out_offset,
+                               real* __restrict__ value, real* __restrict__ grad) {
+    using O = RealOps<real>;
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const real* qb = traj_T > 0 ? q + ((size_t)b * traj_T + (traj_T - 1)) * 2 * n : q + (size_t)b * n;
+    real Z[SGPMP_MAX_JOINTS][3], Oj[SGPMP_MAX_JOINTS][3];
+    real R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    const int nj = ch->n_joints;
+    for (int j = 0; j < nj; ++j) {
+        const JointDev& J = ch->j[j];
+        real F[9], tt[3], Rn[9];
+        for (int i = 0; i < 9; ++i) F[i] = (real)J.R[i];
+        for (int i = 0; i < 3; ++i) tt[i] = (real)J.t[i];
+        for (int r = 0; r < 3; ++r) p[r] += R[r * 3 + 0] * tt[0] + R[r * 3 + 1] * tt[1] + R[r * 3 + 2] * tt[2];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                Rn[r * 3 + c] = R[r * 3 + 0] * F[c] + R[r * 3 + 1] * F[3 + c] + R[r * 3 + 2] * F[6 + c];
+        for (int r = 0; r < 3; ++r) { Z[j][r] = Rn[r * 3 + 2]; Oj[j][r] = p[r]; }     // joint axis and origin
+        if (J.revolute) {
+            real sn, cs;
+            O::sincos_(qb[J.qidx], &sn, &cs);
+            for (int r = 0; r < 3; ++r) {
+                const real aa = Rn[r * 3 + 0], bb = Rn[r * 3 + 1];
+                Rn[r * 3 + 0] = aa * cs + bb * sn;
+                Rn[r * 3 + 1] = bb * cs - aa * sn;
+            }
+        }
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    }
+    // distance and its directions
+    const real dx = p[0] - tg.p[0], dy = p[1] - tg.p[1], dz = p[2] - tg.p[2];
+    const real dpos = O::sqrt_(dx * dx + dy * dy + dz * dz);
+    real tr = 0;
+    for (int i = 0; i < 9; ++i) tr += R[i] * tg.R[i];
+    const real cth = fmin(fmax((tr - (real)1) * (real)0.5, (real)-1), (real)1);
+    const real dist = tg.w_pos * dpos + tg.w_rot * acos(cth);
+    real E[9];                                                             // E = R R*^T
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            E[r * 3 + c] = R[r * 3 + 0] * tg.R[c * 3 + 0] + R[r * 3 + 1] * tg.R[c * 3 + 1] + R[r * 3 + 2] * tg.R[c * 3 + 2];
+    real w[3] = {E[7] - E[5], E[2] - E[6], E[3] - E[1]};
+    const real wn = O::sqrt_(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const bool interior = cth > (real)-1 && cth < (real)1 && wn > (real)0;   // (acos has no slope to offer at +-1)
+    const real outer = tg.square ? (real)2 * dist : (real)1;                 // d f / d dist
+    const real su = dpos > (real)0 ? outer * tg.w_pos / dpos : (real)0;
+    const real sa = interior ? outer * tg.w_rot / wn : (real)0;
+    const real gp[3] = {su * dx, su * dy, su * dz};                          // d f / d p
+    const real ta[3] = {sa * w[0], sa * w[1], sa * w[2]};                    // d f / d (rotation vector)
+    const size_t o = (size_t)(b * out_stride + out_offset);
+    if (value) value[o] = tg.square ? dist * dist : dist;
+    real* gb = grad + o * n;
+    for (int k = 0; k < n; ++k) gb[k] = 0;
+    for (int j = 0; j < nj; ++j) {
+        if (!ch->j[j].revolute) continue;
+        const real rx = p[0] - Oj[j][0], ry = p[1] - Oj[j][1], rz = p[2] - Oj[j][2];
+        const real cx = Z[j][1] * rz - Z[j][2] * ry, cy = Z[j][2] * rx - Z[j][0] * rz, cz = Z[j][0] * ry - Z[j][1] * rx;
+        gb[ch->j[j].qidx] += gp[0] * cx + gp[1] * cy + gp[2] * cz + Z[j][0] * ta[0] + Z[j][1] * ta[1] + Z[j][2] * ta[2];
+    }
+}
+
+hipError_t launch_ee_grad(int dtype, int n, const CostTerm& term, const ChainDev* d_chain, const void* q,
+                          long long batch, int traj_T, long long out_stride, long long out_offset, void* value,
+                          void* grad, hipStream_t stream) {
+    const int block = 64;
+    const unsigned grid = (unsigned)((batch + block - 1) / block);
+    if (grid == 0) return hipSuccess;
+    if (dtype == SGPMP_F64)
+        hipLaunchKernelGGL((ee_grad_kernel<double>), dim3(grid), dim3(block), 0, stream, n, traj_T, d_chain,
+                           (const double*)q, batch, make_ee_target<double>(term), out_stride, out_offset,
+                           (double*)value, (double*)grad);
+    else
+        hipLaunchKernelGGL((ee_grad_kernel<float>), dim3(grid), dim3(block), 0, stream, n, traj_T, d_chain,
+                           (const float*)q, batch, make_ee_target<float>(term), out_stride, out_offset,
+                           (float*)value, (float*)grad);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------- standalone ops
 // FK callable: q [B,n] -> frames [B,L,4,4]  (cost_functions.py:51-52).
 template <typename real>

@@ -173,6 +173,9 @@ hipError_t launch_stats_add(double* dst, const double* src, hipStream_t stream);
 hipError_t launch_ee_goal(int dtype, int n, int T, const CostTerm& term, const ChainDev* d_chain,
                           const void* trajs, long long batch, void* costs, double* costs64,
                           hipStream_t stream);
+hipError_t launch_ee_grad(int dtype, int n, const CostTerm& term, const ChainDev* d_chain, const void* q,
+                          long long batch, int traj_T, long long out_stride, long long out_offset, void* value,
+                          void* grad, hipStream_t stream);
 hipError_t launch_field_grad(int dtype, int n, const CostTerm& term, const ChainDev* d_chain, int n_joints,
                              const void* q, long long batch, int traj_T, const void* spheres, int n_spheres,
                              void* value, void* grad, hipStream_t stream);

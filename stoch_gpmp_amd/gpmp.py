@@ -59,6 +59,10 @@ class GPMP(StochGPMP):
         equations per particle, move the means by step_size * d_theta.  Returns (d_theta, costs) where
         costs = b^T K b at the linearisation point (what the reference's `_get_costs(b, K)` gives)."""
         eng = self._engine
+        cv = self.cost.version()
+        if cv != self._cost_version:                     # a field / cost was edited (the reference reads them live)
+            self.cost.compile_into(eng)
+            self._cost_version = cv
         trust = bool(self.solver_params['trust_region'])
         diag = self._diag_sum if trust else None
         if self.num_particles_local > 0:

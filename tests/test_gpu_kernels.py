@@ -473,6 +473,41 @@ def test_field_jacobian_matches_autograd_through_fk(dtype, rtol, which, interp):
         ff.get_error(trajs.to(**ta), field, calc_jacobian=True, **obs)
 
 
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-8), (torch.float32, 5e-4)])
+@pytest.mark.parametrize("square", [True, False])
+def test_ee_goal_linear_system_matches_autograd(dtype, rtol, square):
+    """CostGoal.get_linear_system (cost_functions.py:323-337) with EESE3DistanceField: value and Jacobian of the
+    end-effector SE(3) distance at the last waypoint -- analytic in `ee_grad_kernel`, autograd through the oracle's
+    FK and distance in the oracle -- and the reference's A / b / K layout."""
+    from oracle.fk import fk_all_links
+    from stoch_gpmp_amd.costs.cost_functions import CostComposite, CostGoal
+    from stoch_gpmp_amd.costs.fields import EESE3DistanceField
+    from stoch_gpmp_amd.robots.panda import DifferentiableFrankaPanda
+    n, B, T, sigma = 7, 6, 5, 0.05
+    ta = TA(dtype)
+    g = torch.Generator().manual_seed(21)
+    trajs = torch.cat([torch.rand(B, T, n, generator=g) * 3 - 1.5, torch.randn(B, T, n, generator=g)], -1).double()
+    H_t = fk_all_links(torch.tensor([[0.3, -0.5, 0.2, -1.9, 0.1, 1.6, 0.4]], dtype=torch.float64))[0, -1].clone()
+    field = EESE3DistanceField(H_t.to(**ta), w_pos=1.0, w_rot=0.5, square=square, tensor_args=ta)
+    cg = CostGoal(n, T, field=field, sigma_goal=sigma, tensor_args=ta)
+    fk = DifferentiableFrankaPanda(gripper=False, device=DEV)
+    CostComposite(n, T, [cg], FK=fk.compute_forward_kinematics_all_links, tensor_args=ta)    # hands the chain down
+    A, b, K = cg.get_linear_system(trajs.to(**ta))
+    Ao, bo, Ko = R.goal_ee_linear_system(trajs, n, fk_all_links,
+                                         lambda fr: R.field_ee_se3(fr, H_t, 1.0, 0.5, square), sigma)
+    assert A.shape == (B, 1, 2 * n * T) and b.shape == (B, 1, 1) and K.shape == (B, 1, 1)
+    close(A, Ao, rtol, atol=rtol * float(Ao.abs().max()))
+    close(b, bo, rtol, atol=rtol * float(bo.abs().max()))
+    close(K, Ko, 1e-6)
+    assert float(A[:, :, :(T - 1) * 2 * n].abs().max()) == 0.0          # only the last waypoint's positions
+    # at the target itself both directions are undefined: value 0, gradient 0 (no NaN)
+    q_t = torch.tensor([[0.3, -0.5, 0.2, -1.9, 0.1, 1.6, 0.4]], dtype=torch.float64)
+    at = torch.cat([q_t, torch.zeros(1, n, dtype=torch.float64)], -1).reshape(1, 1, 2 * n).repeat(1, T, 1)
+    A0, b0, _ = cg.get_linear_system(at.to(**ta))
+    # (acos near 1 amplifies the rounding of the trace: theta ~ sqrt(2 eps))
+    assert torch.isfinite(A0).all() and float(b0.abs().max()) < (1e-6 if dtype == torch.float64 else 2e-3)
+
+
 def test_collision_linear_system_matches_reference_layout():
     """CostCollision.get_linear_system (cost_functions.py:263-279): A, b, K against the oracle's
     restatement (autograd Jacobian placed in the position columns of waypoint i+1)."""
