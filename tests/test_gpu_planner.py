@@ -477,6 +477,37 @@ def test_pipelined_optimize_equals_single_steps_bitwise(golden, kind):
     same()
 
 
+@pytest.mark.parametrize("nppg,G,S,T", [(2, 2, 8, 16), (3, 2, 24, 48), (64, 2, 64, 64)])
+def test_three_dof_point_mass_fused_matches_the_two_launch_path(golden, nppg, G, S, T):
+    """The no-FK fused launch for n = 3 (fused_planar_kernel<3>: two segments per chain in its scan, pair broadcasts)
+    against sampler + generic sweep, and -- at the size that splits -- as two chains against single calls."""
+    c3 = dict(SC.PLANAR, n_dof=3, start=[-9., -9., 0.5, 0., 0., 0.])
+    goals = [[9., 6., 1., 0., 0., 0.], [9., -3., -1., 0., 0., 0.]][:G]
+    om = planar_map(golden, F32)
+    a = hip_planar_planner(c3, T, goals, nppg, S, om, F32, seed=37)
+    b = hip_planar_planner(c3, T, goals, nppg, S, om, F32, seed=37)
+    b._engine.set_option("no_fused_step", 1)
+    for it in range(3):
+        a.optimize()
+        b.optimize()
+        assert a._engine.last_cost_kernel() == "fused_planar_kernel"
+        assert b._engine.last_cost_kernel() == "cost_sweep_kernel<f32, no FK>"
+        scale = float(b.state_samples.abs().max())
+        assert float((a.state_samples - b.state_samples).abs().max()) <= 4e-7 * scale
+        assert rel_err(a._costs, b._costs) < 2e-5
+        assert torch.equal(a._costs.argmin(1), b._costs.argmin(1))
+        b.particle_means.copy_(a.particle_means)
+    if nppg * G * S >= 16384:
+        twin = hip_planar_planner(c3, T, goals, nppg, S, om, F32, seed=37, pipeline_steps=False)
+        for _ in range(3):
+            twin.optimize()
+        a.optimize(opt_iters=4)
+        for _ in range(4):
+            twin.optimize()
+        assert a._engine.pipeline_split_steps() == 4
+        assert torch.equal(a.particle_means, twin.particle_means) and torch.equal(a._costs, twin._costs)
+
+
 def test_prepared_is_weights_follow_every_edit_of_the_means():
     """A fused step has its update kernel prepare the next step's importance-sampling weights, and the next
     sgpmp_step skips K5 when the caller vouches (SGPMP_STEP_MEANS_KEPT) that the means are untouched.  The
