@@ -135,6 +135,12 @@ const char* sgpmp_last_cost_kernel(sgpmp_ctx* ctx);
  * Synchronous (reads back the positive-definiteness flag): returns SGPMP_ENOTPD on failure. */
 int sgpmp_set_prior(sgpmp_ctx* ctx, int which, double dt, double sigma_start, double sigma_gp,
                     double sigma_goal, const double* qc_inv, void* stream);
+/* The two priors of StochGPMP.reset (planner.py:204-226: [0] initialisation, [1] sampling; isotropic Q_c) in one
+ * call: K1 is a single wave for ~1.2 ms, so the two factorisations run concurrently (the second on a stream of the
+ * context) and the call synchronises once.  sigma_goal[w] < 0: not goal-directed.  Same results and errors as two
+ * sgpmp_set_prior calls. */
+int sgpmp_set_priors(sgpmp_ctx* ctx, double dt, const double* sigma_start, const double* sigma_gp,
+                     const double* sigma_goal, void* stream);
 
 /* MultiMPPrior.set_Sigma_invs (mp_priors_multi.py:125-128): one precision matrix PER MODE, given by its
  * blocks -- D HOST double[n_modes][T][d][d] (diagonal blocks), E HOST double[n_modes][T-1][d][d] with

@@ -76,6 +76,8 @@ struct sgpmp_ctx {
     double isw_temperature;
     const char* last_cost_kernel; // name of the cost-sweep kernel the dispatcher picked last
     StepPipe pipe;                // two-chain execution of consecutive steps (sgpmp_pipeline_begin / _end)
+    hipStream_t k1_side = nullptr;   // sgpmp_set_priors: the second factorisation's stream
+    hipEvent_t k1_fork = nullptr;
 };
 
 // name -> field of SgpmpToggles (environment variable = "SGPMP_" + upper-case name)
@@ -155,7 +157,7 @@ extern "C" int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out) {
     int rc;
     if ((rc = alloc_prior(c, c->prior[0])) != SGPMP_OK) return rc;
     if ((rc = alloc_prior(c, c->prior[1])) != SGPMP_OK) return rc;
-    HIPCHK(hipMalloc(&c->d_qc, sizeof(double) * dims->n_dof * dims->n_dof));
+    HIPCHK(hipMalloc(&c->d_qc, sizeof(double) * 2 * dims->n_dof * dims->n_dof));   // (two: sgpmp_set_priors)
     HIPCHK(hipMalloc(&c->d_prog, sizeof(CostProgram)));
     HIPCHK(hipMalloc(&c->d_chain, sizeof(ChainDev)));
     const size_t P = (size_t)(dims->num_particles > 0 ? dims->num_particles : 1);
@@ -245,6 +247,8 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     }
     if (c->pipe.fork_ev) hipEventDestroy(c->pipe.fork_ev);
     hipFree(c->pipe.stats2);
+    if (c->k1_side) hipStreamDestroy(c->k1_side);
+    if (c->k1_fork) hipEventDestroy(c->k1_fork);
     delete c;
 }
 
@@ -274,6 +278,51 @@ extern "C" int sgpmp_set_prior(sgpmp_ctx* c, int which, double dt, double sigma_
     if (status != 0)
         return fail(SGPMP_ENOTPD, "sgpmp_set_prior: prior precision matrix is not positive definite");
     p.valid = 1;
+    return SGPMP_OK;
+}
+
+// Both priors of StochGPMP.reset (planner.py:204-226) at once: K1 is one wave for ~1.2 ms whatever the problem
+// size, so the two factorisations run side by side -- the sampling prior's on `stream`, the initialisation prior's
+// on a stream of the context -- and the call synchronises once.  Isotropic Q_c only (what the planner builds).
+extern "C" int sgpmp_set_priors(sgpmp_ctx* c, double dt, const double* sigma_start, const double* sigma_gp,
+                                const double* sigma_goal, void* stream) {
+    if (!c || !sigma_start || !sigma_gp || !sigma_goal) return fail(SGPMP_EINVAL, "sgpmp_set_priors: null argument");
+    for (int w = 0; w < 2; ++w)
+        if (!(dt > 0.) || !(sigma_start[w] > 0.) || !(sigma_gp[w] > 0.))
+            return fail(SGPMP_EINVAL, "sgpmp_set_priors: dt and sigmas must be positive");
+    const int n = c->dims.n_dof;
+    hipStream_t st = (hipStream_t)stream;
+    if (!c->k1_side) {
+        HIPCHK(hipStreamCreateWithFlags(&c->k1_side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->k1_fork, hipEventDisableTiming));
+    }
+    c->isw_ready = false;
+    HIPCHK(hipEventRecord(c->k1_fork, st));                       // whatever used the old factors comes first
+    HIPCHK(hipStreamWaitEvent(c->k1_side, c->k1_fork, 0));
+    std::vector<double> qc((size_t)2 * n * n, 0.);
+    for (int w = 0; w < 2; ++w)
+        for (int i = 0; i < n; ++i) qc[(size_t)w * n * n + (size_t)i * n + i] = 1. / (sigma_gp[w] * sigma_gp[w]);
+    HIPCHK(hipMemcpyAsync(c->d_qc, qc.data(), sizeof(double) * 2 * n * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(c->k1_fork, st));
+    HIPCHK(hipStreamWaitEvent(c->k1_side, c->k1_fork, 0));
+    int status[2] = {0, 0};
+    for (int w = 0; w < 2; ++w) {
+        PriorDev& p = c->prior[w];
+        hipStream_t sw = w == SGPMP_PRIOR_SAMPLE ? st : c->k1_side;
+        p.ks = 1. / (sigma_start[w] * sigma_start[w]);
+        p.kg = sigma_goal[w] > 0. ? 1. / (sigma_goal[w] * sigma_goal[w]) : -1.;
+        p.dt = dt; p.isotropic = 1; p.valid = 0; p.n_factor_modes = 0;
+        HIPCHK(launch_prior_factor(n, c->dims.traj_len, dt, p.ks, p.kg, c->d_qc + (size_t)w * n * n, 1, p, sw));
+    }
+    // (both launches first: a device-to-host copy into pageable memory blocks the host until its stream is idle)
+    HIPCHK(hipMemcpyAsync(&status[SGPMP_PRIOR_INIT], c->prior[SGPMP_PRIOR_INIT].status, sizeof(int), hipMemcpyDeviceToHost, c->k1_side));
+    HIPCHK(hipMemcpyAsync(&status[SGPMP_PRIOR_SAMPLE], c->prior[SGPMP_PRIOR_SAMPLE].status, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(c->k1_side));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int w = 0; w < 2; ++w) {
+        if (status[w] != 0) return fail(SGPMP_ENOTPD, "sgpmp_set_priors: prior precision matrix is not positive definite");
+        c->prior[w].valid = 1;
+    }
     return SGPMP_OK;
 }
 

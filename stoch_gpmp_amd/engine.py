@@ -112,6 +112,27 @@ class Engine:
                 float(sigma_goal) if sigma_goal is not None else -1.0, qc, L.stream_ptr()))
         self._prior_key[which] = key
 
+    def set_priors(self, dt, init, sample):
+        """Both priors of a planner's reset(): init / sample = (sigma_start, sigma_gp, sigma_goal or None).  The two K1
+        factorisations (one wave, ~1.2 ms each) run concurrently (include/sgpmp.h: sgpmp_set_priors); priors whose
+        numbers did not change keep the factor already on the device."""
+        keys = {}
+        for which, (ss, sgp, sgoal) in ((L.PRIOR_INIT, init), (L.PRIOR_SAMPLE, sample)):
+            keys[which] = (float(dt), float(ss), float(sgp), None if sgoal is None else float(sgoal), None)
+        stale = [w for w in keys if self._prior_key.get(w) != keys[w]]
+        if len(stale) == 1:
+            w = stale[0]
+            ss, sgp, sgoal = init if w == L.PRIOR_INIT else sample
+            return self.set_prior(w, dt, ss, sgp, sgoal)
+        if not stale:
+            return
+        arr = lambda i: (C.c_double * 2)(*[float(-1.0 if v[i] is None else v[i]) for v in (init, sample)])   # noqa: E731
+        for w in stale:
+            self._prior_key.pop(w, None)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_set_priors(self._ctx, float(dt), arr(0), arr(1), arr(2), L.stream_ptr()))
+        self._prior_key.update(keys)
+
     def get_prior(self, which, n_modes=None):
         """-> (blocks [4,d,d], G [T,d,d], H [T,d,d]) as fp64 CPU tensors (inspection/tests); after
         set_prior_blocks pass n_modes: G, H are [n_modes,T,d,d] and blocks is None."""

@@ -166,9 +166,11 @@ class StochGPMP:
         traj_dim = (multi_goal_states.shape[0], self.num_particles_per_goal, T, self.d_state_opt)
         state_traj = torch.zeros(traj_dim, **self.tensor_args)
         mean_vel = (multi_goal_states[:, :n] - start_state[:n]) / (T * self.dt)
-        for i in range(T):
-            interp = start_state[:n] * (T - i - 1) / (T - 1) + multi_goal_states[:, :n] * i / (T - 1)
-            state_traj[:, :, i, :n] = interp.unsqueeze(1)
+        # (the reference's T-long loop as one expression with the same elementwise operations in the same order:
+        # 64 waypoints x 5 tiny launches were 3 ms of every reset())
+        i = torch.arange(T, **self.tensor_args).reshape(1, T, 1)
+        interp = start_state[:n] * (T - i - 1) / (T - 1) + multi_goal_states[:, None, :n] * i / (T - 1)   # [G,T,n]
+        state_traj[:, :, :, :n] = interp.unsqueeze(1)
         state_traj[:, :, :, n:] = mean_vel.unsqueeze(1).unsqueeze(1)
         return state_traj
 
@@ -180,9 +182,9 @@ class StochGPMP:
             return self.start_state.repeat(T, 1).unsqueeze(0).contiguous()
         means = torch.zeros(self.num_goals, T, self.d_state_opt, **self.tensor_args)
         vel = (self.multi_goal_states[:, :n] - self.start_state[:n]) / (steps * self.dt)
-        for i in range(T):
-            means[:, i, :n] = self.start_state[:n] * (steps - i) * 1. / steps \
-                + self.multi_goal_states[:, :n] * i * 1. / steps
+        i = torch.arange(T, **self.tensor_args).reshape(1, T, 1)        # (one expression instead of a T-long loop)
+        means[:, :, :n] = self.start_state[:n] * (steps - i) * 1. / steps \
+            + self.multi_goal_states[:, None, :n] * i * 1. / steps
         means[:, :, n:] = vel.unsqueeze(1)
         return means
 
@@ -210,8 +212,12 @@ class StochGPMP:
         eng = self._engine
         goal_init = self.sigma_goal_init if self.goal_directed else None
         goal_sample = self.sigma_goal_sample if self.goal_directed else None
-        # K1 twice (init + sampling priors): planner.py:206-212, 218-225
-        eng.set_prior(L.PRIOR_SAMPLE, self.dt, self.sigma_start_sample, self.sigma_gp_sample, goal_sample)
+        # K1 twice (init + sampling priors): planner.py:206-212, 218-225 -- side by side when both are needed
+        if initial_particle_means is None:
+            eng.set_priors(self.dt, (self.sigma_start_init, self.sigma_gp_init, goal_init),
+                           (self.sigma_start_sample, self.sigma_gp_sample, goal_sample))
+        else:
+            eng.set_prior(L.PRIOR_SAMPLE, self.dt, self.sigma_start_sample, self.sigma_gp_sample, goal_sample)
         # (the draw counter keeps running across reset(), as the reference's generator does: a
         # replanning loop must not see the same noise after every reset)
 
@@ -222,7 +228,6 @@ class StochGPMP:
                 pm = initial_particle_means
             pm = pm.to(**ta)
         else:
-            eng.set_prior(L.PRIOR_INIT, self.dt, self.sigma_start_init, self.sigma_gp_init, goal_init)
             init_means = self._const_vel_prior_means().contiguous()
             eps = None
             if self.noise == 'torch':                      # reference draw #1: randn(nppg, G, M)
