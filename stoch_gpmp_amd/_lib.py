@@ -147,9 +147,15 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
+def stream_ptr(device_index=None):
+    """The current HIP stream of `device_index` (default: the current device) as a raw handle.
+    (torch._C._cuda_getCurrentRawStream where this torch has it: 0.3 us instead of the 7 us that building a
+    torch.cuda.Stream object costs -- a third of the host time of a step at the launch-bound sizes.)"""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return C.c_void_p(raw(torch.cuda.current_device() if device_index is None else device_index))
+    return C.c_void_p(torch.cuda.current_stream(device_index).cuda_stream)
 
 
 def require_cuda(tensor_args):

@@ -311,8 +311,7 @@ class Engine:
         def call(draw, flags=0):
             if torch.cuda.current_device() != dev_index:
                 torch.cuda.set_device(dev_index)
-            L.check(fn(ctx, seed, draw, None, 0, 0, *fixed, flags,
-                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            L.check(fn(ctx, seed, draw, None, 0, 0, *fixed, flags, L.stream_ptr(dev_index)))
         return call
 
     def fk(self, q):
