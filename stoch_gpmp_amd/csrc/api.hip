@@ -865,7 +865,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     // K5 is skipped when the previous step's update kernel already prepared the weights for exactly these
     // means (the caller vouches with SGPMP_STEP_MEANS_KEPT that nothing else wrote them since); the fused
     // launch then zeroes the statistics itself
-    const bool prepared = fused && (flags & SGPMP_STEP_MEANS_KEPT) && c->isw_ready && c->isw_means == means &&
+    const bool prepared = (flags & SGPMP_STEP_MEANS_KEPT) && c->isw_ready && c->isw_means == means &&
                           c->isw_temperature == temperature;
     c->isw_ready = false;
     if (!prepared)
@@ -883,7 +883,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     }
     if (!fused) {
         HIPCHK(launch_sample(D.dtype, D.n_dof, D.traj_len, pr, seed, draw, means, P, D.particle_offset, S, eps,
-                             eps_modes, eps_mode_offset, samples, st, c->tg));
+                             eps_modes, eps_mode_offset, samples, st, c->tg, prepared ? acc_stats : nullptr));
         if (se) HIPCHK(hipEventRecord(se->ev[2], st));
         HIPCHK(launch_cost(D.dtype, D.n_dof, D.traj_len, c->h_prog, c->d_chain, c->h_chain,
                            samples, (long long)P * S, (long long)D.particle_offset * S, spheres, n_spheres,
@@ -892,9 +892,8 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     if (se) HIPCHK(hipEventRecord(se->ev[3], st));
     // (a fused step also has its update kernel prepare the NEXT step's importance-sampling weights)
     HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
-                         temperature, step_size, weights, grad, means_prev, acc_stats, st, k4_done,
-                         fused ? &pr : nullptr, fused ? c->d_isw : nullptr));
-    if (fused) { c->isw_ready = true; c->isw_means = means; c->isw_temperature = temperature; }
+                         temperature, step_size, weights, grad, means_prev, acc_stats, st, k4_done, &pr, c->d_isw));
+    c->isw_ready = true; c->isw_means = means; c->isw_temperature = temperature;
     if (se) HIPCHK(hipEventRecord(se->ev[4], st));
     // multi-GPU: sum the statistics over all ranks on the side stream (never gates the next step)
     if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats, false));

@@ -20,6 +20,13 @@
 //     tile is flushed, once per VW-wide vector instead of per scalar;
 //   * tiles are flushed as whole row segments with VW-wide stores (16 B per lane when the row pitch
 //     allows), so a wave writes contiguous spans instead of 4-byte fragments 3.5 KB apart.
+// A step whose importance-sampling weights were prepared by the previous update kernel has no K5 launch to zero
+// its statistics: the sampler's first workgroup does it (K4 accumulates into them two launches later).
+#define SGPMP_ZERO_STATS(ptr)                                                                     \
+    do {                                                                                          \
+        if ((ptr) && blockIdx.x == 0 && blockIdx.y == 0)                                          \
+            for (int i_ = threadIdx.x; i_ < SGPMP_STAT_SHARDS * 4; i_ += blockDim.x) (ptr)[i_] = 0.; \
+    } while (0)
 #define SGPMP_SAMPLE_TC 16
 #define SGPMP_SAMPLE_PAD(n) ((n) > 4 ? 8 : 4)
 
@@ -28,7 +35,8 @@ __global__ void __launch_bounds__(256)
 sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*[T][8]*/,
                   const real* __restrict__ means, const real* __restrict__ eps, int eps_modes,
                   int eps_mode_offset, int mode_offset, uint64_t seed, uint64_t draw, int lpr_shift,
-                  real* __restrict__ out) {
+                  real* __restrict__ out, double* __restrict__ zero_stats) {
+    SGPMP_ZERO_STATS(zero_stats);
     // Each WAVE owns spw = 64 / n samples (one lane per (sample, dof)) and its own rows of the LDS
     // tile, so producing a tile and flushing it need no workgroup barrier: waves run out of step and
     // one wave's stores overlap the others' arithmetic.
@@ -153,7 +161,9 @@ sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*
 template <typename real>
 __global__ void __launch_bounds__(256)
 sample_iso_small_kernel(int n, int T, int S, const real* __restrict__ coef, const real* __restrict__ means,
-                        int mode_offset, uint64_t seed, uint64_t draw, real* __restrict__ out) {
+                        int mode_offset, uint64_t seed, uint64_t draw, real* __restrict__ out,
+                        double* __restrict__ zero_stats) {
+    SGPMP_ZERO_STATS(zero_stats);
     typedef real vec __attribute__((ext_vector_type(2)));
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int TC = SGPMP_SMALL_TC, SPB = SGPMP_SMALL_SPB;
@@ -255,7 +265,8 @@ __global__ void __launch_bounds__(256)
 sample_dense_kernel(int n, int T, int S, const real* __restrict__ G, const real* __restrict__ H, size_t mode_stride,
                     const real* __restrict__ means, const real* __restrict__ eps, int eps_modes,
                     int eps_mode_offset, int mode_offset, uint64_t seed, uint64_t draw,
-                    real* __restrict__ out) {
+                    real* __restrict__ out, double* __restrict__ zero_stats) {
+    SGPMP_ZERO_STATS(zero_stats);
     using DT = DenseTile<real>;
     const int D = 2 * n;
     const int m = blockIdx.y;
@@ -318,7 +329,7 @@ template <typename real>
 static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t seed, uint64_t draw,
                                   const real* means, int n_modes, int mode_offset, int S,
                                   const real* eps, int eps_modes, int eps_mode_offset, real* out,
-                                  hipStream_t stream, const SgpmpToggles& tg) {
+                                  hipStream_t stream, const SgpmpToggles& tg, double* zero_stats) {
     constexpr bool f64 = sizeof(real) == 8;
     if (prior.isotropic) {
         const real* coef = f64 ? (const real*)prior.iso64 : (const real*)prior.iso32;
@@ -331,7 +342,7 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
             dim3 sgrid((S + SGPMP_SMALL_SPB - 1) / SGPMP_SMALL_SPB, n_modes);
             const size_t slds = ((size_t)SGPMP_SMALL_SPB * (SGPMP_SMALL_TC * d + 4) + SGPMP_SMALL_TC * 8) * sizeof(real);
             hipLaunchKernelGGL((sample_iso_small_kernel<real>), sgrid, dim3(256), slds, stream, n, T, S, coef, means,
-                               mode_offset, seed, draw, out);
+                               mode_offset, seed, draw, out, zero_stats);
             return hipGetLastError();
         }
         const int wpb = waves < 4 ? waves : 4;
@@ -345,10 +356,10 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
         while ((1 << lpr_shift) < SGPMP_SAMPLE_TC * d / vw && lpr_shift < 6) ++lpr_shift;
         if (f64 || !v16)
             hipLaunchKernelGGL((sample_iso_kernel<real, 2>), grid, block, lds, stream, n, T, S, spw, coef,
-                               means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, lpr_shift, out);
+                               means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, lpr_shift, out, zero_stats);
         else
             hipLaunchKernelGGL((sample_iso_kernel<real, 4>), grid, block, lds, stream, n, T, S, spw, coef,
-                               means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, lpr_shift, out);
+                               means, eps, eps_modes, eps_mode_offset, mode_offset, seed, draw, lpr_shift, out, zero_stats);
         return hipGetLastError();
     }
     const real* G = f64 ? (const real*)prior.G : (const real*)prior.G32;
@@ -358,19 +369,19 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
     if (n < 1 || n > 8) return hipErrorInvalidValue;     // state block = one 16 x 16 tile
     dim3 grid((S + 63) / 64, n_modes), block(256);       // 4 waves x 16 samples
     hipLaunchKernelGGL((sample_dense_kernel<real>), grid, block, 0, stream, n, T, S, G, H, mode_stride, means, eps,
-                       eps_modes, eps_mode_offset, mode_offset, seed, draw, out);
+                       eps_modes, eps_mode_offset, mode_offset, seed, draw, out, zero_stats);
     return hipGetLastError();
 }
 
 hipError_t launch_sample(int dtype, int n, int T, const PriorDev& prior, uint64_t seed, uint64_t draw,
                          const void* means, int n_modes, int mode_offset, int n_samples,
                          const void* eps, int eps_modes, int eps_mode_offset, void* out,
-                         hipStream_t stream, const SgpmpToggles& tg) {
+                         hipStream_t stream, const SgpmpToggles& tg, double* zero_stats) {
     if (dtype == SGPMP_F64)
         return sample_dispatch<double>(n, T, prior, seed, draw, (const double*)means, n_modes,
                                        mode_offset, n_samples, (const double*)eps, eps_modes,
-                                       eps_mode_offset, (double*)out, stream, tg);
+                                       eps_mode_offset, (double*)out, stream, tg, zero_stats);
     return sample_dispatch<float>(n, T, prior, seed, draw, (const float*)means, n_modes, mode_offset,
                                   n_samples, (const float*)eps, eps_modes, eps_mode_offset,
-                                  (float*)out, stream, tg);
+                                  (float*)out, stream, tg, zero_stats);
 }

@@ -140,7 +140,7 @@ hipError_t launch_prior_quadform(int dtype, int n, int T, long long rows, int n_
 hipError_t launch_sample(int dtype, int n, int T, const PriorDev& prior, uint64_t seed, uint64_t draw,
                          const void* means, int n_modes, int mode_offset, int n_samples,
                          const void* eps, int eps_modes, int eps_mode_offset, void* out,
-                         hipStream_t stream, const SgpmpToggles& tg);
+                         hipStream_t stream, const SgpmpToggles& tg, double* zero_stats = nullptr);
 
 hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const ChainDev* d_chain,
                        const ChainDev& h_chain, const void* trajs, long long batch,

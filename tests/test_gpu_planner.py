@@ -508,23 +508,28 @@ def test_three_dof_point_mass_fused_matches_the_two_launch_path(golden, nppg, G,
         assert torch.equal(a.particle_means, twin.particle_means) and torch.equal(a._costs, twin._costs)
 
 
-def test_prepared_is_weights_follow_every_edit_of_the_means():
-    """A fused step has its update kernel prepare the next step's importance-sampling weights, and the next
-    sgpmp_step skips K5 when the caller vouches (SGPMP_STEP_MEANS_KEPT) that the means are untouched.  The
+@pytest.mark.parametrize("ta,kernel", [(F32, "fused_step_kernel"), (F64, "cost_sweep_kernel<f64, chain code>")])
+def test_prepared_is_weights_follow_every_edit_of_the_means(ta, kernel):
+    """A step has its update kernel prepare the next step's importance-sampling weights, and the next
+    sgpmp_step skips K5 when the caller vouches (SGPMP_STEP_MEANS_KEPT) that the means are untouched (fused
+    fp32 steps: the fused launch zeroes the statistics; other steps: the sampler does).  The
     planner vouches only while the tensor's version counter stands still; a twin that NEVER vouches (it bumps
     the counter before every step, so K5 always runs) must stay bit-identical through plain steps, in-place
     edits of the means, and a `sample_and_eval` + `_update_distribution` detour."""
     T, nppg, S = 32, 6, 16
-    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
-    a = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=23)
-    b = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=23)
+    sph = torch.as_tensor(SC.panda_spheres()).to(**ta)
+    a = hip_panda_planner(SC.PANDA, T, nppg, S, ta, seed=23)
+    b = hip_panda_planner(SC.PANDA, T, nppg, S, ta, seed=23)
 
     def both(fn):
         fn(a)
         b.particle_means.add_(0)                         # version bump: b never claims "means kept"
         fn(b)
-        assert a._engine.last_cost_kernel() == b._engine.last_cost_kernel() == "fused_step_kernel"
+        assert a._engine.last_cost_kernel() == b._engine.last_cost_kernel()
+        assert a._engine.last_cost_kernel().startswith(kernel.split("<")[0]), a._engine.last_cost_kernel()
         assert torch.equal(a._costs, b._costs) and torch.equal(a.particle_means, b.particle_means)
+        sa, sb = a.global_stats(), b.global_stats()
+        assert abs(sa[0] / sb[0] - 1) < 1e-12 and abs(sa[1] / sb[1] - 1) < 1e-12
 
     step = lambda pl: pl.optimize(obstacle_spheres=sph)          # noqa: E731
     for _ in range(3):
