@@ -264,7 +264,7 @@ def test_panda_fp32_headline_kernel_means_match_fp64_oracle(fused, kernel):
     recs = _fp32_panda_run(T=32, nppg=48, S=32, iters=6, expect_kernel=kernel, fused=fused)
     frac = _report(f"Panda 48x32x32 rbf ({kernel})", recs)
     assert max(r["cost_rel"] for r in recs) < 5e-3
-    assert frac >= 0.99, frac                          # measured on MI355X: 1.0000 (arg-min identical for every particle)
+    assert frac >= 0.99, frac                          # measured on MI355X: 1.0000 (two-launch kernels), 0.9965 (fused: one near-tie of 288)
 
 
 @pytest.mark.parametrize("fused,kernel", [(True, "fused_step_kernel"), ("chunked", "cost_sweep_chunked_kernel"),
