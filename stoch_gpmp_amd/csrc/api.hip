@@ -297,14 +297,12 @@ extern "C" int sgpmp_set_priors(sgpmp_ctx* c, double dt, const double* sigma_sta
         HIPCHK(hipEventCreateWithFlags(&c->k1_fork, hipEventDisableTiming));
     }
     c->isw_ready = false;
-    HIPCHK(hipEventRecord(c->k1_fork, st));                       // whatever used the old factors comes first
-    HIPCHK(hipStreamWaitEvent(c->k1_side, c->k1_fork, 0));
     std::vector<double> qc((size_t)2 * n * n, 0.);
     for (int w = 0; w < 2; ++w)
         for (int i = 0; i < n; ++i) qc[(size_t)w * n * n + (size_t)i * n + i] = 1. / (sigma_gp[w] * sigma_gp[w]);
     HIPCHK(hipMemcpyAsync(c->d_qc, qc.data(), sizeof(double) * 2 * n * n, hipMemcpyHostToDevice, st));
-    HIPCHK(hipEventRecord(c->k1_fork, st));
-    HIPCHK(hipStreamWaitEvent(c->k1_side, c->k1_fork, 0));
+    HIPCHK(hipEventRecord(c->k1_fork, st));                       // the Q_c copy, and whatever used the old factors,
+    HIPCHK(hipStreamWaitEvent(c->k1_side, c->k1_fork, 0));        // precede the second factorisation too
     int status[2] = {0, 0};
     for (int w = 0; w < 2; ++w) {
         PriorDev& p = c->prior[w];
