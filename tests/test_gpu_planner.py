@@ -384,6 +384,38 @@ def test_fused_step_corners_match_the_two_launch_path(nppg, G, S, T, field_type,
         b.particle_means.copy_(a.particle_means)
 
 
+def test_fused_step_random_shapes_match_the_two_launch_path():
+    """Twelve seeded random shapes inside the fused launch's domain (S multiple of 8, T multiple of 16, 1-3 goals,
+    1-64 spheres, every field type, with and without the clamp): fused launch vs sampler + sweep, as in the
+    corner test above."""
+    rng = np.random.default_rng(2024)
+    c, n = SC.PANDA, 7
+    all_goals = [c["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n,
+                 [0.8, -0.2, 0.1, -1.0, -0.4, 1.1, 0.9] + [0.] * n]
+    for trial in range(12):
+        nppg, G = int(rng.integers(1, 6)), int(rng.integers(1, 4))
+        S, T = 8 * int(rng.integers(1, 6)), 16 * int(rng.integers(1, 7))
+        ft = ["rbf", "sdf", "occupancy"][int(rng.integers(0, 3))]
+        n_sph = int(rng.integers(1, 65))
+        goals = None if G == 1 else all_goals[:G]
+        sph = torch.as_tensor(SC.panda_spheres(num=n_sph, seed=trial)).to(**F32)
+        a = hip_panda_planner(c, T, nppg, S, F32, field_type=ft, seed=100 + trial, goals=goals)
+        b = hip_panda_planner(c, T, nppg, S, F32, field_type=ft, seed=100 + trial, goals=goals)
+        b._engine.set_option("no_fused_step", 1)
+        tag = f"trial {trial}: nppg={nppg} G={G} S={S} T={T} {ft} spheres={n_sph}"
+        for it in range(2):
+            a.optimize(obstacle_spheres=sph)
+            b.optimize(obstacle_spheres=sph)
+            assert a._engine.last_cost_kernel() == "fused_step_kernel", tag
+            assert b._engine.last_cost_kernel() != "fused_step_kernel", tag
+            scale = float(b.state_samples.abs().max())
+            assert float((a.state_samples - b.state_samples).abs().max()) <= 4e-7 * scale, tag
+            assert rel_err(a._costs, b._costs) < 2e-5, tag
+            assert float((a.particle_means - b.particle_means).abs().max()) <= 1e-6 * scale or \
+                not torch.equal(a._costs.argmin(1), b._costs.argmin(1)), tag      # (a near-tie may flip the arg-min)
+            b.particle_means.copy_(a.particle_means)
+
+
 @pytest.mark.parametrize("nppg,G,S,T,fused", [
     (2, 2, 8, 16, True), (3, 2, 24, 48, True), (5, 1, 16, 128, True), (1, 4, 8, 32, True),
     (2, 2, 12, 32, False),                    # S not a multiple of 8
