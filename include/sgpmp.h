@@ -222,7 +222,8 @@ int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, in
 /* flags of sgpmp_step: */
 #define SGPMP_STEP_MEANS_KEPT 1    /* the caller guarantees that `means` still holds exactly what this context's
                                       previous sgpmp_step left there: the importance-sampling weights that step's
-                                      update kernel prepared for them are then used, and the K5 launch is skipped.
+                                      update kernel prepared for them are then used, and the K5 launch is skipped
+                                      (on every path: the fused launch, or else the sampler, zeroes `stats`).
                                       Without the flag (or after anything else wrote the means) K5 runs. */
 
 /* The loop of planner.py:289-299 itself (`for opt_step in range(opt_iters)`), when its iterations follow each
