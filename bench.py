@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--field", default="rbf", choices=["rbf", "sdf", "occupancy"])
     ap.add_argument("--spheres", type=int, default=5, help="number of sphere obstacles (panda; 64 = stress variant)")
     ap.add_argument("--goals", type=int, default=1, help="panda: number of goals (config 5: 4)")
+    ap.add_argument("--shard-of", default=None, metavar="R,W",
+                    help="N=1 only: build shard R of W of a (particles x W)-particle problem without a process group "
+                         "(config 5's per-GPU share: --goals 4 --particles 512 --samples 256 --traj-len 128 --shard-of 3,8)")
     ap.add_argument("--single-iteration-calls", action="store_true",
                     help="time K calls of optimize(opt_iters=1) instead of one optimize(opt_iters=K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -346,6 +349,7 @@ def main():
         goals = 4
     pl, obs, name = build_planner(torch, args.workload, P_local, S, T, dtype, dev, rank, world,
                                   field=args.field, spheres=args.spheres, goals=goals,
+                                  shard_of=tuple(int(v) for v in args.shard_of.split(",")) if args.shard_of and world == 1 else None,
                                   force_stats_allreduce=use_dist and world == 1)
     w = 4 if dtype == torch.float32 else 8
     d = pl.d_state_opt

@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define SGPMP_ABI_VERSION 1
+/* 2: sgpmp_step gained `flags`, sgpmp_set_priors / pipeline_* / comm_* appeared (round 2); 3: round 3 (see git log).
+ * The Python binding refuses any other value at load time. */
+#define SGPMP_ABI_VERSION 3
 
 enum { SGPMP_F32 = 0, SGPMP_F64 = 1 };
 enum { SGPMP_PRIOR_INIT = 0, SGPMP_PRIOR_SAMPLE = 1 };
@@ -255,6 +257,10 @@ long long sgpmp_pipeline_split_steps(sgpmp_ctx* ctx);
 int sgpmp_comm_unique_id(unsigned char* out128);
 int sgpmp_comm_init(sgpmp_ctx* ctx, const unsigned char* id128, int world_size, int rank);
 int sgpmp_comm_destroy(sgpmp_ctx* ctx);
+/* What the attached communicator itself reports (ncclCommCount / ncclCommUserRank / ncclGetVersion), so that a
+ * multi-GPU bench line can prove that RCCL saw N ranks: *world = 0 when no communicator is attached.
+ * rccl_version: NCCL_VERSION_CODE of the loaded librccl (e.g. 22205), 0 if unavailable.  Any pointer may be NULL. */
+int sgpmp_comm_info(sgpmp_ctx* ctx, int* world, int* rank, int* rccl_version);
 /* Sum stats (DEVICE double[SGPMP_STAT_SHARDS][4], produced on `stream`) over all ranks, in place, on
  * the context's side stream: returns at once and never makes `stream` wait. (planner.py:668-672's
  * statistic over all particles of all GPUs.) */

@@ -206,6 +206,16 @@ extern "C" int sgpmp_comm_destroy(sgpmp_ctx* c) {
     return SGPMP_OK;
 }
 
+extern "C" int sgpmp_comm_info(sgpmp_ctx* c, int* world, int* rank, int* rccl_version) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_comm_info: null context");
+    if (world) *world = 0;
+    if (rank) *rank = 0;
+    if (rccl_version) *rccl_version = 0;
+    if (!c->comm) return SGPMP_OK;
+    COMMCHK(comm_info(c->comm, world, rank, rccl_version));
+    return SGPMP_OK;
+}
+
 extern "C" int sgpmp_allreduce_stats(sgpmp_ctx* c, double* stats, void* stream) {
     if (!c || !stats) return fail(SGPMP_EINVAL, "sgpmp_allreduce_stats: null argument");
     if (!c->comm) return fail(SGPMP_ESTATE, "sgpmp_allreduce_stats: no communicator (sgpmp_comm_init)");
@@ -774,6 +784,7 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
     const bool reduce = c->comm && stats;
     double* slots[2] = {stats, stats ? c->pipe.stats2 : nullptr};
     hipEvent_t k4_done[2] = {nullptr, nullptr};
+    bool tail[2] = {false, false};
     if (reduce)
         COMMCHK(comm_step_begin2(c->comm, c->pipe.side[0], c->pipe.side[1], &slots[0], &slots[1], &k4_done[0], &k4_done[1]));
     for (int h = 0; h < 2; ++h) {
@@ -798,9 +809,10 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
                                       (long long)Ph * S, cs, c64, sh));
         HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, Ph, S, c64, SGPMP_F64, X, mu, temperature, step_size,
                              weights ? weights + off * S * w : nullptr, grad ? grad + off * M * w : nullptr,
-                             means_prev ? means_prev + off * M * w : nullptr, slot, sh, k4_done[h], &pr, isw));
+                             means_prev ? means_prev + off * M * w : nullptr, slot, sh, k4_done[h], &pr, isw,
+                             &tail[h]));
     }
-    c->isw_ready = true; c->isw_means = means; c->isw_temperature = temperature;
+    c->isw_ready = tail[0] && tail[1]; c->isw_means = means; c->isw_temperature = temperature;
     if (reduce) COMMCHK(comm_step_end(c->comm, stats, true));
     c->pipe.last_stats = reduce ? nullptr : stats;
     c->pipe.split_steps += 1;
@@ -813,7 +825,24 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
                           int eps_mode_offset, void* means, void* samples, void* costs, void* weights,
                           void* grad, void* means_prev, const void* spheres, int n_spheres, double temperature,
                           double step_size, double* stats, int flags, void* stream) {
-    if (!c || !means || !samples) return fail(SGPMP_EINVAL, "sgpmp_step: null argument");
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_step: null context");
+    if (c->dims.num_particles == 0) {
+        // A rank whose shard is empty (more ranks than particles) has no kernels to run, but the per-step
+        // statistics all-reduce is a collective: it contributes a zeroed slot, or the other ranks' all-reduce
+        // never completes.
+        if (c->comm && stats) {
+            hipStream_t st0 = (hipStream_t)stream;
+            if (c->pipe.active) { int rcj = pipe_join(c, st0); if (rcj != SGPMP_OK) return rcj; }
+            double* slot = nullptr;
+            hipEvent_t done = nullptr;
+            COMMCHK(comm_step_begin(c->comm, st0, &slot, &done));
+            HIPCHK(hipMemsetAsync(slot, 0, sizeof(double) * SGPMP_STAT_SHARDS * 4, st0));
+            HIPCHK(hipEventRecord(done, st0));
+            COMMCHK(comm_step_end(c->comm, stats, false));
+        }
+        return SGPMP_OK;
+    }
+    if (!means || !samples) return fail(SGPMP_EINVAL, "sgpmp_step: null argument");
     if (!c->prior[SGPMP_PRIOR_SAMPLE].valid) return fail(SGPMP_ESTATE, "sgpmp_step: sampling prior not set");
     if (c->prior[SGPMP_PRIOR_SAMPLE].n_factor_modes > 0)
         return fail(SGPMP_ESTATE, "sgpmp_step: per-mode precisions (sgpmp_set_prior_blocks) are for sampling / log_prob only");
@@ -823,7 +852,6 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     if ((rc = check_spheres(c, spheres, n_spheres)) != SGPMP_OK) return rc;
     const sgpmp_dims& D = c->dims;
     const int P = D.num_particles, S = D.num_samples;
-    if (P == 0) return SGPMP_OK;
     if (eps && (eps_modes < 1 || eps_mode_offset < 0 || eps_mode_offset + P > eps_modes))
         return fail(SGPMP_EINVAL, "sgpmp_step: eps particle window out of range");
     hipStream_t st = (hipStream_t)stream;
@@ -888,10 +916,13 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
                            c->d_isw, S, pr.dt, costs, c->d_costs64, st, c->tg, &c->last_cost_kernel));
     }
     if (se) HIPCHK(hipEventRecord(se->ev[3], st));
-    // (a fused step also has its update kernel prepare the NEXT step's importance-sampling weights)
+    // (the update kernel also prepares the NEXT step's importance-sampling weights -- unless the new means do not
+    // fit its LDS beside the weights, launch_update decides)
+    bool tail_ran = false;
     HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
-                         temperature, step_size, weights, grad, means_prev, acc_stats, st, k4_done, &pr, c->d_isw));
-    c->isw_ready = true; c->isw_means = means; c->isw_temperature = temperature;
+                         temperature, step_size, weights, grad, means_prev, acc_stats, st, k4_done, &pr, c->d_isw,
+                         &tail_ran));
+    c->isw_ready = tail_ran; c->isw_means = means; c->isw_temperature = temperature;
     if (se) HIPCHK(hipEventRecord(se->ev[4], st));
     // multi-GPU: sum the statistics over all ranks on the side stream (never gates the next step)
     if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats, false));

@@ -28,6 +28,9 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     const char* (*GetErrorString)(ncclResult_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int*);
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*);
+    ncclResult_t (*GetVersion)(int*);
 };
 
 static RcclApi g_rccl = {};
@@ -49,6 +52,9 @@ static const char* load_rccl() {
     SYM(AllReduce, "ncclAllReduce")
     SYM(AllGather, "ncclAllGather")
     SYM(GetErrorString, "ncclGetErrorString")
+    SYM(CommCount, "ncclCommCount")
+    SYM(CommUserRank, "ncclCommUserRank")
+    SYM(GetVersion, "ncclGetVersion")
 #undef SYM
     g_rccl.handle = h;
     return nullptr;
@@ -80,9 +86,15 @@ static hipEvent_t* reduced_event(SgpmpComm* c, double* stats, bool create) {
     for (auto& p : c->reduced)
         if (p.first == stats) return &p.second;
     if (!create) return nullptr;
-    if (c->reduced.size() >= 8) {                            // buffers come and go (reset()): keep the table small
-        for (auto& p : c->reduced) hipEventDestroy(p.second);
-        c->reduced.clear();
+    if (c->reduced.size() >= 8) {
+        // buffers come and go (reset()): keep the table small -- but only entries whose all-reduce has COMPLETED
+        // may go (a later sgpmp_stats_wait for an evicted buffer finds no event and does not wait)
+        for (size_t i = 0; i < c->reduced.size();) {
+            if (hipEventQuery(c->reduced[i].second) == hipSuccess) {
+                hipEventDestroy(c->reduced[i].second);
+                c->reduced.erase(c->reduced.begin() + (long)i);
+            } else ++i;
+        }
     }
     hipEvent_t e;
     if (hipEventCreateWithFlags(&e, kEventFlags) != hipSuccess) return nullptr;
@@ -107,19 +119,21 @@ const char* comm_create(const unsigned char* id128, int world, int rank, SgpmpCo
     c->rank = rank; c->world = world; c->comm = nullptr;
     const ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
     if (r != ncclSuccess) { delete c; return g_rccl.GetErrorString(r); }
+    c->side = nullptr; c->produced = nullptr; c->ring = nullptr;
+    for (int i = 0; i < SGPMP_COMM_RING; ++i) {
+        c->ring_produced[i] = c->ring_produced2[i] = c->ring_reduced[i] = nullptr;
+        c->ring_used[i] = false;
+    }
     bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&c->produced, kEventFlags) == hipSuccess &&
               hipMalloc(&c->ring, sizeof(double) * SGPMP_COMM_RING * 2 * SGPMP_STAT_SHARDS * 4) == hipSuccess;
-    for (int i = 0; ok && i < SGPMP_COMM_RING; ++i) {
+    for (int i = 0; ok && i < SGPMP_COMM_RING; ++i)
         ok = hipEventCreateWithFlags(&c->ring_produced[i], kEventFlags) == hipSuccess &&
              hipEventCreateWithFlags(&c->ring_produced2[i], kEventFlags) == hipSuccess &&
              hipEventCreateWithFlags(&c->ring_reduced[i], kEventFlags) == hipSuccess;
-        c->ring_used[i] = false;
-    }
     c->step = 0;
     if (!ok) {
-        g_rccl.CommDestroy(c->comm);
-        delete c;
+        comm_destroy(c);                                     // (frees whatever was created: all handles start null)
         return "comm_create: cannot create the side stream / events / ring";
     }
     *out = c;
@@ -128,16 +142,32 @@ const char* comm_create(const unsigned char* id128, int world, int rank, SgpmpCo
 
 void comm_destroy(SgpmpComm* c) {
     if (!c) return;
-    hipStreamSynchronize(c->side);
+    if (c->side) hipStreamSynchronize(c->side);
     for (auto& p : c->reduced) hipEventDestroy(p.second);
-    hipEventDestroy(c->produced);
+    if (c->produced) hipEventDestroy(c->produced);
     for (int i = 0; i < SGPMP_COMM_RING; ++i) {
-        hipEventDestroy(c->ring_produced[i]); hipEventDestroy(c->ring_produced2[i]); hipEventDestroy(c->ring_reduced[i]);
+        if (c->ring_produced[i]) hipEventDestroy(c->ring_produced[i]);
+        if (c->ring_produced2[i]) hipEventDestroy(c->ring_produced2[i]);
+        if (c->ring_reduced[i]) hipEventDestroy(c->ring_reduced[i]);
     }
     hipFree(c->ring);
-    hipStreamDestroy(c->side);
+    if (c->side) hipStreamDestroy(c->side);
     if (c->comm) g_rccl.CommDestroy(c->comm);
     delete c;
+}
+
+// What the communicator ITSELF says (not what the caller passed to comm_create): a bench line quoting these
+// numbers proves that RCCL saw that many ranks.
+const char* comm_info(const SgpmpComm* c, int* world, int* rank, int* version) {
+    int w = 0, r = 0, v = 0;
+    ncclResult_t rc = g_rccl.CommCount(c->comm, &w);
+    if (rc == ncclSuccess) rc = g_rccl.CommUserRank(c->comm, &r);
+    if (rc == ncclSuccess) rc = g_rccl.GetVersion(&v);
+    if (rc != ncclSuccess) return g_rccl.GetErrorString(rc);
+    if (world) *world = w;
+    if (rank) *rank = r;
+    if (version) *version = v;
+    return nullptr;
 }
 
 int comm_rank(const SgpmpComm* c) { return c->rank; }

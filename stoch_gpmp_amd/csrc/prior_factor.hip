@@ -267,11 +267,15 @@ prior_quadform_kernel(int d, int T, long long rows, int n_modes, const real* __r
 hipError_t launch_prior_quadform(int dtype, int n, int T, long long rows, int n_modes, const void* x,
                                  const void* means, const PriorDev& prior, double* out, hipStream_t stream) {
     if (rows <= 0) return hipSuccess;
+    // per-mode blocks only while they are the prior's current precision (sgpmp_set_prior after
+    // sgpmp_set_prior_blocks leaves Dm / Em allocated but stale)
+    const double* Dm = prior.n_factor_modes > 0 ? prior.Dm : nullptr;
+    const double* Em = prior.n_factor_modes > 0 ? prior.Em : nullptr;
     if (dtype == SGPMP_F64)
         hipLaunchKernelGGL((prior_quadform_kernel<double>), dim3((unsigned)rows), dim3(64), 0, stream, 2 * n, T, rows,
-                           n_modes, (const double*)x, (const double*)means, prior.blocks, prior.Dm, prior.Em, out);
+                           n_modes, (const double*)x, (const double*)means, prior.blocks, Dm, Em, out);
     else
         hipLaunchKernelGGL((prior_quadform_kernel<float>), dim3((unsigned)rows), dim3(64), 0, stream, 2 * n, T, rows,
-                           n_modes, (const float*)x, (const float*)means, prior.blocks, prior.Dm, prior.Em, out);
+                           n_modes, (const float*)x, (const float*)means, prior.blocks, Dm, Em, out);
     return hipGetLastError();
 }

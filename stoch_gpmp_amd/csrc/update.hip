@@ -226,10 +226,19 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int costs_dtype,
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
-                         hipStream_t stream, hipEvent_t done, const PriorDev* isw_prior, void* isw_next) {
+                         hipStream_t stream, hipEvent_t done, const PriorDev* isw_prior, void* isw_next,
+                         bool* isw_written) {
     const int M = T * 2 * n;
     size_t lds = (size_t)S * (sizeof(double) + sizeof(int));
-    if (isw_prior) lds = ((lds + 15) & ~(size_t)15) + (size_t)M * (dtype == SGPMP_F64 ? 8 : 4);   // + the new means
+    if (isw_prior) {
+        // + the new means for the tail.  Shapes whose weights fit the 64 KB of a workgroup but not together with
+        // the means (e.g. S = 4096, T = 512, n = 7 in fp32: 77 KB) run WITHOUT the tail: the next step then
+        // computes its importance-sampling weights with K5, as before the tail existed.
+        const size_t with_tail = ((lds + 15) & ~(size_t)15) + (size_t)M * (dtype == SGPMP_F64 ? 8 : 4);
+        if (with_tail + 256 <= 65536) lds = with_tail;
+        else isw_prior = nullptr;
+    }
+    if (isw_written) *isw_written = isw_prior != nullptr && P > 0;
     if (P <= 0) return hipSuccess;
     dim3 grid(P), block(256);
     // `done` (multi-GPU statistics): the event is signalled by this kernel's own dispatch packet

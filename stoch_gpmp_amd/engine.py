@@ -75,6 +75,13 @@ class Engine:
         with torch.cuda.device(self.device):
             L.check(self.lib.sgpmp_comm_init(self._ctx, unique_id, int(world_size), int(rank)))
 
+    def comm_info(self):
+        """(world, rank, rccl_version) as the attached RCCL communicator itself reports them (ncclCommCount,
+        ncclCommUserRank, ncclGetVersion); world == 0 when no communicator is attached."""
+        w, r, v = C.c_int(), C.c_int(), C.c_int()
+        L.check(self.lib.sgpmp_comm_info(self._ctx, C.byref(w), C.byref(r), C.byref(v)))
+        return w.value, r.value, v.value
+
     def allreduce_stats(self, stats):
         with torch.cuda.device(self.device):
             L.check(self.lib.sgpmp_allreduce_stats(self._ctx, L.ptr(stats), L.stream_ptr()))

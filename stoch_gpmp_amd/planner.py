@@ -417,6 +417,13 @@ class StochGPMP:
                                   weights=self._weights_buf, grad=self._grad, means_prev=self._means_prev,
                                   spheres=self._spheres(observation), eps=self._draw_eps(),
                                   eps_mode_offset=self.p0, stats=self._stats[slot])
+        elif self._comm_attached:
+            # an empty shard (more ranks than particles) still joins the step's statistics all-reduce: it is a
+            # collective, and the other ranks' side streams would wait for this rank for ever
+            if self.noise == 'torch':
+                self._draw_eps()                         # (keep the global generator aligned with the other ranks)
+            self._engine.step(self.seed, self._draw, self.particle_means, self.state_samples, self.temperature,
+                              self.step_size, stats=self._stats[slot])
         self._draw += 1
         self._reduce_stats(slot)
         self._stats_slot ^= 1

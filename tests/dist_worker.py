@@ -26,6 +26,7 @@ def main():
     full = hip_panda_planner(SC.PANDA, T, P, S, ta, seed=4)                     # unsharded, on this GPU
     shard = hip_panda_planner(SC.PANDA, T, P, S, ta, seed=4, rank=rank, world_size=world)
     assert shard._comm_attached, "RCCL communicator not attached"
+    assert shard._engine.comm_info()[:2] == (world, rank), shard._engine.comm_info()   # RCCL's own count / rank
     assert torch.equal(shard.particle_means, full.particle_means[shard.p0:shard.p1])
     for _ in range(iters):
         full.optimize(obstacle_spheres=sph)
@@ -47,6 +48,19 @@ def main():
     assert torch.equal(shard2.particle_means, full2.particle_means[shard2.p0:shard2.p1]), "means differ (two chains)"
     gs2, gf2 = shard2.global_stats(), full2.global_stats()
     assert abs(gs2[0] / gf2[0] - 1) < 1e-12 and abs(gs2[1] / gf2[1] - 1) < 1e-12, (gs2, gf2)
+    # more ranks than particles: the ranks with an empty shard still join every step's statistics all-reduce
+    # (a collective) -- the others would hang in global_stats() / reset() otherwise
+    P3 = world - 1
+    full3 = hip_panda_planner(SC.PANDA, T, P3, S, ta, seed=9)
+    shard3 = hip_panda_planner(SC.PANDA, T, P3, S, ta, seed=9, rank=rank, world_size=world)
+    assert shard3._comm_attached and (shard3.num_particles_local == 0) == (rank == world - 1)
+    for k in (1, 3):
+        full3.optimize(opt_iters=k, obstacle_spheres=sph)
+        shard3.optimize(opt_iters=k, obstacle_spheres=sph)
+    gs3, gf3 = shard3.global_stats(), full3.global_stats()
+    assert abs(gs3[0] / gf3[0] - 1) < 1e-12 and abs(gs3[1] / gf3[1] - 1) < 1e-12, (gs3, gf3)
+    assert torch.equal(shard3.particle_means, full3.particle_means[shard3.p0:shard3.p1])
+    shard3.reset()
     dist.barrier()
     if rank == 0:
         print(f"DIST_OK world={world} stats={gs}")

@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libsgpmp.so does not export {name}"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in stoch_gpmp_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.sgpmp_abi_version() == 1
+    assert lib.sgpmp_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_ctypes_structs_match_the_c_layout(tmp_path):

@@ -42,7 +42,7 @@ def test_one_rank_rccl_statistics_allreduce_inside_the_step(one_rank_group):
     T, P, S = 32, 48, 32
     sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
     pl = hip_panda_planner(SC.PANDA, T, P, S, F32, seed=2, force_stats_allreduce=True)
-    assert pl._comm_attached
+    assert pl._comm_attached and pl._engine.comm_info()[:2] == (1, 0)      # what RCCL itself reports
     ref = hip_panda_planner(SC.PANDA, T, P, S, F32, seed=2)                    # no communicator
     assert not ref._comm_attached
     for it in range(5):
@@ -71,6 +71,24 @@ def test_one_rank_rccl_statistics_allreduce_inside_the_step(one_rank_group):
     assert pl._comm_attached
     pl.optimize(obstacle_spheres=sph)
     assert pl.global_stats()[0] > 0
+
+
+def test_empty_shard_still_joins_the_statistics_allreduce(one_rank_group):
+    """A context with zero particles (a rank of a world bigger than the particle count) has no kernels to run, but
+    sgpmp_step must still take part in the per-step all-reduce: it contributes a zeroed ring slot.  With one rank the
+    all-reduced statistics are then exactly zero, and nothing hangs (stats_wait, reset, destroy)."""
+    from stoch_gpmp_amd.engine import Engine
+    eng = Engine(7, 16, 0, 8, 1, 4, particle_offset=4, num_particles_global=4, tensor_args=F32)
+    eng.comm_init(eng.comm_unique_id(), 1, 0)
+    assert eng.comm_info()[:2] == (1, 0) and eng.comm_info()[2] > 0
+    stats = torch.full((64, 4), 7.0, device=DEV, dtype=torch.float64)
+    empty = torch.empty(0, 16, 14, **F32)
+    for draw in range(10):                                # (more steps than ring slots)
+        eng.step(0, draw, empty, torch.empty(0, 8, 16, 14, **F32), 1.0, 0.1, stats=stats)
+    eng.stats_wait(stats)
+    torch.cuda.synchronize()
+    assert float(stats.abs().sum()) == 0.0
+    eng.close()
 
 
 def test_two_chain_steps_with_the_rccl_statistics_allreduce(one_rank_group):
