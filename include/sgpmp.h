@@ -283,13 +283,22 @@ int sgpmp_grid_lookup(sgpmp_ctx* ctx, int term, const void* xy, int64_t batch, v
 int sgpmp_field_eval(sgpmp_ctx* ctx, int term, const void* frames, int64_t batch, int n_links,
                      const void* spheres, int n_spheres, void* out, void* stream);
 
+/* LinkDistanceField.distances / compute_collision / compute_distance (fields.py:40-61; spheres DEVICE [n_spheres,4]:
+ * D[l][o] = |p_l - c_o| - r_o) and LinkSelfDistanceField's (fields.py:100-112; spheres NULL: D[i][j] = |p_i - p_j|)
+ * on link frames [B,L,4,4] in ctx dtype.  mode 0: out [B,L,n_spheres or L] = D;  mode 1: out [B] = 1 where any
+ * D < buffer (self: over link pairs i - j >= 2, torch.tril(.., diagonal=-2)), else 0;  mode 2: out [B] = sum D. */
+int sgpmp_link_distances(sgpmp_ctx* ctx, const void* frames, int64_t batch, int n_links, const void* spheres,
+                         int n_spheres, int mode, double buffer, void* out, void* stream);
+
 /* FieldFactor.get_error(calc_jacobian=True) (factors/field_factor.py:28-38): value [B] (may be NULL) and
  * gradient d value / d q [B,n] of link-field term `term` at joint configurations q [B,n], with the
  * context's FK chain -- the analytic form of the reference's torch.autograd.grad through FK and the
- * field (the reference's H is MINUS this gradient).  Smooth fields only: SPHERES with the rbf type,
- * SELF and EE_GOAL (end-effector SE(3) distance: position part u . (z_j x (p - o_j)), rotation part
- * z_j . axis; what CostGoal.get_linear_system needs, cost_functions.py:323-337); sdf / occupancy ->
- * SGPMP_EINVAL.   */
+ * field (the reference's H is MINUS this gradient).  SPHERES with the rbf type; SPHERES with the sdf type
+ * (fields.py:79-83: value = max over (link point, sphere) of r - dist, optionally clamped at 0; gradient = that of
+ * the arg-max pair, first maximum in (point, sphere) order as torch's max keeps it, zero where the clamp is
+ * active -- what autograd returns through sdf.max(-1)[0].max(-1)[0]); SELF; EE_GOAL (end-effector SE(3) distance:
+ * position part u . (z_j x (p - o_j)), rotation part z_j . axis; what CostGoal.get_linear_system needs,
+ * cost_functions.py:323-337).  The occupancy count has no gradient -> SGPMP_EINVAL.   */
 int sgpmp_field_grad(sgpmp_ctx* ctx, int term, const void* q, int64_t batch, const void* spheres,
                      int n_spheres, void* value, void* grad, void* stream);
 
@@ -299,7 +308,7 @@ int sgpmp_field_grad(sgpmp_ctx* ctx, int term, const void* q, int64_t batch, con
  * the context), and -- when `diag_sum` [T*d] is given -- the sum over THIS context's particles of the
  * field part of diag(A^T K A), which the trust-region damping averages over all particles
  * (planner.py:618-622; all-reduce it across ranks before sgpmp_gpmp_solve when particles are sharded).
- * The cost list may hold one CostGP, one CostGoalPrior and up to 4 rbf-sphere / self-distance /
+ * The cost list may hold one CostGP, one CostGoalPrior and up to 4 rbf- or sdf-sphere / self-distance /
  * end-effector-goal fields (CostGoal: one row, on the last waypoint). */
 int sgpmp_gpmp_linearize(sgpmp_ctx* ctx, const void* means, const void* spheres, int n_spheres,
                          double* diag_sum, void* stream);

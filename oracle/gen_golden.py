@@ -429,11 +429,38 @@ def gen_gpmp():
     np.savez_compressed(os.path.join(OUT, "g7_gpmp.npz"), **out)
 
 
+def gen_field_surface():
+    """The remaining methods of the cited field classes (no caller inside the reference): distances /
+    compute_collision / compute_distance of both link fields (fields.py:40-61,100-112) and ObstacleMap.get_xy_grid
+    (obst_map.py:158-162), run on the frames and spheres of g4 plus a configuration with links in contact."""
+    z = np.load(os.path.join(OUT, "g4_panda_fields.npz"))
+    frames = torch.from_numpy(z["frames"]).clone()
+    frames[1, 2, 9, :3, 3] = frames[1, 2, 6, :3, 3] + 0.01        # links 9 and 6 nearly coincide (self collision)
+    frames[2, 1, 4, :3, 3] = torch.tensor([0.3, 0.1, 0.4]) + 0.05  # link 4 inside sphere 0
+    spheres = torch.from_numpy(z["spheres"])[0]                   # [O,4]
+    out = {"frames": npy(frames), "spheres": npy(spheres)}
+    for tag, ta in (("f64", F64), ("f32", F32)):
+        fr, sp = frames.to(**ta), spheres.to(**ta)
+        f = LinkDistanceField(tensor_args=ta)
+        out[f"{tag}/sph_distances"] = npy(f.distances(fr, sp))
+        out[f"{tag}/sph_collision"] = npy(f.compute_collision(fr, sp))
+        out[f"{tag}/sph_collision_b01"] = npy(f.compute_collision(fr, sp, buffer=0.1))
+        out[f"{tag}/sph_distance"] = npy(f.compute_distance(fr, sp))
+        s = LinkSelfDistanceField(tensor_args=ta)
+        out[f"{tag}/self_distances"] = npy(s.distances(fr))
+        out[f"{tag}/self_collision"] = npy(s.compute_collision(fr))
+        out[f"{tag}/self_collision_b02"] = npy(s.compute_collision(fr, buffer=0.2))
+        out[f"{tag}/self_distance"] = npy(s.compute_distance(fr))
+    om = ObstacleMap([4, 6], 0.5, tensor_args=F64)
+    out["xy_grid_4x6_c05"] = npy(om.get_xy_grid(torch.device("cpu")))
+    np.savez_compressed(os.path.join(OUT, "g8_field_surface.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
     gens = {"g1": gen_prior, "g2": gen_planar_e2e, "g3": gen_cost_terms, "g4": gen_panda_fields,
-            "g5": gen_update_and_is, "g6": gen_scene_tooling, "g7": gen_gpmp}
+            "g5": gen_update_and_is, "g6": gen_scene_tooling, "g7": gen_gpmp, "g8": gen_field_surface}
     for key in (sys.argv[1:] or sorted(gens)):          # `python oracle/gen_golden.py g6` regenerates one
         gens[key]()
     for f in sorted(os.listdir(OUT)):

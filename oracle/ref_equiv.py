@@ -220,6 +220,46 @@ def field_spheres(link_tensor, spheres, field_type='rbf', clamp_sdf=False, num_i
     raise ValueError(field_type)
 
 
+def link_sphere_distances(link_tensor, spheres):
+    """LinkDistanceField.distances -- fields.py:40-46: |p_l - c_o| - r_o, [..,L,O] (no interpolated points)."""
+    pos = link_tensor[..., :3, -1].unsqueeze(-2)
+    sph = spheres.reshape(-1, 4)
+    return torch.linalg.norm(pos - sph[:, :3], dim=-1) - sph[:, 3]
+
+
+def link_sphere_collision(link_tensor, spheres, buffer=0.02):
+    """LinkDistanceField.compute_collision -- fields.py:48-54."""
+    return (link_sphere_distances(link_tensor, spheres) < buffer).any(-1).any(-1)
+
+
+def link_sphere_distance_sum(link_tensor, spheres):
+    """LinkDistanceField.compute_distance -- fields.py:56-61."""
+    return link_sphere_distances(link_tensor, spheres).sum((-1, -2))
+
+
+def link_self_distances(link_tensor):
+    """LinkSelfDistanceField.distances -- fields.py:100-102: |p_i - p_j|, [..,L,L]."""
+    pos = link_tensor[..., :3, -1]
+    return torch.linalg.norm(pos.unsqueeze(-2) - pos.unsqueeze(-3), dim=-1)
+
+
+def link_self_collision(link_tensor, buffer=0.05):
+    """LinkSelfDistanceField.compute_collision -- fields.py:104-108: pairs at least two links apart (tril, diagonal -2)."""
+    return torch.tril(link_self_distances(link_tensor) < buffer, diagonal=-2).any(-1).any(-1)
+
+
+def link_self_distance_sum(link_tensor):
+    """LinkSelfDistanceField.compute_distance -- fields.py:110-112."""
+    return link_self_distances(link_tensor).sum((-1, -2))
+
+
+def xy_grid(xlim, ylim, x_dim, y_dim):
+    """ObstacleMap.get_xy_grid -- obst_map.py:158-162."""
+    xv, yv = torch.meshgrid([torch.linspace(xlim[0], xlim[1], x_dim), torch.linspace(ylim[0], ylim[1], y_dim)],
+                            indexing="ij")
+    return torch.stack((xv, yv), dim=2)
+
+
 def field_self(link_tensor, margin=0.03, num_interpolate=0, link_interpolate_range=(5, 7)):
     """LinkSelfDistanceField.compute_cost -- fields.py:114-124 (full LxL sum, diagonal included)."""
     pts = _link_points(link_tensor, num_interpolate, link_interpolate_range)

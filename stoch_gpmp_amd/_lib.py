@@ -78,6 +78,7 @@ SIGNATURES = {
     "sgpmp_fk": (_I, [_P, _P, _I64, _P, _P]),
     "sgpmp_grid_lookup": (_I, [_P, _I, _P, _I64, _P, _P]),
     "sgpmp_field_eval": (_I, [_P, _I, _P, _I64, _I, _P, _I, _P, _P]),
+    "sgpmp_link_distances": (_I, [_P, _P, _I64, _I, _P, _I, _I, _D, _P, _P]),
     "sgpmp_field_grad": (_I, [_P, _I, _P, _I64, _P, _I, _P, _P, _P]),
     "sgpmp_gpmp_linearize": (_I, [_P, _P, _P, _I, _P, _P]),
     "sgpmp_gpmp_solve": (_I, [_P, _P, _P, C.c_double, C.c_double, _P, _P, _P]),

@@ -85,6 +85,30 @@ class LinkDistanceField(DistanceField):
                     interp_lo=self.link_interpolate_range[0], interp_hi=self.link_interpolate_range[1],
                     alpha=_linspace_alpha(self.num_interpolate))
 
+    def _dist(self, link_tensor, obstacle_spheres, mode, buffer=0.0):
+        frames = link_tensor.contiguous()
+        sph = obstacle_spheres.to(device=frames.device, dtype=frames.dtype).reshape(-1, 4).contiguous()
+        return self._engine(frames.dtype, frames.device).link_distances(frames, sph, mode, buffer), sph.shape[0]
+
+    def distances(self, link_tensor, obstacle_spheres):
+        """fields.py:40-46: |p_l - c_o| - r_o for every link frame and sphere -> [.., L, O]."""
+        out, n_sph = self._dist(link_tensor, obstacle_spheres, 0)
+        return out.reshape(tuple(link_tensor.shape[:-2]) + (n_sph,))
+
+    def compute_collision(self, link_tensor, obstacle_spheres=None, buffer=0.02):
+        """fields.py:48-54: does any link come closer than `buffer` to any sphere? -> bool [..]"""
+        if obstacle_spheres is None:
+            return torch.zeros(link_tensor.shape[:2]).to(**self.tensor_args)
+        out, _ = self._dist(link_tensor, obstacle_spheres, 1, buffer)
+        return out.reshape(link_tensor.shape[:-3]) != 0
+
+    def compute_distance(self, link_tensor, obstacle_spheres=None, **kwargs):
+        """fields.py:56-61: the signed link-sphere distances summed over links and spheres."""
+        if obstacle_spheres is None:
+            return 1e10
+        out, _ = self._dist(link_tensor, obstacle_spheres, 2)
+        return out.reshape(link_tensor.shape[:-3])
+
     def compute_cost(self, link_tensor, obstacle_spheres=None, **kwargs):
         if obstacle_spheres is None:
             return 0                                        # fields.py:64-65
@@ -110,6 +134,22 @@ class LinkSelfDistanceField(DistanceField):
                     num_interpolate=self.num_interpolate,
                     interp_lo=self.link_interpolate_range[0], interp_hi=self.link_interpolate_range[1],
                     alpha=_linspace_alpha(self.num_interpolate))
+
+    def _dist(self, link_tensor, mode, buffer=0.0):
+        frames = link_tensor.contiguous()
+        return self._engine(frames.dtype, frames.device).link_distances(frames, None, mode, buffer)
+
+    def distances(self, link_tensor):
+        """fields.py:100-102: pairwise link distances -> [.., L, L]."""
+        return self._dist(link_tensor, 0).reshape(tuple(link_tensor.shape[:-2]) + (link_tensor.shape[-3],))
+
+    def compute_collision(self, link_tensor, buffer=0.05):
+        """fields.py:104-108: any pair of links at least two apart in the chain closer than `buffer`? -> bool [..]"""
+        return self._dist(link_tensor, 1, buffer).reshape(link_tensor.shape[:-3]) != 0
+
+    def compute_distance(self, link_tensor):
+        """fields.py:110-112: sum of all pairwise link distances."""
+        return self._dist(link_tensor, 2).reshape(link_tensor.shape[:-3])
 
     def compute_cost(self, link_tensor, **kwargs):
         shape = link_tensor.shape[:-3]

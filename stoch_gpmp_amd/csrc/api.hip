@@ -969,6 +969,16 @@ extern "C" int sgpmp_field_eval(sgpmp_ctx* c, int term, const void* frames, int6
     return SGPMP_OK;
 }
 
+extern "C" int sgpmp_link_distances(sgpmp_ctx* c, const void* frames, int64_t batch, int n_links, const void* spheres,
+                                    int n_spheres, int mode, double buffer, void* out, void* stream) {
+    if (!c || batch < 0 || n_links < 1 || (batch > 0 && (!frames || !out)) || mode < 0 || mode > 2 ||
+        (spheres && n_spheres < 1))
+        return fail(SGPMP_EINVAL, "sgpmp_link_distances: bad argument");
+    HIPCHK(launch_link_dist(c->dims.dtype, frames, batch, n_links, spheres, spheres ? n_spheres : n_links, mode, buffer,
+                            out, (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
 extern "C" int sgpmp_field_grad(sgpmp_ctx* c, int term, const void* q, int64_t batch, const void* spheres,
                                 int n_spheres, void* value, void* grad, void* stream) {
     if (!c || !q || !grad || batch < 0) return fail(SGPMP_EINVAL, "sgpmp_field_grad: bad argument");
@@ -979,8 +989,8 @@ extern "C" int sgpmp_field_grad(sgpmp_ctx* c, int term, const void* q, int64_t b
     if ((rc = finalize_program(c)) != SGPMP_OK) return rc;
     CostTerm t = c->h_prog.terms[term];
     if (t.kind == SGPMP_COST_SPHERES) {
-        if ((t.flags & 15) != SGPMP_FIELD_RBF)
-            return fail(SGPMP_EINVAL, "sgpmp_field_grad: only the rbf sphere field is differentiable here");
+        if ((t.flags & 15) == SGPMP_FIELD_OCCUPANCY)
+            return fail(SGPMP_EINVAL, "sgpmp_field_grad: the occupancy count has no gradient (rbf and sdf sphere fields do)");
         if (!spheres || n_spheres < 1) return fail(SGPMP_EINVAL, "LinkDistanceField cost needs obstacle_spheres");
     } else if (t.kind == SGPMP_COST_EE_GOAL) {
         HIPCHK(launch_ee_grad(c->dims.dtype, c->dims.n_dof, t, c->d_chain, q, batch, 0, 1, 0, value, grad,
@@ -1017,8 +1027,8 @@ static int gpmp_args(sgpmp_ctx* c, GpmpArgs& a, int* field_terms) {
                 a.Kg = t.K; a.goals = t.dev_data; a.rows_per_goal = D.num_particles_per_goal > 0 ? D.num_particles_per_goal : 1;
                 break;
             case SGPMP_COST_SPHERES:
-                if ((t.flags & 15) != SGPMP_FIELD_RBF)
-                    return fail(SGPMP_EINVAL, "GPMP: only the rbf sphere field has a Jacobian");
+                if ((t.flags & 15) == SGPMP_FIELD_OCCUPANCY)
+                    return fail(SGPMP_EINVAL, "GPMP: the occupancy sphere field has no Jacobian (rbf and sdf do)");
                 /* fall through */
             case SGPMP_COST_EE_GOAL:                      // (a field row on the last waypoint only)
             case SGPMP_COST_SELF:

@@ -1031,6 +1031,58 @@ __global__ void field_eval_kernel(const TermK<real> tm, const real* __restrict__
     if (b < batch) out[b] = v;
 }
 
+// LinkDistanceField.distances / compute_collision / compute_distance (fields.py:40-61) and the same three of
+// LinkSelfDistanceField (fields.py:100-112) on explicit frames [B,L,4,4]; no interpolated points there.
+//   other = spheres [O,4]:  D[l][o] = |p_l - c_o| - r_o                       (n_other = O)
+//   other = null (self):    D[i][j] = |p_i - p_j|                             (n_other = L)
+//   mode 0: out [B,L,n_other] = D;  mode 1: out [B] = any(D < buffer) -- self: over the pairs i - j >= 2 only
+//   (torch.tril(.., diagonal=-2), fields.py:106);  mode 2: out [B] = sum of D.
+// One thread per (configuration, link) in mode 0, per configuration otherwise.
+template <typename real>
+__global__ void link_dist_kernel(const real* __restrict__ frames, long long batch, int n_links,
+                                 const real* __restrict__ sph, int n_other, int mode, real buffer,
+                                 real* __restrict__ out) {
+    using O = RealOps<real>;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = mode == 0 ? batch * n_links : batch;
+    if (i >= total) return;
+    const long long b = mode == 0 ? i / n_links : i;
+    const real* f = frames + (size_t)b * n_links * 16;
+    const int l0 = mode == 0 ? (int)(i - b * n_links) : 0, l1 = mode == 0 ? l0 + 1 : n_links;
+    real acc = 0;
+    bool hit = false;
+    for (int l = l0; l < l1; ++l) {
+        const real px = f[l * 16 + 3], py = f[l * 16 + 7], pz = f[l * 16 + 11];
+        for (int o = 0; o < n_other; ++o) {
+            real cx, cy, cz, r = 0;
+            if (sph) { cx = sph[o * 4]; cy = sph[o * 4 + 1]; cz = sph[o * 4 + 2]; r = sph[o * 4 + 3]; }
+            else { cx = f[o * 16 + 3]; cy = f[o * 16 + 7]; cz = f[o * 16 + 11]; }
+            const real dx = px - cx, dy = py - cy, dz = pz - cz;
+            const real dist = O::sqrt_(dx * dx + dy * dy + dz * dz) - r;
+            if (mode == 0) out[(size_t)i * n_other + o] = dist;
+            acc += dist;
+            if (dist < buffer && (sph || l - o >= 2)) hit = true;
+        }
+    }
+    if (mode == 1) out[i] = hit ? (real)1 : (real)0;
+    if (mode == 2) out[i] = acc;
+}
+
+hipError_t launch_link_dist(int dtype, const void* frames, long long batch, int n_links, const void* spheres,
+                            int n_other, int mode, double buffer, void* out, hipStream_t stream) {
+    const long long total = mode == 0 ? batch * n_links : batch;
+    if (total <= 0) return hipSuccess;
+    const int block = 64;
+    const unsigned grid = (unsigned)((total + block - 1) / block);
+    if (dtype == SGPMP_F64)
+        hipLaunchKernelGGL((link_dist_kernel<double>), dim3(grid), dim3(block), 0, stream, (const double*)frames, batch,
+                           n_links, (const double*)spheres, n_other, mode, buffer, (double*)out);
+    else
+        hipLaunchKernelGGL((link_dist_kernel<float>), dim3(grid), dim3(block), 0, stream, (const float*)frames, batch,
+                           n_links, (const float*)spheres, n_other, mode, (float)buffer, (float*)out);
+    return hipGetLastError();
+}
+
 // EESE3DistanceField.compute_cost on explicit frames [B,L,4,4]: distance of the LAST link frame.
 template <typename real>
 __global__ void ee_field_kernel(EeTarget<real> tg, const real* __restrict__ frames, long long batch, int n_links,
@@ -1109,7 +1161,35 @@ field_grad_kernel(const ChainDev* __restrict__ ch, TermK<real> tm, int n, const 
 #pragma unroll
     for (int l = 0; l < npts; ++l) G[l][0] = G[l][1] = G[l][2] = 0;
     real val = 0;
-    if (tm.kind == SGPMP_COST_SPHERES) {                     // rbf only (checked by the host)
+    if (tm.kind == SGPMP_COST_SPHERES && (tm.flags & 15) == SGPMP_FIELD_SDF) {
+        // sdf (fields.py:79-83): value = max over (point, sphere) of r - dist (clamped from above at 0 with
+        // clamp_sdf).  The reference differentiates it by autograd (field_factor.py:35): the gradient is that of
+        // the arg-max pair -- torch's max(-1)[0].max(-1)[0] keeps the FIRST maximum, spheres within a point
+        // first, then points, hence point-major order and a strict comparison here -- i.e. -(p - c)/dist on that
+        // point, and exactly zero where the clamp is active (clamp(max=0) passes the gradient for sdf <= 0).
+        const bool clampv = (tm.flags & SGPMP_FLAG_SDF_CLAMP) != 0;
+        real best = (real)-__builtin_inff();
+        int bl = 0;
+        real bg[3] = {0, 0, 0};
+#pragma unroll
+        for (int l = 0; l < npts; ++l)
+            for (int o = 0; o < n_spheres; ++o) {
+                const real dx = P[l][0] - spheres[o * 4], dy = P[l][1] - spheres[o * 4 + 1], dz = P[l][2] - spheres[o * 4 + 2];
+                const real dist = O::sqrt_(dx * dx + dy * dy + dz * dz);
+                real sd = spheres[o * 4 + 3] - dist;
+                const bool cut = clampv && sd > (real)0;
+                if (cut) sd = 0;
+                if (sd > best) {
+                    best = sd; bl = l;
+                    const real w = cut ? (real)0 : (real)-1 / dist;
+                    bg[0] = w * dx; bg[1] = w * dy; bg[2] = w * dz;
+                }
+            }
+        val = best;
+#pragma unroll
+        for (int l = 0; l < npts; ++l)
+            if (l == bl) { G[l][0] = bg[0]; G[l][1] = bg[1]; G[l][2] = bg[2]; }
+    } else if (tm.kind == SGPMP_COST_SPHERES) {              // rbf (occupancy is refused by the host)
         for (int o = 0; o < n_spheres; ++o) {
             const real cx = spheres[o * 4], cy = spheres[o * 4 + 1], cz = spheres[o * 4 + 2], rr = spheres[o * 4 + 3];
             const real ir2 = (real)1 / (rr * rr);

@@ -210,6 +210,8 @@ struct GpmpArgs {
 hipError_t launch_gpmp_diag(int dtype, const GpmpArgs& a, double* diag_sum, hipStream_t stream);
 hipError_t launch_gpmp_solve(int dtype, const GpmpArgs& a, void* means, void* d_theta, void* costs,
                              hipStream_t stream);
+hipError_t launch_link_dist(int dtype, const void* frames, long long batch, int n_links, const void* spheres,
+                            int n_other, int mode, double buffer, void* out, hipStream_t stream);
 hipError_t launch_fk(int dtype, int n, const ChainDev* d_chain, int n_links, const void* q,
                      long long batch, void* frames, hipStream_t stream);
 hipError_t launch_grid_lookup(int dtype, const CostTerm& term, const void* xy, long long batch,

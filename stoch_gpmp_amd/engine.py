@@ -353,6 +353,24 @@ class Engine:
                                               L.ptr(spheres), n_sph, L.ptr(out), L.stream_ptr()))
         return out
 
+    def link_distances(self, frames, spheres=None, mode=0, buffer=0.0):
+        """fields.py:40-61,100-112 on frames [..,L,4,4]: mode 0 -> distances [B,L,O] (spheres) / [B,L,L] (self),
+        mode 1 -> 1.0 where any distance < buffer, mode 2 -> summed distances (include/sgpmp.h: sgpmp_link_distances)."""
+        self._chk(frames, "link_tensor")
+        n_links = frames.shape[-3]
+        B = frames.numel() // (n_links * 16)
+        n_sph = 0
+        if spheres is not None:
+            spheres = spheres.reshape(-1, 4)
+            self._chk(spheres, "obstacle_spheres")
+            n_sph = spheres.shape[0]
+        shape = (B, n_links, n_sph if spheres is not None else n_links) if mode == 0 else (B,)
+        out = torch.empty(shape, **self.tensor_args)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_link_distances(self._ctx, L.ptr(frames), B, n_links, L.ptr(spheres), n_sph, int(mode),
+                                                  float(buffer), L.ptr(out), L.stream_ptr()))
+        return out
+
     def field_grad(self, term, q, spheres=None):
         """Value [B] and gradient [B,n] of link-field term `term` at joint configurations q [B,n]
         (analytic FK Jacobians in `field_grad_kernel`)."""

@@ -84,6 +84,14 @@ class ObstacleMap:
         self._engines = {}
         return self.map_torch
 
+    def get_xy_grid(self, device):
+        """World coordinates of the grid nodes, [x_dim, y_dim, 2] (obst_map.py:158-162; a plotting / sampling helper
+        with no caller in the reference): x_dim points across xlim along axis 0, y_dim across ylim along axis 1."""
+        xs = torch.linspace(self.xlim[0], self.xlim[1], self.x_dim)
+        ys = torch.linspace(self.ylim[0], self.ylim[1], self.y_dim)
+        return torch.stack((xs[:, None].expand(self.x_dim, self.y_dim), ys[None, :].expand(self.x_dim, self.y_dim)),
+                           dim=2).to(device)
+
     def descriptor(self, sigma):
         if self.map_torch is None:
             self.convert_map()

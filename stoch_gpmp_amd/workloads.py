@@ -65,7 +65,7 @@ def hip_planar_planner(c, T, goals, nppg, S, obst_map, ta, initial_particle_mean
 
 
 def hip_panda_cost(c, T, nppg, S, ta, field_type='rbf', goals=None, with_self=True,
-                   with_spheres=True):
+                   with_spheres=True, clamp_sdf=False):
     n = c["n_dof"]
     start = torch.tensor(c["start_q"] + [0.] * n, **ta)
     goals_t = torch.tensor([c["goal_q"] + [0.] * n], **ta) if goals is None \
@@ -82,7 +82,7 @@ def hip_panda_cost(c, T, nppg, S, ta, field_type='rbf', goals=None, with_self=Tr
                                                                      tensor_args=ta),
                                    sigma_coll=c["sigma_self"], tensor_args=ta))
     if with_spheres:
-        terms.append(CostCollision(n, T, field=LinkDistanceField(field_type=field_type,
+        terms.append(CostCollision(n, T, field=LinkDistanceField(field_type=field_type, clamp_sdf=clamp_sdf,
                                                                  tensor_args=ta),
                                    sigma_coll=c["sigma_coll"], tensor_args=ta))
     return CostComposite(n, T, terms, FK=fk.compute_forward_kinematics_all_links, tensor_args=ta)
