@@ -485,7 +485,7 @@ def test_field_jacobian_matches_autograd_through_fk(dtype, rtol, which, interp):
     ta = TA(dtype)
     g = torch.Generator().manual_seed(11)
     trajs = torch.cat([torch.rand(B, T, n, generator=g) * 4 - 2, torch.randn(B, T, n, generator=g)], -1).double()
-    sph = torch.as_tensor(SC.panda_spheres(num=6, seed=3))
+    sph = torch.as_tensor(SC.panda_spheres(num=6, seed=3)).reshape(-1, 4)
     if which == "rbf":
         field = LinkDistanceField(field_type="rbf", num_interpolate=interp, tensor_args=ta)
         fn = lambda fr: R.field_spheres(fr, sph, field_type="rbf", num_interpolate=interp)   # noqa: E731
@@ -496,7 +496,7 @@ def test_field_jacobian_matches_autograd_through_fk(dtype, rtol, which, interp):
         clamp = which == "sdf_clamp"
         if clamp:
             sph = sph.clone()
-            sph[:, 3] *= 3.0
+            sph[:, 3] *= 1.6
         field = LinkDistanceField(field_type="sdf", clamp_sdf=clamp, num_interpolate=interp, tensor_args=ta)
         fn = lambda fr: R.field_spheres(fr, sph, field_type="sdf", clamp_sdf=clamp, num_interpolate=interp)   # noqa: E731
         obs = {"obstacle_spheres": sph.to(**ta)}
@@ -508,14 +508,17 @@ def test_field_jacobian_matches_autograd_through_fk(dtype, rtol, which, interp):
     if which == "sdf_clamp":                              # the case is only a test if both regimes occur
         assert bool((err_o == 0).any()) and bool((err_o < 0).any())
         assert float(H_o[err_o == 0].abs().max()) == 0.0
-    if which.startswith("sdf") and dtype == torch.float32:
+    if which.startswith("sdf"):
         # inputs away from ties: rows whose two best (point, sphere) pairs lie closer than fp32 resolves may
-        # legitimately pick the other pair; the seeded inputs have none (margin asserted on the oracle's values)
+        # legitimately pick the other pair; the seeded inputs have none.  (EXACT ties do occur -- link frames that
+        # coincide for every q, e.g. panda_link8 / panda_hand: torch's max and the kernel both keep the first, and
+        # the gradient through either is the same function of q.)
         fr = fk_all_links(trajs[:, 1:, :n].reshape(-1, n))
         pts = R._link_points(fr, interp, (5, 7)).unsqueeze(-2)
         sd = (sph[:, 3] - torch.linalg.norm(pts - sph[:, :3], dim=-1)).reshape(pts.shape[0], -1)
-        top2 = sd.topk(2, dim=-1)[0]
-        assert float((top2[:, 0] - top2[:, 1]).min()) > 1e-5 or which == "sdf_clamp"
+        gap = sd.max(-1, keepdim=True)[0] - sd
+        gap[gap == 0] = float("inf")
+        assert float(gap.min()) > 1e-4
     ff = FieldFactor(n, 0.01, [1, T])
     err, H = ff.get_error(trajs.to(**ta), field, calc_jacobian=True, fk_chain=HIP_CHAIN, **obs)
     assert err.shape == (B, T - 1) and H.shape == (B, T - 1, n)

@@ -181,7 +181,8 @@ def test_planar_fp32_against_fp64_oracle_same_noise(golden):
         agree &= (d / ora.particle_means.abs().max()).numpy() < 1e-3
         # keep both sides on the same trajectory so later iterations stay comparable
         pl.particle_means.copy_(ora.particle_means.to(**F32))
-    assert agree.mean() >= 0.75, f"only {agree.mean():.2f} of the particles within 1e-3"
+    print(f"\n[fp32 parity] planar 16 x 32 x 64, reference noise: particles within 1e-3 over 5 iterations: {agree.mean():.4f}")
+    assert agree.mean() >= 0.9, f"only {agree.mean():.2f} of the particles within 1e-3 in EVERY one of 5 iterations"
 
 
 def _is_dot(samples, w, n, dt):
@@ -313,6 +314,161 @@ def test_planar_fp32_means_match_fp64_oracle_native_noise(golden):
         same.append(float((costs.cpu().argmin(1) == costs_o.argmin(1)).double().mean()))
     print(f"\n[fp32 parity] planar 64x32x64: particles within 1e-3: {np.mean(fr):.4f} {fr}; same arg-min {np.mean(same):.4f}")
     assert np.mean(fr) >= 0.99                         # measured: 1.0000 (arg-min identical for 99.7 %)
+
+
+# --------------------------------------------------------------------------- BASELINE's stated sizes, directly
+# The tests above meet the oracle in miniature and carry the result to the full sizes through kernel-vs-kernel
+# identities.  These run the HIP planner AT the sizes BASELINE.json states and check a handful of its particles
+# directly against the oracle: in-kernel noise is keyed on the GLOBAL particle index, so any particle of the big
+# run is reproducible on its own -- the oracle gets oracle.native_noise.native_eps for exactly those indices and
+# the same (fp32-representable) means, and must return the same costs [p, :] and the same updated means.
+_PARITY_LOG = {}
+
+
+def _record_parity(tag, rec):
+    """Measured fractions -> gpurun_out/parity_full_size.json (copied to profiles/rNN/ and quoted by bench.py)."""
+    import json
+    import os
+    _PARITY_LOG[tag] = rec
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        path = os.path.join(out, "parity_full_size.json")
+        old = json.load(open(path)) if os.path.exists(path) else {}
+        old.update(_PARITY_LOG)
+        json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+
+
+def _check_subset(tag, pl, local_idx, oracle_step, iters, obs, expect_kernel):
+    """Run `iters` iterations of the full-size HIP planner; after each, compare particles `local_idx` with
+    oracle_step(means [k,T,d] fp64, global indices, draw) -> (costs [k,S], samples [k,S,T,d], new means [k,T,d])."""
+    idx = torch.as_tensor(local_idx, device=DEV)
+    scale = None
+    trials = ok = flips = 0
+    worst_cost = worst_samples = worst_means = 0.0
+    for it in range(iters):
+        draw = pl._draw
+        mu = pl.particle_means[idx].cpu().double()
+        costs_o, samples_o, means_o = oracle_step(mu, [pl.p0 + i for i in local_idx], draw)
+        _, _, _, _, costs, _ = pl.optimize(**obs)
+        assert pl._engine.last_cost_kernel() == expect_kernel, pl._engine.last_cost_kernel()
+        scale = scale or float(means_o.abs().max())
+        x = pl.state_samples[idx].cpu().double()
+        worst_samples = max(worst_samples, float((x - samples_o).abs().max() / samples_o.abs().max()))
+        c32 = costs[idx].cpu().double()
+        worst_cost = max(worst_cost, float(((c32 - costs_o).abs() / costs_o.abs()).max()))
+        d = (pl.particle_means[idx].cpu().double() - means_o).abs().amax(dim=(1, 2)) / scale
+        worst_means = max(worst_means, float(d.max()))
+        for k in range(len(local_idx)):
+            trials += 1
+            if float(d[k]) < 1e-3:
+                ok += 1
+                continue
+            # the update is an arg-min over samples (temperature 1, costs of 1e9..1e11): a particle can only differ
+            # when the two best samples lie closer than the fp32 cost error, and then legitimately
+            a, b = int(c32[k].argmin()), int(costs_o[k].argmin())
+            gap = float((costs_o[k, a] - costs_o[k, b]).abs() / costs_o[k, b].abs())
+            assert a != b and gap < 2e-5, f"{tag}: particle {local_idx[k]} off by {float(d[k]):.2e} without a near-tie (gap {gap:.2e})"
+            flips += 1
+    rec = dict(particles=[int(pl.p0 + i) for i in local_idx], iterations=iters, trials=trials,
+               means_within_1e3=ok / trials, argmin_flips_on_near_ties=flips, cost_rel_max=worst_cost,
+               samples_rel_max=worst_samples, means_rel_max=worst_means, kernel=expect_kernel)
+    print(f"\n[full-size parity] {tag}: {rec}")
+    _record_parity(tag, rec)
+    assert worst_samples < 2e-5 and worst_cost < 5e-3, rec
+    return rec
+
+
+def _dense_panda_oracle(T, S, k, seed, sph, goals=None):
+    """oracle_step for _check_subset on the dense reference-equivalent oracle (k particles of ONE goal)."""
+    from oracle.native_noise import native_eps
+    c, n = SC.PANDA, 7
+    ora = SC.oracle_panda_planner(c, T, k, S, seed=seed, goals=goals,
+                                  eps_init=torch.zeros(k, 1, T * 2 * n, dtype=torch.float64))
+
+    def step(mu, gidx, draw):
+        ora.particle_means.copy_(mu)
+        ora.prior.set_mean(ora.particle_means.view(k, -1))
+        eps = torch.from_numpy(native_eps(seed, draw, gidx, S, T, n, "float32")).double()
+        costs, _ = ora.step(eps=eps, obstacle_spheres=sph)
+        return costs, ora.state_samples.clone(), ora.particle_means.clone()
+    return step
+
+
+def test_config3_full_size_particles_match_the_dense_oracle():
+    """BASELINE configs[2] itself: Panda, 1024 particles x 128 samples x 64 waypoints, fp32, the fused launch.
+    Particles 0, 1, 511, 1023 (both ends of the XCD-aware workgroup map) against the dense fp64 oracle
+    (planner.py:229-275 restated), two iterations."""
+    T, S, P, seed = 64, 128, 1024, 31
+    sph = torch.as_tensor(SC.panda_spheres(num=5))
+    pl = hip_panda_planner(SC.PANDA, T, P, S, F32, seed=seed)
+    sub = [0, 1, 511, 1023]
+    rec = _check_subset("config 3: Panda 1024 x 128 x 64 fp32 (fused launch)", pl, sub,
+                        _dense_panda_oracle(T, S, len(sub), seed, sph), 2, {"obstacle_spheres": sph.to(**F32)},
+                        "fused_step_kernel")
+    assert rec["means_within_1e3"] + rec["argmin_flips_on_near_ties"] / rec["trials"] == 1.0
+
+
+def test_config4_last_shard_particles_match_the_dense_oracle():
+    """BASELINE configs[3]: 8192 particles sharded over 8 ranks; rank 7's shard (global particles 7168..8191) on this
+    GPU, its first and last particle (8191 = the highest global noise key of the problem) against the dense oracle."""
+    T, S, seed = 64, 128, 37
+    sph = torch.as_tensor(SC.panda_spheres(num=5))
+    pl = hip_panda_planner(SC.PANDA, T, 8192, S, F32, seed=seed, rank=7, world_size=8)
+    assert (pl.p0, pl.p1) == (7168, 8192)
+    sub = [0, 1023]
+    _check_subset("config 4: shard 7 of 8 of Panda 8192 x 128 x 64 fp32 (fused launch)", pl, sub,
+                  _dense_panda_oracle(T, S, len(sub), seed, sph), 1, {"obstacle_spheres": sph.to(**F32)},
+                  "fused_step_kernel")
+
+
+def test_config5_share_particles_match_the_banded_oracle():
+    """BASELINE configs[4]'s per-GPU share at its stated S x T: 4 goals x 1024 particles, 256 samples, 128 waypoints,
+    fp64 prior + fp32 cost path; shard 3 of 8 (global particles 1536..2047, all of goal 1).  Oracle:
+    oracle/banded_equiv.py (pinned to the dense oracle at 1e-9; the dense form needs 6 GB per particle here)."""
+    from oracle import banded_equiv as B
+    from oracle.native_noise import native_eps
+    c, n = SC.PANDA, 7
+    T, S, nppg, seed = 128, 256, 1024, 41
+    goals = torch.tensor([g + [0.] * n for g in [c["goal_q"], [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5],
+                                                 [0.9, -0.2, 0.4, -1.1, -0.3, 1.9, 0.8],
+                                                 [-0.8, 0.1, 0.6, -2.4, 0.4, 2.6, -0.2]]], dtype=torch.float64)
+    sph = torch.as_tensor(SC.panda_spheres(num=5))
+    pl = hip_panda_planner(c, T, nppg, S, F32, seed=seed, goals=goals.tolist(), rank=3, world_size=8)
+    assert (pl.p0, pl.p1) == (1536, 2048)
+    sub = [0, 255, 511]
+    g = pl.p0 // nppg
+    start = torch.tensor(c["start_q"] + [0.] * n, dtype=torch.float64)
+
+    def step(mu, gidx, draw):
+        band = B.BandedPlanner(len(sub), S, T, c["dt"], n, start, goals[g:g + 1],
+                               B.panda_chunk_cost(c, T, S, goals[g:g + 1], "rbf"), c["step_size"], c["temperature"],
+                               c["sigma_start_sample"], c["sigma_goal_sample"], c["sigma_gp_sample"], mu, chunk=1)
+        eps = torch.from_numpy(native_eps(seed, draw, gidx, S, T, n, "float32")).double()
+        costs, _ = band.step(eps, obstacle_spheres=sph)
+        return costs, band.state_samples.clone(), band.particle_means.clone()
+    _check_subset("config 5 share: shard 3 of 8 of Panda 4 goals x 1024 x 256 x 128 fp32 (fused launch)", pl, sub, step, 2,
+                  {"obstacle_spheres": sph.to(**F32)}, "fused_step_kernel")
+
+
+def test_config2_full_size_particles_match_the_dense_oracle(golden):
+    """BASELINE configs[1]: 2-D point mass, 4 goals x 64 particles, 64 samples, T = 128, fp32, fused_planar_kernel.
+    Two particles of every goal against the dense fp64 oracle, three iterations."""
+    from oracle.native_noise import native_eps
+    z = golden("g2_planar_e2e.npz")
+    T, nppg, S, n, seed = 128, 64, 64, 2, 43
+    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
+    pl = hip_planar_planner(SC.PLANAR, T, goals, nppg, S, planar_map(golden, F32), F32, seed=seed)
+    sub = [g * nppg + k for g in range(4) for k in ((7 * g) % nppg, nppg - 1 - g)]       # oracle order: g * 2 + k
+    ora = SC.oracle_planar_planner(SC.PLANAR, T, goals, 2, S, z["grid"], float(z["cell_size"]), z["c_offset"],
+                                   seed=seed, eps_init=torch.zeros(2, 4, T * 2 * n, dtype=torch.float64))
+
+    def step(mu, gidx, draw):
+        ora.particle_means.copy_(mu)
+        ora.prior.set_mean(ora.particle_means.view(len(sub), -1))
+        eps = torch.from_numpy(native_eps(seed, draw, gidx, S, T, n, "float32")).double()
+        costs, _ = ora.step(eps=eps)
+        return costs, ora.state_samples.clone(), ora.particle_means.clone()
+    _check_subset("config 2: planar 256 x 64 x 128 fp32 (fused_planar_kernel)", pl, sub, step, 3, {}, "fused_planar_kernel")
 
 
 # --------------------------------------------------------------------------- API surface
