@@ -63,6 +63,7 @@ SIGNATURES = {
     "sgpmp_pipeline_begin": (_I, [_P, _P]),
     "sgpmp_pipeline_end": (_I, [_P, _P]),
     "sgpmp_pipeline_split_steps": (C.c_longlong, [_P]),
+    "sgpmp_last_step_launches": (_I, [_P]),
     "sgpmp_set_prior": (_I, [_P, _I, _D, _D, _D, _D, C.POINTER(_D), _P]),
     "sgpmp_set_priors": (_I, [_P, _D, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), _P]),
     "sgpmp_get_prior": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),

@@ -76,6 +76,13 @@ struct sgpmp_ctx {
     double isw_temperature;
     const char* last_cost_kernel; // name of the cost-sweep kernel the dispatcher picked last
     StepPipe pipe;                // two-chain execution of consecutive steps (sgpmp_pipeline_begin / _end)
+    // K4 inside the fused launch (fused_tail.inc): per-particle arrival counters, per-launch finished-particle
+    // counters and statistics accumulators ([0]: whole range / first half, [1]: second half of a two-chain step);
+    // all zero between launches by construction (the launch's last waves reset them)
+    unsigned* d_arrive = nullptr;    // [P]
+    unsigned* d_done = nullptr;      // [2]
+    double* d_tail_acc = nullptr;    // [2][SGPMP_STAT_SHARDS][4]
+    int last_step_launches = 0;      // kernels the last sgpmp_step enqueued for its particle range (1: everything in one launch)
     hipStream_t k1_side = nullptr;   // sgpmp_set_priors: the second factorisation's stream
     hipEvent_t k1_fork = nullptr;
 };
@@ -87,6 +94,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"k3_no_one", &SgpmpToggles::k3_no_one}, {"k3_no_lds_prefetch", &SgpmpToggles::k3_no_lds_prefetch},
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
+    {"no_tail_update", &SgpmpToggles::no_tail_update},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {
@@ -163,6 +171,12 @@ extern "C" int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out) {
     const size_t P = (size_t)(dims->num_particles > 0 ? dims->num_particles : 1);
     HIPCHK(hipMalloc(&c->d_isw, P * (dims->traj_len + 1) * c->d * c->esz));
     HIPCHK(hipMalloc(&c->d_costs64, P * dims->num_samples * sizeof(double)));
+    HIPCHK(hipMalloc(&c->d_arrive, P * sizeof(unsigned)));
+    HIPCHK(hipMalloc(&c->d_done, 2 * sizeof(unsigned)));
+    HIPCHK(hipMalloc(&c->d_tail_acc, 2 * SGPMP_STAT_SHARDS * 4 * sizeof(double)));
+    HIPCHK(hipMemset(c->d_arrive, 0, P * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->d_done, 0, 2 * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->d_tail_acc, 0, 2 * SGPMP_STAT_SHARDS * 4 * sizeof(double)));
     *out = c;
     return SGPMP_OK;
 }
@@ -245,7 +259,7 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     free_prior(c->prior[0]);
     free_prior(c->prior[1]);
     hipFree(c->d_qc); hipFree(c->d_prog); hipFree(c->d_chain); hipFree(c->d_isw);
-    hipFree(c->d_costs64);
+    hipFree(c->d_costs64); hipFree(c->d_arrive); hipFree(c->d_done); hipFree(c->d_tail_acc);
     for (int i = 0; i < 4; ++i) { hipFree(c->d_fval[i]); hipFree(c->d_fgrad[i]); }
     hipFree(c->d_gscratch); hipFree(c->d_diag); hipFree(c->d_gstatus);
     for (void* p : c->owned) hipFree(p);
@@ -799,18 +813,27 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
         double* c64 = c->d_costs64 + off * S;
         if (!prepared) HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, mu, Ph, temperature, isw, slot, sh));
         bool launched = false;
+        char* wh = weights ? weights + off * S * w : nullptr;
+        char* gh = grad ? grad + off * M * w : nullptr;
+        char* mph = means_prev ? means_prev + off * M * w : nullptr;
+        // the update inside the launch when the half qualifies (its last particle writes the statistics into `slot`)
+        FusedTailHost th = {c->d_arrive + off, c->d_done + h, c->d_tail_acc + (size_t)h * SGPMP_STAT_SHARDS * 4, slot, wh, gh, mph,
+                            temperature, step_size};
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, mu, Ph,
                                  D.particle_offset + (int)off, S, X, spheres, n_spheres, isw, slot, cs, c64, sh, c->tg,
-                                 &c->last_cost_kernel, &launched));
+                                 &c->last_cost_kernel, &launched, &th, k4_done[h], &tail[h]));
         if (!launched) return fail(SGPMP_ESTATE, "sgpmp_step: a half of a pipelined step did not qualify for the fused launch");
+        c->last_step_launches = 1;
+        if (tail[h]) continue;
         for (int i = 0; i < c->h_prog.n_terms; ++i)
-            if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL)
+            if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) {
                 HIPCHK(launch_ee_goal(D.dtype, D.n_dof, D.traj_len, c->h_prog.terms[i], c->d_chain, X,
                                       (long long)Ph * S, cs, c64, sh));
-        HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, Ph, S, c64, SGPMP_F64, X, mu, temperature, step_size,
-                             weights ? weights + off * S * w : nullptr, grad ? grad + off * M * w : nullptr,
-                             means_prev ? means_prev + off * M * w : nullptr, slot, sh, k4_done[h], &pr, isw,
-                             &tail[h]));
+                c->last_step_launches += 1;
+            }
+        HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, Ph, S, c64, SGPMP_F64, X, mu, temperature, step_size, wh, gh, mph,
+                             slot, sh, k4_done[h], &pr, isw, &tail[h]));
+        c->last_step_launches += 1;
     }
     c->isw_ready = tail[0] && tail[1]; c->isw_means = means; c->isw_temperature = temperature;
     if (reduce) COMMCHK(comm_step_end(c->comm, stats, true));
@@ -820,6 +843,7 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
 }
 
 extern "C" long long sgpmp_pipeline_split_steps(sgpmp_ctx* c) { return c ? c->pipe.split_steps : 0; }
+extern "C" int sgpmp_last_step_launches(sgpmp_ctx* c) { return c ? c->last_step_launches : 0; }
 
 extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void* eps, int eps_modes,
                           int eps_mode_offset, void* means, void* samples, void* costs, void* weights,
@@ -897,15 +921,22 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     if (!prepared)
         HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, means, P, temperature, c->d_isw, acc_stats, st));
     if (se) { HIPCHK(hipEventRecord(se->ev[1], st)); se->has[0] = !prepared; }
+    c->last_step_launches = prepared ? 0 : 1;
+    bool tail_ran = false;                                       // the update ran inside the fused launch
     if (fused) {
         if (se) { HIPCHK(hipEventRecord(se->ev[2], st)); se->has[1] = false; }   // (fused: the whole launch is booked on the sweep)
+        // ... and the update too when the step qualifies (fused_tail.inc): ONE launch per iteration
+        FusedTailHost th = {c->d_arrive, c->d_done, c->d_tail_acc, acc_stats, weights, grad, means_prev, temperature, step_size};
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, means, P,
                                  D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, acc_stats, costs,
-                                 c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused));
+                                 c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, &th, k4_done, &tail_ran));
+        if (fused) c->last_step_launches += 1;
         for (int i = 0; fused && i < c->h_prog.n_terms; ++i)
-            if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL)
+            if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) {
                 HIPCHK(launch_ee_goal(D.dtype, D.n_dof, D.traj_len, c->h_prog.terms[i], c->d_chain, samples,
                                       (long long)P * S, costs, c->d_costs64, st));
+                c->last_step_launches += 1;
+            }
     }
     if (!fused) {
         HIPCHK(launch_sample(D.dtype, D.n_dof, D.traj_len, pr, seed, draw, means, P, D.particle_offset, S, eps,
@@ -914,16 +945,20 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         HIPCHK(launch_cost(D.dtype, D.n_dof, D.traj_len, c->h_prog, c->d_chain, c->h_chain,
                            samples, (long long)P * S, (long long)D.particle_offset * S, spheres, n_spheres,
                            c->d_isw, S, pr.dt, costs, c->d_costs64, st, c->tg, &c->last_cost_kernel));
+        c->last_step_launches += 2;
     }
     if (se) HIPCHK(hipEventRecord(se->ev[3], st));
-    // (the update kernel also prepares the NEXT step's importance-sampling weights -- unless the new means do not
-    // fit its LDS beside the weights, launch_update decides)
-    bool tail_ran = false;
-    HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
-                         temperature, step_size, weights, grad, means_prev, acc_stats, st, k4_done, &pr, c->d_isw,
-                         &tail_ran));
-    c->isw_ready = tail_ran; c->isw_means = means; c->isw_temperature = temperature;
-    if (se) HIPCHK(hipEventRecord(se->ev[4], st));
+    // (the update also prepares the NEXT step's importance-sampling weights -- unless, as a kernel of its own, the new
+    // means do not fit its LDS beside the weights: launch_update decides)
+    bool isw_written = tail_ran;
+    if (!tail_ran) {
+        HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
+                             temperature, step_size, weights, grad, means_prev, acc_stats, st, k4_done, &pr, c->d_isw,
+                             &isw_written));
+        c->last_step_launches += 1;
+    }
+    c->isw_ready = isw_written; c->isw_means = means; c->isw_temperature = temperature;
+    if (se) { HIPCHK(hipEventRecord(se->ev[4], st)); se->has[3] = !tail_ran; }
     // multi-GPU: sum the statistics over all ranks on the side stream (never gates the next step)
     if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats, false));
     return SGPMP_OK;

@@ -34,6 +34,8 @@
 #include "chain_code_generated.h"
 #include "rng.h"
 #include "sgpmp_internal.h"
+#include "update_common.h"
+#include <hip/hip_ext.h>
 
 template <typename real> struct RealOps;
 template <> struct RealOps<float> {
@@ -529,13 +531,28 @@ bool fused_step_eligible(int dtype, int n, int T, const PriorDev& prior, const C
     return fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg) != 0;
 }
 
+// Can the fused launch also do the update (K4 by the last wave of every particle, fused_tail.inc)?  The step must
+// qualify for the fused launch, its costs must be complete inside the launch (no end-effector term: ee_goal_kernel
+// adds to them afterwards) and the tail's scratch must fit a wave's tile.
+bool fused_tail_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
+                         const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
+                         const SgpmpToggles& tg) {
+    if (tg.no_tail_update || h_prog.n_ee > 0) return false;
+    const int kind = fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
+    if (kind != 1) return false;
+    const size_t tile_bytes = (size_t)SGPMP_FUSED_SPW * ((((2 * n + 3) / 4) * 4) + SGPMP_FUSED_TC * 2 * n) * 4;
+    return T <= 64 * SGPMP_TAIL_MAX_BLOCKS && tail_lds_bytes(S, T * 2 * n) <= tile_bytes;
+}
+
 // K2 + K3 in one launch when the step qualifies; *launched says whether it did.
 hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                              const ChainDev& h_chain, uint64_t seed, uint64_t draw, const void* means, int P,
                              int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
                              const void* isw, double* zero_stats, void* costs, double* costs64,
-                             hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched) {
+                             hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched,
+                             const FusedTailHost* tail, hipEvent_t done, bool* tail_ran) {
     *launched = false;
+    if (tail_ran) *tail_ran = false;
     using CCp = ChainCode_panda;
     const int kind = (!samples || !isw) ? 0 : fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
     if (kind == 0) return hipSuccess;
@@ -555,6 +572,16 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     fs.seed = seed; fs.draw = draw; fs.mode_offset = mode_offset; fs.S = S;
     fs.gpp = S / SGPMP_FUSED_SPW; fs.gpp_shift = log2_exact(fs.gpp);
     fs.zero_stats = zero_stats;
+    std::memset(&fs.tail, 0, sizeof(fs.tail));
+    if (tail && fused_tail_eligible(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg)) {
+        TailArgs& t = fs.tail;
+        t.arrive = tail->arrive; t.done = tail->done; t.acc = tail->acc; t.stats_out = tail->stats_out;
+        t.means = (float*)const_cast<void*>(means); t.weights = (float*)tail->weights; t.grad = (float*)tail->grad;
+        t.means_prev = (float*)tail->means_prev; t.isw_next = (float*)const_cast<void*>(isw);
+        t.Qinv = prior.Qinv; t.ks = prior.ks; t.kg = prior.kg; t.dt = prior.dt;
+        t.temperature = tail->temperature; t.step_size = tail->step_size; t.isotropic = prior.isotropic; t.P = P;
+        fs.zero_stats = nullptr;                              // (the launch's last particle writes the statistics)
+    }
     const long long nitems = batch / SGPMP_FUSED_SPW;
     long long blocks = (nitems + 3) / 4;
     // one item per wave measured fastest at config 3 (4096 workgroups 0.216 ms/iteration, 2048: 0.219,
@@ -571,13 +598,16 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         return hipGetLastError();
     }
     const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
+    // (`done`, multi-GPU statistics: signalled by this kernel's own dispatch packet -- hipExtLaunchKernelGGL stop
+    // event -- instead of a separate barrier packet behind it)
     if (ft == SGPMP_FIELD_RBF)
-        hipLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_RBF>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);
+        hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_RBF>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs);
     else if (ft == SGPMP_FIELD_SDF)
-        hipLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_SDF>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);
+        hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_SDF>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs);
     else
-        hipLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_OCCUPANCY>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);
+        hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_OCCUPANCY>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs);
     if (picked) *picked = "fused_step_kernel";
+    if (tail_ran) *tail_ran = fs.tail.arrive != nullptr;
     *launched = true;
     return hipGetLastError();
 }

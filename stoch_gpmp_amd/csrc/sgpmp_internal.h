@@ -107,6 +107,7 @@ struct SgpmpToggles {
     int no_fused_step;        // SGPMP_NO_FUSED_STEP        K2 and K3 as separate kernels inside sgpmp_step
     int no_chunked_sweep;     // SGPMP_NO_CHUNKED_SWEEP     64-lane-pass two-trajectory sweeps instead of the chunked one
     int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
+    int no_tail_update;       // SGPMP_NO_TAIL_UPDATE       update_kernel as a second launch instead of inside the fused launch
     long long pipe_split;     // SGPMP_PIPE_SPLIT           first chain's share of the particles in 16ths (0 = default 8)
     long long k3_blocks;      // SGPMP_K3_BLOCKS            workgroup cap of the dual sweep (0: default)
 };
@@ -149,12 +150,25 @@ hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const
                        const void* is_weights, int rows_per_particle, double is_dt, void* costs,
                        double* costs64, hipStream_t stream, const SgpmpToggles& tg, const char** picked);
 
+// K4 inside the fused launch (fused_tail.inc): what the host hands over; null = update_kernel follows the launch
+struct FusedTailHost {
+    unsigned* arrive;             // [P] arrival counters of the launch's particles (zero between launches)
+    unsigned* done;               // finished-particle counter (zero between launches)
+    double* acc;                  // [SGPMP_STAT_SHARDS][4] statistics accumulators (zero between launches)
+    double* stats_out;            // the step's statistics buffer or null
+    void* weights; void* grad; void* means_prev;   // K4's optional outputs (context dtype)
+    double temperature, step_size;
+};
+bool fused_tail_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
+                         const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
+                         const SgpmpToggles& tg);
 // K2 + K3 fused (cost_sweep.hip / fused_step.inc): launches only when the step qualifies (*launched)
 hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                              const ChainDev& h_chain, uint64_t seed, uint64_t draw, const void* means, int P,
                              int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
                              const void* isw, double* zero_stats, void* costs, double* costs64,
-                             hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched);
+                             hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched,
+                             const FusedTailHost* tail = nullptr, hipEvent_t done = nullptr, bool* tail_ran = nullptr);
 // does the step qualify for the fused launch? (same conditions, no launch)
 bool fused_step_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                          const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,

@@ -58,6 +58,10 @@ class Engine:
         """Steps of this context that ran as two chains so far."""
         return int(self.lib.sgpmp_pipeline_split_steps(self._ctx))
 
+    def last_step_launches(self):
+        """Kernels the last step enqueued for its particle range (1: the whole iteration in one launch)."""
+        return int(self.lib.sgpmp_last_step_launches(self._ctx))
+
     def last_cost_kernel(self):
         """Name of the cost-sweep kernel the dispatcher picked at the last launch."""
         return self.lib.sgpmp_last_cost_kernel(self._ctx).decode()
