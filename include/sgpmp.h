@@ -120,7 +120,7 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
 /* Development switches (kernel-variant A/B, tests of the fallback paths).  Every switch has an
  * environment variable SGPMP_<NAME> that is read ONCE, in sgpmp_create; this call changes a switch
  * on a live context.  Names: force_generic_fk, no_flat_program, no_chain_codegen, no_dual_sweep,
- * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, no_tail_update (0/1) and k3_blocks
+ * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, tail_update (0/1) and k3_blocks
  * (count).
  * No reference counterpart. */
 int sgpmp_set_option(sgpmp_ctx* ctx, const char* name, long long value);
@@ -243,7 +243,9 @@ int sgpmp_pipeline_begin(sgpmp_ctx* ctx, void* stream);
 int sgpmp_pipeline_end(sgpmp_ctx* ctx, void* stream);
 /* Kernels the last sgpmp_step enqueued for its particle range (per chain when it ran as two): 1 = the whole iteration
  * -- sampler, cost sweep, update and the next step's importance-sampling weights -- in ONE launch (csrc/fused_tail.inc:
- * the last wave of every particle updates it); 2 = fused sampler + sweep, then update_kernel; 3-4 = separate kernels. */
+ * the last wave of every particle updates it; opt-in through the "tail_update" switch, bit-identical results, measured
+ * slower than two launches at BASELINE's sizes: DESIGN.md); 2 = fused sampler + sweep, then update_kernel (the default);
+ * 3-4 = separate kernels. */
 int sgpmp_last_step_launches(sgpmp_ctx* ctx);
 /* how many steps of this context ran as two chains so far (tests and bench.py report it) */
 long long sgpmp_pipeline_split_steps(sgpmp_ctx* ctx);

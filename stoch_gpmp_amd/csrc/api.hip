@@ -94,7 +94,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"k3_no_one", &SgpmpToggles::k3_no_one}, {"k3_no_lds_prefetch", &SgpmpToggles::k3_no_lds_prefetch},
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
-    {"no_tail_update", &SgpmpToggles::no_tail_update},
+    {"tail_update", &SgpmpToggles::tail_update},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {
@@ -107,6 +107,7 @@ static void toggles_from_env(SgpmpToggles& tg) {
     }
     if (const char* e = getenv("SGPMP_K3_BLOCKS")) tg.k3_blocks = atoll(e);
     if (const char* e = getenv("SGPMP_PIPE_SPLIT")) tg.pipe_split = atoll(e);
+    if (const char* e = getenv("SGPMP_TAIL_DEBUG")) tg.tail_debug = atoll(e);
 }
 
 extern "C" int sgpmp_abi_version(void) { return SGPMP_ABI_VERSION; }

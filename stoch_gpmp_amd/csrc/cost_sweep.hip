@@ -537,11 +537,12 @@ bool fused_step_eligible(int dtype, int n, int T, const PriorDev& prior, const C
 bool fused_tail_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                          const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
                          const SgpmpToggles& tg) {
-    if (tg.no_tail_update || h_prog.n_ee > 0) return false;
+    if (!tg.tail_update || h_prog.n_ee > 0) return false;
     const int kind = fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
     if (kind != 1) return false;
     const size_t tile_bytes = (size_t)SGPMP_FUSED_SPW * ((((2 * n + 3) / 4) * 4) + SGPMP_FUSED_TC * 2 * n) * 4;
-    return T <= 64 * SGPMP_TAIL_MAX_BLOCKS && tail_lds_bytes(S, T * 2 * n) <= tile_bytes;
+    if (((long long)P * S / SGPMP_FUSED_SPW + 3) / 4 > (tg.k3_blocks > 0 ? tg.k3_blocks : (1LL << 18))) return false;   // one item per wave
+    return T <= 64 * SGPMP_TAIL_MAX_BLOCKS && S <= SGPMP_TAIL_MAX_S && tail_lds_bytes(S, T * 2 * n, 2 * n) <= tile_bytes;
 }
 
 // K2 + K3 in one launch when the step qualifies; *launched says whether it did.
@@ -580,6 +581,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         t.means_prev = (float*)tail->means_prev; t.isw_next = (float*)const_cast<void*>(isw);
         t.Qinv = prior.Qinv; t.ks = prior.ks; t.kg = prior.kg; t.dt = prior.dt;
         t.temperature = tail->temperature; t.step_size = tail->step_size; t.isotropic = prior.isotropic; t.P = P;
+        t.debug = (int)tg.tail_debug;
         fs.zero_stats = nullptr;                              // (the launch's last particle writes the statistics)
     }
     const long long nitems = batch / SGPMP_FUSED_SPW;

@@ -572,6 +572,113 @@ def test_fused_step_random_shapes_match_the_two_launch_path():
             b.particle_means.copy_(a.particle_means)
 
 
+# --------------------------------------------------------------------------- the update inside the fused launch
+def _one_vs_two_launches(build, iters, obs, soft=None, expect_one=True):
+    """The same planner twice: `a` lets the fused launch update the particles itself (csrc/fused_tail.inc, the last
+    wave of every particle; the opt-in "tail_update" switch), `b` runs update_kernel as a second launch (the default).  Same noise keys, same
+    arithmetic, same summation order: every buffer must come out bit-identical, statistics to rounding (their
+    atomics commute only up to the order of the additions)."""
+    a, b = build(), build()
+    a._engine.set_option("tail_update", 1)
+    if soft is not None:                                  # a temperature at which many samples carry weight:
+        probe = build()                                   # a sixth of the typical cost spread over a particle's samples
+        probe.optimize(**obs)
+        cp = probe._costs.double()
+        a.temperature = b.temperature = float((cp.max(1)[0] - cp.min(1)[0]).median()) / 6.0
+    for it in range(iters):
+        ra = a.optimize(**obs)
+        rb = b.optimize(**obs)
+        k5 = 1 if it == 0 else 0                          # (the first step after reset() computes its IS weights itself)
+        assert a._engine.last_step_launches() == (1 if expect_one else 2) + k5, (it, a._engine.last_step_launches())
+        assert b._engine.last_step_launches() == 2 + k5, b._engine.last_step_launches()
+        assert torch.equal(a._costs, b._costs) and torch.equal(a.state_samples, b.state_samples), it
+        assert torch.equal(a._weights_buf, b._weights_buf), it
+        assert torch.equal(a._grad, b._grad) and torch.equal(a._means_prev, b._means_prev), it
+        assert torch.equal(a.particle_means, b.particle_means), it
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y)
+        sa, sb = a.global_stats(), b.global_stats()
+        assert abs(sa[0] / sb[0] - 1) < 1e-12 and abs(sa[1] / sb[1] - 1) < 1e-12, (sa, sb)
+    return a, b
+
+
+@pytest.mark.parametrize("nppg,G,S,T,field_type,soft", [
+    (3, 1, 8, 16, "rbf", None),               # one wave per particle: every wave is its particle's last
+    (5, 2, 24, 48, "sdf", None),              # three waves per particle (not a power of two), two goals
+    (7, 1, 128, 64, "rbf", None),             # config 3's S x T: 16 waves per particle, one 64-waypoint block
+    (3, 2, 256, 128, "rbf", None),            # config 5's S x T: 32 waves per particle, two blocks
+    (4, 1, 128, 64, "rbf", True),             # soft weights: dozens of rows carry weight (pairs + an odd one out)
+    (3, 1, 256, 16, "occupancy", True),       # the largest S the in-launch update takes
+    (2, 1, 64, 128, "rbf", True),             # two 64-waypoint blocks with several rows each
+])
+def test_update_inside_the_fused_launch_equals_the_update_kernel_bitwise(nppg, G, S, T, field_type, soft):
+    c, n = SC.PANDA, 7
+    goals = None if G == 1 else [c["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n][:G]
+    if soft is not None:
+        # The importance-sampling term temperature * x Sigma^-1 mu (planner.py:233-236) scales WITH the temperature and
+        # its spread over the samples is ~ |mu_0| / sigma_start: with the Panda start state the weights are one-hot at
+        # any temperature.  Start and goal at the origin make it small, and the weights follow the other costs.
+        c = dict(c, start_q=[0.] * n, goal_q=[0.02] * n)
+    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=3)).to(**F32)
+    a, _ = _one_vs_two_launches(lambda: hip_panda_planner(c, T, nppg, S, F32, field_type=field_type, seed=23, goals=goals),
+                                4, {"obstacle_spheres": sph}, soft=soft)
+    if soft is not None:                                  # the case is only a test if the weights really are soft
+        nnz = (a._weights_buf != 0).sum(1)
+        assert int(nnz.max()) >= 3, nnz
+
+
+def test_update_inside_the_fused_launch_falls_back_where_it_does_not_fit():
+    """S = 264 is more than the 256 costs a wave holds in registers; T = 144 is more than two 64-waypoint blocks; a
+    CostGoal term adds to the costs after the launch: update_kernel follows in all three."""
+    from stoch_gpmp_amd.costs.cost_functions import CostGoal
+    from stoch_gpmp_amd.costs.fields import EESE3DistanceField
+    c = SC.PANDA
+    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=3)).to(**F32)
+    for S, T in ((264, 16), (8, 144)):
+        pl = hip_panda_planner(c, T, 2, S, F32, seed=5)
+        pl._engine.set_option("tail_update", 1)
+        pl.optimize(obstacle_spheres=sph)
+        assert pl._engine.last_cost_kernel() == "fused_step_kernel" and pl._engine.last_step_launches() == 3   # K5 + 2
+        pl.optimize(obstacle_spheres=sph)
+        assert pl._engine.last_step_launches() == 2
+    pl = hip_panda_planner(c, 32, 2, 16, F32, seed=5)
+    pl._engine.set_option("tail_update", 1)
+    pl.cost.cost_list.append(CostGoal(7, 32, field=EESE3DistanceField(torch.eye(4, **F32), tensor_args=F32), sigma_goal=1.,
+                                      tensor_args=F32))
+    pl.cost.touch()
+    pl.optimize(obstacle_spheres=sph)
+    pl.optimize(obstacle_spheres=sph)
+    assert pl._engine.last_cost_kernel() == "fused_step_kernel" and pl._engine.last_step_launches() == 3   # + ee_goal_kernel
+
+
+def test_full_size_one_launch_iterations_equal_two_launch_iterations_bitwise():
+    """BASELINE configs[2] (Panda 1024 x 128 x 64): 30 iterations as ONE launch each against fused launch +
+    update_kernel; every buffer bit-identical after every iteration.  The chip is full (4096 workgroups, four per
+    CU) and the particles' last waves finish all over the launch: the hand-off of rows and costs between waves on
+    different CUs (sc1 stores, arrival counter, sc1 loads) is exercised 30 720 times under load -- a single stale
+    word would move a particle."""
+    sph = torch.as_tensor(SC.panda_spheres(num=5)).to(**F32)
+    a, b = _one_vs_two_launches(lambda: hip_panda_planner(SC.PANDA, 64, 1024, 128, F32, seed=77), 30,
+                                {"obstacle_spheres": sph})
+    # ... and with soft weights (every particle reads dozens of rows written by other waves)
+    soft_c = dict(SC.PANDA, start_q=[0.] * 7, goal_q=[0.02] * 7)
+    s1, _ = _one_vs_two_launches(lambda: hip_panda_planner(soft_c, 64, 1024, 128, F32, seed=78), 6, {"obstacle_spheres": sph},
+                                 soft=True)
+    assert int((s1._weights_buf != 0).sum(1).max()) >= 3
+    # ... and inside optimize(opt_iters=K): two particle-half chains, each one launch per iteration
+    x = hip_panda_planner(SC.PANDA, 64, 1024, 128, F32, seed=79)
+    x._engine.set_option("tail_update", 1)
+    y = hip_panda_planner(SC.PANDA, 64, 1024, 128, F32, seed=79, pipeline_steps=False)
+    for k in (7, 1, 12):
+        x.optimize(opt_iters=k, obstacle_spheres=sph)
+        y.optimize(opt_iters=k, obstacle_spheres=sph)
+        assert torch.equal(x.particle_means, y.particle_means) and torch.equal(x._costs, y._costs)
+        assert torch.equal(x._grad, y._grad) and torch.equal(x._weights_buf, y._weights_buf)
+        sx, sy = x.global_stats(), y.global_stats()
+        assert abs(sx[0] / sy[0] - 1) < 1e-12 and abs(sx[1] / sy[1] - 1) < 1e-12
+    assert x._engine.pipeline_split_steps() == 19 and x._engine.last_step_launches() == 1
+
+
 @pytest.mark.parametrize("nppg,G,S,T,fused", [
     (2, 2, 8, 16, True), (3, 2, 24, 48, True), (5, 1, 16, 128, True), (1, 4, 8, 32, True),
     (2, 2, 12, 32, False),                    # S not a multiple of 8
