@@ -110,6 +110,10 @@ typedef struct sgpmp_joint {
 typedef struct sgpmp_ctx sgpmp_ctx;
 
 int sgpmp_abi_version(void);
+/* Rounds of the Philox4x32 bijection behind the in-kernel noise (csrc/rng.h, build parameter SGPMP_PHILOX_ROUNDS: 10 =
+ * Random123's default, 7 = its documented Crush-resistant minimum): the CPU restatement of the stream
+ * (oracle/native_noise.py) must be run with the same count. */
+int sgpmp_philox_rounds(void);
 const char* sgpmp_last_error(void);
 
 /* ---- context ---------------------------------------------------------------------------------- */

@@ -12,6 +12,10 @@ Pinned by the Random123 known-answer vectors for philox4x32-10 (tests/test_oracl
 """
 import numpy as np
 
+# Round count of the stream being restated: the tests set it to what the library under test reports
+# (sgpmp_philox_rounds(); csrc/rng.h SGPMP_PHILOX_ROUNDS).  10 = Random123's default, 7 = its Crush-resistant minimum.
+DEFAULT_ROUNDS = 10
+
 M0 = np.uint64(0xD2511F53)
 M1 = np.uint64(0xCD9E8D57)
 W0 = 0x9E3779B9
@@ -19,13 +23,13 @@ W1 = 0xBB67AE85
 MASK = np.uint64(0xFFFFFFFF)
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Vectorised Philox4x32-10: counters are uint32 arrays (broadcastable), keys Python ints."""
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=10):
+    """Vectorised Philox4x32-R: counters are uint32 arrays (broadcastable), keys Python ints."""
     c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & MASK for c in (c0, c1, c2, c3))
     c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
     k0 &= 0xFFFFFFFF
     k1 &= 0xFFFFFFFF
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = M0 * c0                                   # < 2^64: exact in uint64
         p1 = M1 * c2
         hi0, lo0 = p0 >> np.uint64(32), p0 & MASK
@@ -34,6 +38,10 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
         k0 = (k0 + W0) & 0xFFFFFFFF
         k1 = (k1 + W1) & 0xFFFFFFFF
     return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    return philox4x32(c0, c1, c2, c3, k0, k1, 10)
 
 
 def box_muller_f32(a, b):
@@ -57,10 +65,12 @@ def box_muller_f64(a, b, c, d):
     return r * np.cos(2.0 * np.pi * u2), r * np.sin(2.0 * np.pi * u2)
 
 
-def native_eps(seed, draw, particles, S, T, n, dtype="float32"):
+def native_eps(seed, draw, particles, S, T, n, dtype="float32", rounds=None):
     """Noise of the HIP sampler for global particle indices `particles` -> [S, len(particles), T*2n]
     (torch.randn(S, P, M) layout: element t*d + k is the position noise of dof k at waypoint t,
     t*d + n + k the velocity noise)."""
+    if rounds is None:
+        rounds = DEFAULT_ROUNDS
     particles = np.asarray(particles, dtype=np.uint64)
     P, d = len(particles), 2 * n
     k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
@@ -71,14 +81,14 @@ def native_eps(seed, draw, particles, S, T, n, dtype="float32"):
     out = np.zeros((S, P, T, d), dtype=np.float64 if dtype == "float64" else np.float32)
     if dtype == "float64":
         t_idx = np.arange(T, dtype=np.uint64).reshape(1, 1, T, 1)
-        x, y, z, w = philox4x32_10(t_idx | (k_idx << np.uint64(20)), s_idx, m_idx,
-                                   c3 ^ np.uint64(0x80000000), k0, k1)
+        x, y, z, w = philox4x32(t_idx | (k_idx << np.uint64(20)), s_idx, m_idx,
+                                c3 ^ np.uint64(0x80000000), k0, k1, rounds)
         z0, z1 = box_muller_f64(x, y, z, w)
         out[..., :n], out[..., n:] = z0, z1
     else:
         nb = (T + 1) // 2
         b_idx = np.arange(nb, dtype=np.uint64).reshape(1, 1, nb, 1)
-        x, y, z, w = philox4x32_10(b_idx | (k_idx << np.uint64(20)), s_idx, m_idx, c3, k0, k1)
+        x, y, z, w = philox4x32(b_idx | (k_idx << np.uint64(20)), s_idx, m_idx, c3, k0, k1, rounds)
         e0, e1 = box_muller_f32(x, y)                  # waypoint 2b:   (pos, vel)
         e2, e3 = box_muller_f32(z, w)                  # waypoint 2b+1: (pos, vel)
         out[:, :, 0::2, :n], out[:, :, 0::2, n:] = e0[:, :, :(T + 1) // 2], e1[:, :, :(T + 1) // 2]

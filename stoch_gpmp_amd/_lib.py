@@ -48,6 +48,7 @@ class Joint(C.Structure):
 _P, _I, _I64, _U64, _D = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
 SIGNATURES = {
     "sgpmp_abi_version": (_I, []),
+    "sgpmp_philox_rounds": (_I, []),
     "sgpmp_last_error": (C.c_char_p, []),
     "sgpmp_create": (_I, [C.POINTER(Dims), C.POINTER(_P)]),
     "sgpmp_destroy": (None, [_P]),

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "chain_code_generated.h"
+#include "rng.h"
 #include "sgpmp_internal.h"
 
 static thread_local std::string g_err;
@@ -111,6 +112,7 @@ static void toggles_from_env(SgpmpToggles& tg) {
 }
 
 extern "C" int sgpmp_abi_version(void) { return SGPMP_ABI_VERSION; }
+extern "C" int sgpmp_philox_rounds(void) { return SGPMP_PHILOX_ROUNDS; }
 extern "C" const char* sgpmp_last_error(void) { return g_err.c_str(); }
 
 static int alloc_prior(sgpmp_ctx* c, PriorDev& p) {

@@ -1,4 +1,4 @@
-// Counter-based standard-normal noise for the sampler (K2): Philox4x32-10 + Box-Muller.
+// Counter-based standard-normal noise for the sampler (K2): Philox4x32-R + Box-Muller, R = SGPMP_PHILOX_ROUNDS.
 //
 // The reference draws eps = randn(S, P, M) from torch's global CPU generator
 // (planner.py:48-49 -> torch multivariate_normal.py:250-253); that stream is sequential and cannot
@@ -12,7 +12,16 @@
 
 struct Philox4 { uint32_t x, y, z, w; };
 
-__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+// Rounds of the Philox4x32 bijection.  Random123 (Salmon et al., SC'11) ships 10 as the default "with a safety
+// margin" and documents 7 as the smallest count that passes BigCrush ("Crush-resistant"); both have known-answer
+// vectors (tests/test_oracle_golden.py pins oracle/native_noise.py to them), and sgpmp_philox_rounds() tells the
+// host which one this library was built with.  The noise source is ~30 % of the fused launch's vector instructions.
+#ifndef SGPMP_PHILOX_ROUNDS
+#define SGPMP_PHILOX_ROUNDS 7
+#endif
+static_assert(SGPMP_PHILOX_ROUNDS >= 7 && SGPMP_PHILOX_ROUNDS <= 10, "Philox4x32: 7 (Crush-resistant minimum) .. 10 rounds");
+
+__device__ __forceinline__ Philox4 philox4x32_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                  uint32_t k0, uint32_t k1) {
     // Rounds 1 and 2 are written with plain xors grouped so that everything WAVE-UNIFORM folds on the scalar
     // unit: the callers key the noise with c2 = particle and c3 = draw, uniform per wave like the key, so in
@@ -39,7 +48,7 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 #pragma unroll
-    for (int r = 2; r < 10; ++r) {
+    for (int r = 2; r < SGPMP_PHILOX_ROUNDS; ++r) {
         // one 32x32->64 multiply (v_mad_u64_u32) per product instead of separate lo / hi multiplies
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -91,7 +100,7 @@ template <> struct NoiseGen<float> {
     __device__ __forceinline__ void get(int t, float& e_pos, float& e_vel) {
         const int blk = t >> 1;
         if (blk != have) {
-            const Philox4 r = philox4x32_10((uint32_t)blk | kk, c1, c2, c3, k0, k1);
+            const Philox4 r = philox4x32_r((uint32_t)blk | kk, c1, c2, c3, k0, k1);
             box_muller_f32(r.x, r.y, z[0], z[1]);
             box_muller_f32(r.z, r.w, z[2], z[3]);
             have = blk;
@@ -101,7 +110,7 @@ template <> struct NoiseGen<float> {
     }
     // both waypoints of an even-aligned pair: e = (pos_t, vel_t, pos_{t+1}, vel_{t+1}); same stream as get()
     __device__ __forceinline__ void get4(int t_even, float (&e)[4]) {
-        const Philox4 r = philox4x32_10((uint32_t)(t_even >> 1) | kk, c1, c2, c3, k0, k1);
+        const Philox4 r = philox4x32_r((uint32_t)(t_even >> 1) | kk, c1, c2, c3, k0, k1);
         box_muller_f32(r.x, r.y, e[0], e[1]);
         box_muller_f32(r.z, r.w, e[2], e[3]);
     }
@@ -115,7 +124,7 @@ template <> struct NoiseGen<double> {
         c1 = s; c2 = mode; c3 = (uint32_t)draw; kk = k << 20;
     }
     __device__ __forceinline__ void get(int t, double& e_pos, double& e_vel) {
-        const Philox4 r = philox4x32_10((uint32_t)t | kk, c1, c2, c3 ^ 0x80000000u, k0, k1);
+        const Philox4 r = philox4x32_r((uint32_t)t | kk, c1, c2, c3 ^ 0x80000000u, k0, k1);
         box_muller_f64(r.x, r.y, r.z, r.w, e_pos, e_vel);
     }
     __device__ __forceinline__ void get4(int t_even, double (&e)[4]) {

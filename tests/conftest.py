@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _noise_restatement_follows_the_library():
+    """oracle/native_noise.py restates the in-kernel Philox stream; the round count is a build parameter of the
+    library (csrc/rng.h SGPMP_PHILOX_ROUNDS), so the checker is told which one the library under test reports."""
+    try:
+        from oracle import native_noise
+        from stoch_gpmp_amd import _lib
+        native_noise.DEFAULT_ROUNDS = int(_lib.load().sgpmp_philox_rounds())
+    except (ImportError, OSError, AttributeError):
+        pass                                      # (library not built: the tests that need it fail on their own)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

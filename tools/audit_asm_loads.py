@@ -96,7 +96,9 @@ def main():
     kernels = groups = bad = 0
     for m in re.finditer(r"^(_Z\w*(?:%s)\w*):[^\n]*\n(.*?)^\.Lfunc_end" % KERNELS, text, re.S | re.M):
         g, b = audit(m.group(1), m.group(2).split("\n"))
-        assert g, m.group(1)
+        # (fused_planar_kernel has no hand-placed load with a VGPR destination any more: its grid gathers go through
+        # LDS-DMA, precisely because of what this audit once found there)
+        assert g or "fused_planar" in m.group(1), m.group(1)
         kernels, groups, bad = kernels + 1, groups + g, bad + b
     print(f"{kernels} kernels audited, {groups} hand-placed loads, {bad} offending instructions")
     return 1 if bad or kernels == 0 else 0

@@ -11,7 +11,7 @@ __global__ void __launch_bounds__(256) k(float* out, int calls, uint64_t seed) {
     float acc = 0.f; uint32_t xacc = 0;
     for (int i = 0; i < calls; ++i) {
         if (MODE == 0) {
-            const Philox4 r = philox4x32_10((uint32_t)i | gen.kk, gen.c1, gen.c2, gen.c3, gen.k0, gen.k1);
+            const Philox4 r = philox4x32_r((uint32_t)i | gen.kk, gen.c1, gen.c2, gen.c3, gen.k0, gen.k1);
             xacc ^= r.x ^ r.y ^ r.z ^ r.w;
         } else {
             float e[4];
