@@ -278,6 +278,21 @@ int sgpmp_allreduce_stats(sgpmp_ctx* ctx, double* stats, void* stream);
 /* Make `stream` wait (stream-side, not host-side) for the pending all-reduce of `stats`
  * (NULL: of every statistics buffer) -- call before reading or overwriting it. */
 int sgpmp_stats_wait(sgpmp_ctx* ctx, double* stats, void* stream);
+/* Per-goal statistics of the particle means -- the "weighted-mean / covariance statistics" of the trajectory
+ * distribution's modes (a mode = the particles of one goal, p = g * nppg + k, planner.py:215); what a covariance
+ * adaptation through MultiMPPrior.set_Sigma_invs (mp_priors_multi.py:125-128) or a mode summary consumes.
+ * out DEVICE double[G][T*d + 1][2]:  [g][m] = (sum, sum of squares) of mu_p[m] over THIS context's particles of goal g,
+ * [g][T*d] = (their number, 0).  sgpmp_mode_stats zeroes `out` and accumulates on `stream`.
+ * sgpmp_allreduce_f64: sum any buffer of doubles over all ranks, in place, on the context's side stream (like
+ * sgpmp_allreduce_stats; honour sgpmp_stats_wait(buf) before reading).
+ * sgpmp_set_step_mode_stats(buf): from now on EVERY sgpmp_step produces them by itself, once per iteration: its update
+ * kernel leaves a snapshot of the new means, the side stream reduces it per goal into `buf` and all-reduces the sums
+ * over the ranks -- nothing is added to the steps' own stream but one event record; sgpmp_mode_stats_wait makes
+ * `stream` wait for the newest one.  NULL switches it off.  (Steps then run as one chain and with update_kernel.) */
+int sgpmp_mode_stats(sgpmp_ctx* ctx, const void* means, double* out, void* stream);
+int sgpmp_allreduce_f64(sgpmp_ctx* ctx, double* buf, int64_t count, void* stream);
+int sgpmp_set_step_mode_stats(sgpmp_ctx* ctx, double* buf);
+int sgpmp_mode_stats_wait(sgpmp_ctx* ctx, void* stream);
 /* All ranks' particle means: local [P_local,T,d] -> all [P_global,T,d] on every rank (ncclAllGather on
  * `stream`; equal shards only). */
 int sgpmp_allgather_means(sgpmp_ctx* ctx, const void* local_means, void* all_means, void* stream);

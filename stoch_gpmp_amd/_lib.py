@@ -60,6 +60,10 @@ SIGNATURES = {
     "sgpmp_allreduce_stats": (_I, [_P, _P, _P]),
     "sgpmp_stats_wait": (_I, [_P, _P, _P]),
     "sgpmp_allgather_means": (_I, [_P, _P, _P, _P]),
+    "sgpmp_mode_stats": (_I, [_P, _P, _P, _P]),
+    "sgpmp_allreduce_f64": (_I, [_P, _P, _I64, _P]),
+    "sgpmp_set_step_mode_stats": (_I, [_P, _P]),
+    "sgpmp_mode_stats_wait": (_I, [_P, _P]),
     "sgpmp_last_cost_kernel": (C.c_char_p, [_P]),
     "sgpmp_pipeline_begin": (_I, [_P, _P]),
     "sgpmp_pipeline_end": (_I, [_P, _P]),

@@ -83,6 +83,15 @@ struct sgpmp_ctx {
     unsigned* d_arrive = nullptr;    // [P]
     unsigned* d_done = nullptr;      // [2]
     double* d_tail_acc = nullptr;    // [2][SGPMP_STAT_SHARDS][4]
+    // per-goal mean statistics once per iteration (sgpmp_set_step_mode_stats): the update kernel leaves a snapshot of
+    // the new means, a side stream reduces it per goal and all-reduces the sums -- nothing on the steps' own stream
+    double* ms_buf = nullptr;        // caller's [G][M+1][2] buffer, or null: off
+    void* ms_snap[2] = {nullptr, nullptr};   // snapshots of the new means [P][M] (ring of two)
+    hipEvent_t ms_read[2] = {nullptr, nullptr};   // side stream: snapshot i has been reduced
+    hipEvent_t ms_ready = nullptr;   // steps' stream: snapshot written
+    hipStream_t ms_side = nullptr;   // the side stream when no communicator is attached
+    bool ms_used[2] = {false, false};
+    unsigned long long ms_step = 0;
     int last_step_launches = 0;      // kernels the last sgpmp_step enqueued for its particle range (1: everything in one launch)
     hipStream_t k1_side = nullptr;   // sgpmp_set_priors: the second factorisation's stream
     hipEvent_t k1_fork = nullptr;
@@ -233,6 +242,65 @@ extern "C" int sgpmp_comm_info(sgpmp_ctx* c, int* world, int* rank, int* rccl_ve
     return SGPMP_OK;
 }
 
+// ---- per-goal statistics of the particle means (the all-reduce's north_star content) -----------------------------
+static size_t mode_stats_count(const sgpmp_ctx* c) { return (size_t)c->dims.num_goals * (c->M + 1) * 2; }
+
+extern "C" int sgpmp_mode_stats(sgpmp_ctx* c, const void* means, double* out, void* stream) {
+    if (!c || !out || (c->dims.num_particles > 0 && !means)) return fail(SGPMP_EINVAL, "sgpmp_mode_stats: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(out, 0, mode_stats_count(c) * sizeof(double), st));
+    HIPCHK(launch_mode_stats(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, c->dims.num_particles, c->dims.particle_offset,
+                             c->dims.num_particles_per_goal, c->dims.num_goals, means, out, st));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_allreduce_f64(sgpmp_ctx* c, double* buf, int64_t count, void* stream) {
+    if (!c || !buf || count < 1) return fail(SGPMP_EINVAL, "sgpmp_allreduce_f64: bad argument");
+    if (!c->comm) return fail(SGPMP_ESTATE, "sgpmp_allreduce_f64: no communicator (sgpmp_comm_init)");
+    COMMCHK(comm_allreduce_f64(c->comm, buf, (size_t)count, (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_set_step_mode_stats(sgpmp_ctx* c, double* buf) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_set_step_mode_stats: null context");
+    if (buf && !c->ms_ready) {
+        const size_t bytes = (size_t)(c->dims.num_particles > 0 ? c->dims.num_particles : 1) * c->M * c->esz;
+        HIPCHK(hipEventCreateWithFlags(&c->ms_ready, hipEventDisableTiming));
+        HIPCHK(hipStreamCreateWithFlags(&c->ms_side, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipMalloc(&c->ms_snap[i], bytes));
+            HIPCHK(hipEventCreateWithFlags(&c->ms_read[i], hipEventDisableTiming));
+        }
+    }
+    c->ms_buf = buf;
+    return SGPMP_OK;
+}
+
+// After the update kernel of a step left snapshot `slot` of the new means (steps' stream `st`): reduce it per goal on
+// the side stream into the caller's buffer and sum over the ranks.  The side stream is the communicator's when there
+// is one (the collectives of a context stay on one stream, in one order on every rank).
+static int step_mode_stats(sgpmp_ctx* c, int slot, hipStream_t st) {
+    hipStream_t side = c->comm ? comm_side_stream(c->comm) : c->ms_side;
+    HIPCHK(hipEventRecord(c->ms_ready, st));
+    HIPCHK(hipStreamWaitEvent(side, c->ms_ready, 0));
+    HIPCHK(hipMemsetAsync(c->ms_buf, 0, mode_stats_count(c) * sizeof(double), side));
+    HIPCHK(launch_mode_stats(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, c->dims.num_particles, c->dims.particle_offset,
+                             c->dims.num_particles_per_goal, c->dims.num_goals, c->ms_snap[slot], c->ms_buf, side));
+    HIPCHK(hipEventRecord(c->ms_read[slot], side));
+    c->ms_used[slot] = true;
+    if (c->comm) COMMCHK(comm_allreduce_f64(c->comm, c->ms_buf, mode_stats_count(c), side));
+    return SGPMP_OK;
+}
+
+extern "C" int sgpmp_mode_stats_wait(sgpmp_ctx* c, void* stream) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_mode_stats_wait: null context");
+    hipStream_t st = (hipStream_t)stream;
+    if (c->comm && c->ms_buf) COMMCHK(comm_stats_wait(c->comm, c->ms_buf, st));
+    for (int i = 0; i < 2; ++i)
+        if (c->ms_used[i]) HIPCHK(hipStreamWaitEvent(st, c->ms_read[i], 0));
+    return SGPMP_OK;
+}
+
 extern "C" int sgpmp_allreduce_stats(sgpmp_ctx* c, double* stats, void* stream) {
     if (!c || !stats) return fail(SGPMP_EINVAL, "sgpmp_allreduce_stats: null argument");
     if (!c->comm) return fail(SGPMP_ESTATE, "sgpmp_allreduce_stats: no communicator (sgpmp_comm_init)");
@@ -263,6 +331,9 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     free_prior(c->prior[1]);
     hipFree(c->d_qc); hipFree(c->d_prog); hipFree(c->d_chain); hipFree(c->d_isw);
     hipFree(c->d_costs64); hipFree(c->d_arrive); hipFree(c->d_done); hipFree(c->d_tail_acc);
+    if (c->ms_side) { hipStreamSynchronize(c->ms_side); hipStreamDestroy(c->ms_side); }
+    for (int i = 0; i < 2; ++i) { hipFree(c->ms_snap[i]); if (c->ms_read[i]) hipEventDestroy(c->ms_read[i]); }
+    if (c->ms_ready) hipEventDestroy(c->ms_ready);
     for (int i = 0; i < 4; ++i) { hipFree(c->d_fval[i]); hipFree(c->d_fgrad[i]); }
     hipFree(c->d_gscratch); hipFree(c->d_diag); hipFree(c->d_gstatus);
     for (void* p : c->owned) hipFree(p);
@@ -867,6 +938,13 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
             HIPCHK(hipEventRecord(done, st0));
             COMMCHK(comm_step_end(c->comm, stats, false));
         }
+        if (c->comm && c->ms_buf) {                              // (and the per-goal mean statistics: all zeros from here)
+            hipStream_t side = comm_side_stream(c->comm);
+            HIPCHK(hipEventRecord(c->ms_ready, (hipStream_t)stream));
+            HIPCHK(hipStreamWaitEvent(side, c->ms_ready, 0));
+            HIPCHK(hipMemsetAsync(c->ms_buf, 0, mode_stats_count(c) * sizeof(double), side));
+            COMMCHK(comm_allreduce_f64(c->comm, c->ms_buf, mode_stats_count(c), side));
+        }
         return SGPMP_OK;
     }
     if (!means || !samples) return fail(SGPMP_EINVAL, "sgpmp_step: null argument");
@@ -886,7 +964,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     if (c->pipe.active) {
         // both halves big enough to fill the chip on their own (256 workgroups of 4 items of 8 rows) and fused
         const int P0 = pipe_first_half(c);
-        const bool split = !eps && !c->profiling && !c->tg.no_step_pipeline &&
+        const bool split = !eps && !c->profiling && !c->tg.no_step_pipeline && !c->ms_buf &&
                            (long long)(P0 < P - P0 ? P0 : P - P0) * S >= 256 * 4 * 8 &&
                            fused_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P0, D.particle_offset,
                                                S, n_spheres, c->tg) &&
@@ -932,7 +1010,8 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         FusedTailHost th = {c->d_arrive, c->d_done, c->d_tail_acc, acc_stats, weights, grad, means_prev, temperature, step_size};
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, means, P,
                                  D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, acc_stats, costs,
-                                 c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, &th, k4_done, &tail_ran));
+                                 c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, c->ms_buf ? nullptr : &th, k4_done,
+                                 &tail_ran));
         if (fused) c->last_step_launches += 1;
         for (int i = 0; fused && i < c->h_prog.n_terms; ++i)
             if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) {
@@ -955,10 +1034,20 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     // means do not fit its LDS beside the weights: launch_update decides)
     bool isw_written = tail_ran;
     if (!tail_ran) {
+        // per-goal mean statistics (sgpmp_set_step_mode_stats): the update kernel also leaves a snapshot of the new
+        // means for the side stream; a snapshot is reused two steps later -- by then its reduction has long finished
+        // (host-side query; the stream wait is the never-taken fallback)
+        const int slot = (int)(c->ms_step & 1);
+        if (c->ms_buf && c->ms_used[slot] && hipEventQuery(c->ms_read[slot]) != hipSuccess)
+            HIPCHK(hipStreamWaitEvent(st, c->ms_read[slot], 0));
         HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
                              temperature, step_size, weights, grad, means_prev, acc_stats, st, k4_done, &pr, c->d_isw,
-                             &isw_written));
+                             &isw_written, c->ms_buf ? c->ms_snap[slot] : nullptr));
         c->last_step_launches += 1;
+        if (c->ms_buf) {
+            if ((rc = step_mode_stats(c, slot, st)) != SGPMP_OK) return rc;
+            c->ms_step += 1;
+        }
     }
     c->isw_ready = isw_written; c->isw_means = means; c->isw_temperature = temperature;
     if (se) { HIPCHK(hipEventRecord(se->ev[4], st)); se->has[3] = !tail_ran; }

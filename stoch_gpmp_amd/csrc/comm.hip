@@ -186,6 +186,29 @@ const char* comm_allreduce_stats(SgpmpComm* c, double* stats, hipStream_t stream
     return nullptr;
 }
 
+// The same for any buffer of doubles (the per-goal mean statistics): in place, on the side stream.
+const char* comm_allreduce_f64(SgpmpComm* c, double* buf, size_t count, hipStream_t stream) {
+    hipEvent_t* done = reduced_event(c, buf, true);
+    if (!done) return "comm_allreduce_f64: cannot create an event";
+    if (hipEventRecord(c->produced, stream) != hipSuccess) return "hipEventRecord failed";
+    if (hipStreamWaitEvent(c->side, c->produced, 0) != hipSuccess) return "hipStreamWaitEvent failed";
+    const ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, c->side);
+    if (r != ncclSuccess) return g_rccl.GetErrorString(r);
+    if (hipEventRecord(*done, c->side) != hipSuccess) return "hipEventRecord failed";
+    return nullptr;
+}
+
+hipStream_t comm_side_stream(SgpmpComm* c) { return c->side; }
+
+// `buf` has just been all-reduced on the side stream by a caller that enqueued the collective itself
+// (sgpmp_step's per-goal mean statistics): remember the event sgpmp_stats_wait(buf) must honour.
+const char* comm_mark_reduced(SgpmpComm* c, double* buf) {
+    hipEvent_t* done = reduced_event(c, buf, true);
+    if (!done) return "comm_mark_reduced: cannot create an event";
+    if (hipEventRecord(*done, c->side) != hipSuccess) return "hipEventRecord failed";
+    return nullptr;
+}
+
 // ---- the per-step path of sgpmp_step ------------------------------------------------------------------
 // Begin a step: the ring slot K5 will zero and K4 will accumulate into, and the event to attach to K4's
 // dispatch.  If the slot's previous all-reduce (SGPMP_COMM_RING steps ago) were still running, `stream`

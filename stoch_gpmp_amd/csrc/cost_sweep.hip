@@ -599,6 +599,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         *launched = true;
         return hipGetLastError();
     }
+    if (!fs.tail.arrive) done = nullptr;          // (the statistics are complete after update_kernel, which then carries the event)
     const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
     // (`done`, multi-GPU statistics: signalled by this kernel's own dispatch packet -- hipExtLaunchKernelGGL stop
     // event -- instead of a separate barrier packet behind it)

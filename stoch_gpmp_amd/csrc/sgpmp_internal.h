@@ -123,6 +123,9 @@ int comm_rank(const SgpmpComm* c);
 int comm_world(const SgpmpComm* c);
 const char* comm_info(const SgpmpComm* c, int* world, int* rank, int* version);   // asked of RCCL itself
 const char* comm_allreduce_stats(SgpmpComm* c, double* stats, hipStream_t stream);
+const char* comm_allreduce_f64(SgpmpComm* c, double* buf, size_t count, hipStream_t stream);
+hipStream_t comm_side_stream(SgpmpComm* c);
+const char* comm_mark_reduced(SgpmpComm* c, double* buf);
 const char* comm_step_begin(SgpmpComm* c, hipStream_t stream, double** slot, hipEvent_t* k4_done);
 const char* comm_step_begin2(SgpmpComm* c, hipStream_t s0, hipStream_t s1, double** slot0, double** slot1,
                              hipEvent_t* done0, hipEvent_t* done1);
@@ -183,9 +186,11 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
                          hipStream_t stream, hipEvent_t done = nullptr, const PriorDev* isw_prior = nullptr,
-                         void* isw_next = nullptr, bool* isw_written = nullptr);
+                         void* isw_next = nullptr, bool* isw_written = nullptr, void* means_copy = nullptr);
 
 hipError_t launch_stats_add(double* dst, const double* src, hipStream_t stream);
+hipError_t launch_mode_stats(int dtype, int n, int T, int P, long long p_offset, int nppg, int G, const void* means,
+                             double* out, hipStream_t stream);
 hipError_t launch_ee_goal(int dtype, int n, int T, const CostTerm& term, const ChainDev* d_chain,
                           const void* trajs, long long batch, void* costs, double* costs64,
                           hipStream_t stream);

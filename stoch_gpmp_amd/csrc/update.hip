@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256)
 update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __restrict__ samples,
               real* __restrict__ means, double temperature, double step_size,
               real* __restrict__ weights, real* __restrict__ grad, real* __restrict__ means_prev,
-              double* __restrict__ stats, IswNext<real> nx) {
+              double* __restrict__ stats, IswNext<real> nx, real* __restrict__ means_copy) {
     typedef real vec __attribute__((ext_vector_type(VW)));
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double* w = reinterpret_cast<double*>(lds_raw);                  // [S] weights
@@ -163,6 +163,7 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
         if (grad) *reinterpret_cast<vec*>(grad + (size_t)p * M + m) = g;
         if (means_prev) *reinterpret_cast<vec*>(means_prev + (size_t)p * M + m) = mu_m;
         *reinterpret_cast<vec*>(mu + m) = mn;
+        if (means_copy) *reinterpret_cast<vec*>(means_copy + (size_t)p * M + m) = mn;   // (snapshot for the side stream's statistics)
         if (nx.out) *reinterpret_cast<vec*>(mu_lds + m) = mn;
     }
     // The NEXT iteration's importance-sampling weights, from the means just written (K5's arithmetic, same
@@ -182,7 +183,7 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
                          hipStream_t stream, hipEvent_t done, const PriorDev* isw_prior, void* isw_next,
-                         bool* isw_written) {
+                         bool* isw_written, void* means_copy) {
     const int M = T * 2 * n;
     size_t lds = (size_t)S * (sizeof(double) + sizeof(int));
     if (isw_prior) {
@@ -204,7 +205,8 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                           step_size, (REAL*)weights, (REAL*)grad, (REAL*)means_prev, stats,          \
                           IswNext<REAL>{isw_prior ? (REAL*)isw_next : nullptr, isw_prior ? isw_prior->Qinv : nullptr, \
                                         isw_prior ? isw_prior->ks : 0., isw_prior ? isw_prior->kg : -1., \
-                                        isw_prior ? isw_prior->dt : 0., n, isw_prior ? isw_prior->isotropic : 1})
+                                        isw_prior ? isw_prior->dt : 0., n, isw_prior ? isw_prior->isotropic : 1}, \
+                          (REAL*)means_copy)
     if (dtype == SGPMP_F64) {
         if (M % 4 == 0) UPD(double, double, 4); else UPD(double, double, 2);
     } else if (costs_dtype == SGPMP_F64) {
@@ -213,6 +215,58 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
         if (M % 4 == 0) UPD(float, float, 4); else UPD(float, float, 2);
     }
 #undef UPD
+    return hipGetLastError();
+}
+
+// Per-goal statistics of the particle means -- what the multi-GPU all-reduce carries besides the cost sums (SURVEY.md
+// 8e: "per-goal sum_p mu_p and sum_p mu_p mu_p^T-diagonal"; north_star: "weighted-mean/covariance statistics"): the
+// modes of the trajectory distribution are the goals (p = g * nppg + k, planner.py:215), and the first two moments of
+// a mode's particles are what a covariance adaptation (MultiMPPrior.set_Sigma_invs, mp_priors_multi.py:125-128) or a
+// mode summary would consume.  out [G][M + 1][2] doubles is ACCUMULATED into (zero it first): [g][m] = (sum of
+// mu_p[m], sum of mu_p[m]^2) over this shard's particles of goal g, [g][M] = (their number, 0).
+// grid = (ceil(M / 256), particle slices); a slice adds its partial sums with one atomic per element and goal run.
+template <typename real>
+__global__ void __launch_bounds__(256)
+mode_stats_kernel(int M, int P, long long p_offset, int nppg, int G, const real* __restrict__ means,
+                  double* __restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = (P + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = min(P, p0 + per);
+    if (p0 >= p1) return;
+    int g = (int)min((long long)(G - 1), (p_offset + p0) / nppg);
+    double s1 = 0., s2 = 0.;
+    int cnt = 0;
+    auto flush = [&]() {
+        if (m < M) {
+            atomicAdd(&out[((size_t)g * (M + 1) + m) * 2], s1);
+            atomicAdd(&out[((size_t)g * (M + 1) + m) * 2 + 1], s2);
+        } else if (m == M) {
+            atomicAdd(&out[((size_t)g * (M + 1) + M) * 2], (double)cnt);
+        }
+        s1 = s2 = 0.; cnt = 0;
+    };
+    for (int p = p0; p < p1; ++p) {
+        const int gp = (int)min((long long)(G - 1), (p_offset + p) / nppg);
+        if (gp != g) { flush(); g = gp; }
+        if (m < M) {
+            const double v = (double)means[(size_t)p * M + m];
+            s1 += v; s2 += v * v;
+        }
+        ++cnt;
+    }
+    flush();
+}
+
+hipError_t launch_mode_stats(int dtype, int n, int T, int P, long long p_offset, int nppg, int G, const void* means,
+                             double* out, hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    const int M = T * 2 * n;
+    const int slices = P >= 32 ? 32 : P;
+    dim3 grid((unsigned)((M + 1 + 255) / 256), (unsigned)slices), block(256);
+    if (dtype == SGPMP_F64)
+        hipLaunchKernelGGL((mode_stats_kernel<double>), grid, block, 0, stream, M, P, p_offset, nppg, G, (const double*)means, out);
+    else
+        hipLaunchKernelGGL((mode_stats_kernel<float>), grid, block, 0, stream, M, P, p_offset, nppg, G, (const float*)means, out);
     return hipGetLastError();
 }
 

@@ -24,6 +24,24 @@ def allreduce_stats_async(stats, group=None):
     return dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 
+def allreduce_mode_sums(buf, group=None):
+    """Sum the per-goal mean statistics [G, M + 1, 2] (local sums, sums of squares, counts: include/sgpmp.h
+    sgpmp_mode_stats) over all ranks, in place -- the torch.distributed twin of sgpmp_allreduce_f64."""
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf
+
+
+def mode_moments(buf, T, d):
+    """[G, T*d + 1, 2] sums -> (mean [G,T,d], variance [G,T,d], particle count [G]) of the particle means of every
+    goal: the first two moments of each mode of the trajectory distribution."""
+    M = T * d
+    cnt = buf[:, M, 0].clamp(min=1.0)
+    mean = buf[:, :M, 0] / cnt[:, None]
+    var = (buf[:, :M, 1] / cnt[:, None] - mean * mean).clamp(min=0.0)
+    G = buf.shape[0]
+    return mean.reshape(G, T, d), var.reshape(G, T, d), buf[:, M, 0].clone()
+
+
 def allgather_means(local_means, num_particles, world_size, group=None):
     """[P_local,T,d] on every rank -> [P,T,d] on every rank (ragged shards allowed)."""
     sizes = [shard_range(num_particles, r, world_size) for r in range(world_size)]

@@ -94,6 +94,28 @@ class Engine:
         with torch.cuda.device(self.device):
             L.check(self.lib.sgpmp_stats_wait(self._ctx, L.ptr(stats), L.stream_ptr()))
 
+    def mode_stats(self, means, out=None):
+        """Local per-goal sums of the particle means: out [G, T*d + 1, 2] fp64 (include/sgpmp.h: sgpmp_mode_stats)."""
+        self._chk(means, "means")
+        if out is None:
+            out = torch.empty(self.dims.num_goals, self.T * self.d + 1, 2, device=self.device, dtype=torch.float64)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_mode_stats(self._ctx, L.ptr(means), L.ptr(out), L.stream_ptr()))
+        return out
+
+    def allreduce_f64(self, buf):
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_allreduce_f64(self._ctx, L.ptr(buf), buf.numel(), L.stream_ptr()))
+
+    def set_step_mode_stats(self, buf):
+        """Every step from now on leaves the per-goal mean statistics, summed over all ranks, in `buf` (None: off)."""
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_set_step_mode_stats(self._ctx, L.ptr(buf)))
+
+    def mode_stats_wait(self):
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_mode_stats_wait(self._ctx, L.stream_ptr()))
+
     def allgather_means(self, local_means, world_size):
         self._chk(local_means, "means")
         out = torch.empty((local_means.shape[0] * world_size,) + tuple(local_means.shape[1:]),

@@ -22,6 +22,10 @@ Additions over the reference API (all optional keyword arguments):
                              collective='torch' keeps the torch.distributed all-reduce instead
                              (what the gloo CPU tests exercise).
   step()                     one loop body, public (the reference only has it inline).
+  mode_stats=False           True: every step also leaves the per-goal statistics of the particle means (sum and sum
+                             of squares per goal, all-reduced over the ranks on the side stream -- the "weighted-mean /
+                             covariance statistics" of the modes); global_mode_stats() reads them.  False: the same
+                             numbers are computed (and all-reduced) when global_mode_stats() is called.
   pipeline_steps=True        optimize(opt_iters >= 2) lets the context run the iterations of the call as two
                              particle-half chains on streams of its own (one half's update kernel under the
                              other half's sampler + sweep launch); same results, bit for bit.
@@ -34,7 +38,7 @@ import torch
 from . import _lib as L
 from .costs.factors.gp_factor import GPFactor
 from .costs.factors.unary_factor import UnaryFactor
-from .dist import allgather_means, allreduce_stats_async, shard_range
+from .dist import allgather_means, allreduce_mode_sums, allreduce_stats_async, mode_moments, shard_range
 from .engine import Engine
 
 
@@ -141,6 +145,8 @@ class StochGPMP:
         self._comm_attached = False
         # optimize(opt_iters >= 2) runs its iterations as two particle-half chains (sgpmp_pipeline_begin)
         self.pipeline_steps = bool(kwargs.get('pipeline_steps', True))
+        self.mode_stats_every_step = bool(kwargs.get('mode_stats', False))
+        self._mode_buf = None
 
         self.reset(start_state, multi_goal_states, initial_particle_means=initial_particle_means)
 
@@ -209,6 +215,9 @@ class StochGPMP:
         if fresh:
             self._engine = Engine(n, T, Pl, S, G, nppg, self.p0, P, tensor_args=ta)
             self._attach_comm()
+            if self.mode_stats_every_step:
+                self._mode_buf = torch.zeros(G, M + 1, 2, device=ta['device'], dtype=torch.float64)
+                self._engine.set_step_mode_stats(self._mode_buf)
         eng = self._engine
         goal_init = self.sigma_goal_init if self.goal_directed else None
         goal_sample = self.sigma_goal_sample if self.goal_directed else None
@@ -378,6 +387,28 @@ class StochGPMP:
         cnt = max(float(s[2]), 1.0)
         return float(s[0]) / cnt, float(s[1]) / cnt
 
+    def global_mode_stats(self):
+        """(mean [G,T,d], variance [G,T,d], particles [G]) of the particle means of every goal over ALL ranks: the first
+        two moments of each mode of the trajectory distribution (a mode = the particles of one goal, planner.py:215).
+        The reference keeps its particles on one device and has no counterpart; the sums behind these numbers are what
+        the multi-GPU all-reduce carries (north_star; include/sgpmp.h sgpmp_mode_stats) and what a covariance
+        adaptation through MultiMPPrior.set_Sigma_invs (mp_priors_multi.py:125-128) would consume.  With
+        mode_stats=True they are produced by every step on the side stream; else here, on demand."""
+        eng = self._engine
+        torch_dist = (self.world_size > 1 or self._force_reduce) and not self._comm_attached \
+            and self._collective == 'torch' and torch.distributed.is_initialized()
+        if self.mode_stats_every_step and self._native_cost:     # (a foreign cost object steps through sgpmp_update)
+            eng.mode_stats_wait()
+            buf = self._mode_buf.clone() if torch_dist else self._mode_buf
+        else:
+            buf = eng.mode_stats(self.particle_means)
+            if self._comm_attached:
+                eng.allreduce_f64(buf)
+                eng.stats_wait(buf)
+        if torch_dist:
+            allreduce_mode_sums(buf, self.process_group)
+        return mode_moments(buf, self.traj_len, self.d_state_opt)
+
     # ------------------------------------------------------------------------------- the loop
     def step(self, **observation):
         """One body of the loop at planner.py:289-299 on this rank's particle shard."""
@@ -498,7 +529,8 @@ class StochGPMP:
         torch_reduce = (self.world_size > 1 or self._force_reduce) and not self._comm_attached \
             and self._collective == 'torch' and torch.distributed.is_initialized()   # (reads the statistics per step)
         piped = (opt_iters >= 2 and not debug and self._native_cost and self.noise == 'philox'
-                 and self.num_particles_local > 0 and self.pipeline_steps and not torch_reduce)
+                 and self.num_particles_local > 0 and self.pipeline_steps and not torch_reduce
+                 and not self.mode_stats_every_step)
         if piped:
             self._spheres(observation)                   # (a first use copies on THIS stream: before the chains fork)
             self._engine.pipeline_begin()

@@ -34,7 +34,24 @@ def _worker(rank, world, port, P, q):
         work.wait()
         expect = torch.tensor([float(costs.sum()), float(costs.min(1)[0].sum()), float(P), 0.0],
                               dtype=torch.float64)
-        q.put((rank, ok_gather, torch.equal(stats, expect)))
+        # per-goal mean statistics (the all-reduce's second payload): local sums by goal -> summed over ranks
+        from stoch_gpmp_amd.dist import allreduce_mode_sums, mode_moments
+        G, nppg = 2, P // 2
+        M = T * d
+        means = torch.sin(torch.arange(P * M, dtype=torch.float64)).reshape(P, T, d)
+        buf = torch.zeros(G, M + 1, 2, dtype=torch.float64)
+        for p in range(p0, p1):
+            g = min(p // nppg, G - 1)
+            buf[g, :M, 0] += means[p].reshape(-1)
+            buf[g, :M, 1] += means[p].reshape(-1) ** 2
+            buf[g, M, 0] += 1
+        allreduce_mode_sums(buf)
+        mean, var, cnt = mode_moments(buf, T, d)
+        by_goal = [means[[p for p in range(P) if min(p // nppg, G - 1) == g]] for g in range(G)]
+        ok_modes = all(torch.allclose(mean[g], by_goal[g].mean(0), atol=1e-13) and
+                       torch.allclose(var[g], by_goal[g].var(0, unbiased=False), atol=1e-13) and
+                       float(cnt[g]) == float(len(by_goal[g])) for g in range(G))
+        q.put((rank, ok_gather, torch.equal(stats, expect) and ok_modes))
     finally:
         dist.destroy_process_group()
 

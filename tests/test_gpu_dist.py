@@ -91,6 +91,66 @@ def test_empty_shard_still_joins_the_statistics_allreduce(one_rank_group):
     eng.close()
 
 
+def _direct_mode_moments(means, G):
+    m = means.double().reshape(G, -1, means.shape[-2], means.shape[-1])
+    return m.mean(1), m.var(1, unbiased=False)
+
+
+def test_mode_statistics_of_eight_shards_sum_to_the_unsharded_run():
+    """The all-reduce's north_star content: per-goal sums and sums of squares of the particle means
+    (sgpmp_mode_stats).  Two goals x 64 particles: global_mode_stats() of the unsharded planner equals torch's moments
+    of its means; the eight `rank = r, world_size = 8` shards' local sums add up to the unsharded sums (what
+    ncclAllReduce computes) to rounding -- shard boundaries fall inside a goal and on a goal boundary."""
+    T, nppg, S, n = 32, 64, 16, 7
+    goals = [SC.PANDA["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n]
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
+    full = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=12, goals=goals)
+    for _ in range(3):
+        full.optimize(obstacle_spheres=sph)
+    mean, var, cnt = full.global_mode_stats()
+    dm, dv = _direct_mode_moments(full.particle_means, 2)
+    assert cnt.tolist() == [64., 64.]
+    assert float((mean - dm).abs().max()) < 1e-12 * float(dm.abs().max())
+    assert float((var - dv).abs().max()) < 1e-9 * float(dv.abs().max()) + 1e-18
+    total = torch.zeros(2, T * 14 + 1, 2, device=DEV, dtype=torch.float64)
+    for r in range(8):
+        sh = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=12, goals=goals, rank=r, world_size=8)
+        sh.particle_means.copy_(full.particle_means[sh.p0:sh.p1])
+        total += sh._engine.mode_stats(sh.particle_means)
+    ref = full._engine.mode_stats(full.particle_means)
+    assert float(((total - ref).abs() / ref.abs().clamp(min=1e-30)).max()) < 1e-12
+    assert total[:, -1, 0].tolist() == [64., 64.]
+
+
+def test_mode_statistics_every_step_through_the_rccl_group(one_rank_group):
+    """mode_stats=True: every sgpmp_step leaves the per-goal mean statistics -- update kernel snapshot, per-goal
+    reduction and ncclAllReduce on the side stream -- and they equal the on-demand ones after every call, single
+    iterations and several per call (more calls than snapshot slots)."""
+    T, nppg, S, n = 32, 48, 32, 7
+    goals = [SC.PANDA["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n]
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
+    a = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=14, goals=goals, force_stats_allreduce=True, mode_stats=True)
+    b = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=14, goals=goals, force_stats_allreduce=True)
+    c = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=14, goals=goals, mode_stats=True)          # no communicator
+    assert a._comm_attached and b._comm_attached and not c._comm_attached
+    for k in (1, 1, 4, 1, 3):
+        for pl in (a, b, c):
+            pl.optimize(opt_iters=k, obstacle_spheres=sph)
+        assert torch.equal(a.particle_means, b.particle_means) and torch.equal(a.particle_means, c.particle_means)
+        ma, va, ca = a.global_mode_stats()
+        mb, vb, cb = b.global_mode_stats()
+        mc, vc, cc = c.global_mode_stats()
+        dm, dv = _direct_mode_moments(a.particle_means, 2)
+        for m_, v_, c_ in ((ma, va, ca), (mb, vb, cb), (mc, vc, cc)):
+            assert c_.tolist() == [48., 48.]
+            assert float((m_ - dm).abs().max()) < 1e-12 * float(dm.abs().max())
+            assert float((v_ - dv).abs().max()) < 1e-9 * float(dv.abs().max()) + 1e-18
+        assert a.global_stats() == b.global_stats()          # the cost statistics keep working beside them
+    a.reset()
+    a.optimize(obstacle_spheres=sph)
+    assert a.global_mode_stats()[2].tolist() == [48., 48.]
+
+
 def test_two_chain_steps_with_the_rccl_statistics_allreduce(one_rank_group):
     """optimize(opt_iters=K) with a communicator attached: the iterations run as two particle-half chains, each
     accumulating into its own block of the statistics ring slot; the all-reduce waits for both update kernels
