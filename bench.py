@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0       # same guide: 6.29 TB/s measured float4 copy (79 % of spec)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 GOALS4_PLANAR = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
 
 
@@ -122,6 +122,59 @@ def build_planner(torch, workload, P_local, S, T, dtype, dev, rank=0, world=1, f
     return pl, obs, name
 
 
+def box_copy_bandwidth():
+    """This box's own streaming figures (tools/membw.hip: 470 MB tensors, float4 per lane): GB/s of a device-to-device
+    copy (read + write) -- the denominator SURVEY.md 8d asks for beside the 8 TB/s spec.  None if the binary is absent."""
+    exe = os.path.join(ROOT, "tools", "membw")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=60).stdout
+        best = {}
+        for ln in out.splitlines():
+            f = ln.split()
+            if len(f) >= 6 and f[0] in ("fill", "read", "copy") and f[-1] == "TB/s":
+                best[f[0]] = max(best.get(f[0], 0.0), float(f[-2]) * 1e3)
+        return best or None
+    except Exception:
+        return None
+
+
+def profiled(config_key, kernel):
+    """HBM traffic / VALU figures of `kernel` from the committed rocprofv3 --pmc passes of THIS configuration
+    (profiles/<round>/traffic_by_config.json, assembled by tools/collect_traffic.py); None when not profiled."""
+    tf = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_by_config.json")
+    if not os.path.exists(tf):
+        return None, None
+    prof = json.load(open(tf)).get(config_key)
+    if not prof:
+        return None, None
+    k = prof["kernels"].get(kernel.split("<")[0].split(" ")[0])
+    src = f"profiles/{PROFILE_ROUND}/{prof.get('files', '')} (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE; {prof.get('command', '')})"
+    return k, src
+
+
+def roofline_of(kernel, kernel_ms, N_elems, w, costs_bytes, fused, config_key, copy_gbs):
+    """`roofline` object of one configuration: algorithmic bytes of SURVEY.md 8(d) -- N w (sampler write) + N w (sweep
+    read) + P S 8 for the fused launch, N w + P S 8 for the sweep alone -- over the launch time measured with HIP events."""
+    alg = (2 if fused else 1) * N_elems * w + costs_bytes
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    k, src = profiled(config_key, kernel)
+    r = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": k.get("bytes") if k else None}
+    detail = {"algorithmic_bytes_per_launch": alg, "avg_launch_ms": kernel_ms, "traffic_source": src,
+              "frac_of_box_copy_bw": achieved / copy_gbs["copy"] if copy_gbs and "copy" in copy_gbs else None,
+              "frac_of_guide_copy_bw": achieved / HBM_COPY_GBS,
+              "box_streaming_GBs": copy_gbs}
+    if k and "valu_floor_ms" in k:
+        detail["compute"] = {"valu_wave_insts_per_launch": k.get("valu_insts"),
+                             "valu_busy_cycles_per_simd": k.get("valu_busy_cycles_per_simd"),
+                             "valu_floor_ms": k["valu_floor_ms"], "frac_of_valu_floor": k["valu_floor_ms"] / kernel_ms,
+                             "valu_busy_frac_under_profiler": k.get("valu_busy_frac_under_profiler"),
+                             "profiled_clock_ghz": k.get("clock_ghz")}
+    return r, detail
+
+
 def kernel_profile(torch, pl, obs, steps):
     """Per-kernel device time with HIP events on the launch stream (a separate pass: the events sit
     between the kernels, so this pass is never the one whose wall time is reported)."""
@@ -157,31 +210,37 @@ def time_loop(torch, pl, obs, steps, warmup, barrier=None, one_call=True):
     return time.perf_counter() - t0
 
 
-def other_configs(torch, dev):
+def other_configs(torch, dev, copy_gbs=None):
     """The other single-GPU configurations of BASELINE.json, each timed for a few hundred iterations
     (they cost milliseconds): configs[0] in fp64, configs[1], configs[2] with the sdf field, and the
     per-GPU share of configs[4] (512 of 4096 particles, 4 goals; shard 3 of 8)."""
     f32, f64 = torch.float32, torch.float64
     specs = [
-        ("config 1: planar 4 x 16 x 64, fp64", dict(workload="planar", P_local=4, S=16, T=64, dtype=f64, goals=2), 300),
-        ("config 2: planar 256 x 64 x 128, fp32", dict(workload="planar", P_local=256, S=64, T=128, dtype=f32, goals=4), 300),
-        ("config 3 with the sdf sphere field", dict(workload="panda", P_local=1024, S=128, T=64, dtype=f32, field="sdf"), 100),
-        ("config 3 with 64 sphere obstacles (SURVEY 8d stress variant)",
+        ("config 1: planar 4 x 16 x 64, fp64", "cfg1", dict(workload="planar", P_local=4, S=16, T=64, dtype=f64, goals=2), 300),
+        ("config 2: planar 256 x 64 x 128, fp32", "cfg2", dict(workload="planar", P_local=256, S=64, T=128, dtype=f32, goals=4), 300),
+        ("config 3 with the sdf sphere field", "cfg3_sdf", dict(workload="panda", P_local=1024, S=128, T=64, dtype=f32, field="sdf"), 100),
+        ("config 3 with 64 sphere obstacles (SURVEY 8d stress variant)", "cfg3_64sph",
          dict(workload="panda", P_local=1024, S=128, T=64, dtype=f32, spheres=64), 40),
-        ("config 5 share: Panda 4 goals, 512 of 4096 particles x 256 x 128, fp32 (shard 3 of 8)",
+        ("config 5 share: Panda 4 goals, 512 of 4096 particles x 256 x 128, fp32 (shard 3 of 8)", "cfg5",
          dict(workload="panda", P_local=512, S=256, T=128, dtype=f32, goals=4, shard_of=(3, 8)), 60),
     ]
     out = []
-    for label, spec, steps in specs:
+    for label, key, spec, steps in specs:
         pl, obs, name = build_planner(torch, dev=dev, **spec)
         time_loop(torch, pl, obs, 150, 0)                        # (clock and chain-stream warm-up, see main())
         el = time_loop(torch, pl, obs, steps, 10)
         el1 = time_loop(torch, pl, obs, steps, 10, one_call=False)
         kms = kernel_profile(torch, pl, obs, min(steps, 30))
+        kernel = pl._engine.last_cost_kernel()
+        w = 4 if spec["dtype"] == f32 else 8
+        fused = kernel.startswith("fused_")
+        roof, roof_detail = roofline_of(kernel + (" (K2+K3 in one launch)" if fused else " (K3)"), kms["cost_sweep"],
+                                        spec["P_local"] * spec["S"] * spec["T"] * pl.d_state_opt, w,
+                                        spec["P_local"] * spec["S"] * 8, fused, key, copy_gbs)
         out.append({"config": label, "workload": name, "iterations_per_s": steps / el,
                     "ms_per_step": 1e3 * el / steps, "steps": steps,
                     "iterations_per_s_single_iteration_calls": steps / el1, "kernel_ms_per_step": kms,
-                    "cost_kernel": pl._engine.last_cost_kernel(),
+                    "cost_kernel": kernel, "roofline": roof, "roofline_detail": roof_detail,
                     "dtype": "f32" if spec["dtype"] == f32 else "f64"})
         del pl
         torch.cuda.empty_cache()
@@ -373,81 +432,96 @@ def main():
     split_steps = pl._engine.pipeline_split_steps() - split0
     # Pass 3 (reported beside it): the same K iterations as K optimize(opt_iters=1) calls
     elapsed_calls = time_loop(torch, pl, obs, args.steps, args.warmup, barrier, one_call=False)
+    rank_rates = None
     if use_dist:
-        t = torch.tensor([elapsed, elapsed_calls], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_calls = float(t[0]), float(t[1])
+        mine = torch.tensor([elapsed, elapsed_calls], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_rates = [args.steps / float(e[0]) for e in every]           # each rank's own clock, before the max
+        elapsed, elapsed_calls = max(float(e[0]) for e in every), max(float(e[1]) for e in every)
     mean_cost, mean_min_cost = pl.global_stats()
+    # what the communicator behind the C ABI itself reports (ncclCommCount / ncclCommUserRank / ncclGetVersion):
+    # proof that RCCL saw `world` ranks, not a number this script made up
+    comm_world, comm_rank, rccl_version = pl._engine.comm_info()
 
     if rank == 0:
         N_elems = P_local * S * T * d
         sweep_kernel = pl._engine.last_cost_kernel()          # what the dispatcher really launched
-        fused = sweep_kernel.startswith("fused_step")
-        if fused:
-            # K2 and K3 in one launch: samples are written once and never re-read by the sweep;
-            # algorithmic bytes of the pair stay SURVEY.md 8(d)'s N*w (sampler write) + N*w (sweep
-            # read) + P*S*8 -- traffic the fusion legitimately avoids raises the fraction
-            dom_ms = kms["cost_sweep"]                       # (the fused launch is booked on the sweep's events)
-            dom_bytes = 2 * N_elems * w + P_local * S * 8
-            dom_name = sweep_kernel + " (K2+K3 in one launch)"
-        else:
-            dom_ms = kms["cost_sweep"]
-            dom_bytes = N_elems * w + P_local * S * 8
-            dom_name = sweep_kernel + " (K3)"
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        # bytes the iteration really moves: K4 reads only the sample rows whose softmax weight is not
-        # exactly zero (one row per particle when the update is an arg-min)
+        fused = sweep_kernel.startswith("fused_")
+        copy_gbs = box_copy_bandwidth() if world == 1 else None
+        is_headline = args.workload == "panda" and (P_local, S, T, args.dtype, args.field, args.spheres, goals) == \
+            (1024, 128, 64, "f32", "rbf", 5, 1)
+        cfg_key = "cfg3" if is_headline else ("cfg2" if (args.workload, P_local, S, T) == ("planar", 256, 64, 128) else
+                                              "cfg5" if (args.workload, P_local, S, T, goals) == ("panda", 512, 256, 128, 4) else "")
+        # K2 and K3 in one launch: samples are written once and never re-read by the sweep; the algorithmic bytes of
+        # the pair stay SURVEY.md 8(d)'s N w + N w + P S 8 -- traffic the fusion legitimately avoids raises the fraction
+        roof, roof_detail = roofline_of(sweep_kernel + (" (K2+K3 in one launch)" if fused else " (K3)"), kms["cost_sweep"],
+                                        N_elems, w, P_local * S * 8, fused, cfg_key, copy_gbs)
+        # bytes the iteration really moves: K4 reads only the sample rows whose softmax weight is not exactly zero
         nnz_rows = int((pl._weights_buf != 0).sum())
         iter_alg = 3 * N_elems * w + 2 * P_local * T * d * w + 2 * P_local * S * 8
         iter_moved = ((1 if fused else 2) * N_elems * w + nnz_rows * T * d * w + 4 * P_local * T * d * w
                       + 3 * P_local * S * 8)
         ms_step = 1e3 * elapsed / args.steps
-        # HBM traffic and VALU instruction counts of the dominant kernel cannot be read from inside this
-        # process (PMC counters need rocprofv3): they come from the committed rocprofv3 --pmc passes of
-        # this same command (profiles/<round>/traffic.json), with provenance; null when not profiled
-        traffic = traffic_src = compute = None
-        tf = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")
-        is_headline = args.workload == "panda" and (P_local, S, T, args.dtype, args.field, args.spheres, goals) == \
-            (1024, 128, 64, "f32", "rbf", 5, 1)
-        if os.path.exists(tf) and is_headline:
-            prof = json.load(open(tf))
-            k = prof["kernels"].get(sweep_kernel)
-            if k:
-                traffic = k.get("bytes")
-                traffic_src = f"profiles/{PROFILE_ROUND}/traffic.json@{prof.get('tag', '?')} (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)"
-                if "valu_floor_ms" in k:
-                    compute = {"valu_wave_insts_per_launch": k.get("valu_insts"),
-                               "valu_busy_cycles_per_simd": k.get("valu_busy_cycles_per_simd"),
-                               "valu_floor_ms": k["valu_floor_ms"],
-                               "frac_of_valu_floor": k["valu_floor_ms"] / dom_ms,
-                               "valu_busy_frac_under_profiler": k.get("valu_busy_frac_under_profiler"),
-                               "profiled_clock_ghz": k.get("clock_ghz"),
-                               "how": k.get("valu_floor_how")}
+        parity = None
+        pf = os.path.join(ROOT, "profiles", PROFILE_ROUND, "parity_full_size.json")
+        if os.path.exists(pf):
+            rec = json.load(open(pf))
+            parity = {"source": f"profiles/{PROFILE_ROUND}/parity_full_size.json (tests/test_gpu_planner.py::test_config*_"
+                                "particles_match_*: particles of the FULL-SIZE run against the fp64 oracle on the restated "
+                                "noise stream)",
+                      "fp32_means_within_1e-3": {k.split(":")[0]: v["means_within_1e3"] for k, v in rec.items()},
+                      "cost_rel_err_max": max(v["cost_rel_max"] for v in rec.values()),
+                      "trials": sum(v["trials"] for v in rec.values())}
+        cpu = cpu_detail = fair = None
+        if world == 1 and not args.no_cpu_baseline:
+            t_cpu = time.perf_counter()
+            cpu_detail = cpu_baseline(args, torch, S, T, P_local)
+            cpu_detail["leg_seconds"] = time.perf_counter() - t_cpu
+            cpu = {"value": cpu_detail["value"], "unit": cpu_detail["unit"], "cores": cpu_detail["cores"],
+                   "kind": cpu_detail["kind"],
+                   "sample": f"{cpu_detail['sample_particles']} of {P_local} particles, full S x T, "
+                             f"{args.cpu_iters} iterations, extrapolated linearly in the particles"}
+            t_cpu = time.perf_counter()
+            fair = cpu_fair(args, torch, S, T, P_local)
+            if fair:
+                fair["leg_seconds"] = time.perf_counter() - t_cpu
+        value = world * args.steps / elapsed
+        # The FIRST 1500 characters carry what the driver's record keeps: value, single_iteration_calls, roofline,
+        # cpu_baseline.  Everything verbose follows.
         out = {
             "metric": "planner iterations/sec (and ms/iter) at fixed particles x samples x T",
-            # whole-job aggregate: every rank advances its 1024-particle shard by one iteration per
-            # step (weak scaling), so the job processes `world` shard-iterations per step; at N = 1
-            # this is plain planner iterations/s of the BASELINE config
-            "value": world * args.steps / elapsed,
-            "unit": "iterations/s" if world == 1 else
-                    f"iterations/s of a {P_local}-particle shard, summed over {world} shards",
-            "planner_iterations_per_s": args.steps / elapsed,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step,
+            # whole-job aggregate: every rank advances its 1024-particle shard by one iteration per step (weak
+            # scaling); at N = 1 this is plain planner iterations/s of the BASELINE config
+            "value": value,
+            "unit": "iterations/s" if world == 1 else f"iterations/s of a {P_local}-particle shard, summed over {world} shards",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
+            "single_iteration_calls": {"iterations_per_s": world * args.steps / elapsed_calls,
+                                       "ms_per_step": 1e3 * elapsed_calls / args.steps},
+            "roofline": roof,
+            "cpu_baseline": cpu,
             "config": {"workload": name, "particles_per_gpu": P_local, "particles_total": P_local * world,
                        "samples": S, "traj_len": T, "state_dim": d,
                        "parallelism": f"particle-sharded x{world}, RCCL statistics all-reduce inside sgpmp_step"
                        if world > 1 else "single GPU",
-                       "noise": "philox (in-kernel)", "prior_factor_dtype": "f64"},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "frac_of_measured_copy_bw": achieved / HBM_COPY_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                         "compute": compute},
+                       "noise": f"philox4x32-{pl._engine.lib.sgpmp_philox_rounds()} + Box-Muller (in-kernel)",
+                       "prior_factor_dtype": "f64"},
+            "rccl": {"ranks": comm_world, "rank": comm_rank, "version": rccl_version,
+                     "how": "ncclCommCount / ncclCommUserRank / ncclGetVersion of the communicator sgpmp_step all-reduces on "
+                            "(0 ranks: no communicator attached, single GPU)"},
+            "per_rank_iterations_per_s": None if rank_rates is None else
+            {"min": min(rank_rates), "max": max(rank_rates), "all": rank_rates},
+            "planner_iterations_per_s": args.steps / elapsed,
+            "speedup_vs_cpu_baseline": value / cpu["value"] if cpu else None,
+            "parity": parity,
+            "roofline_detail": roof_detail,
+            "cpu_baseline_detail": cpu_detail,
+            "cpu_fair": fair,
+            "speedup_vs_cpu_fair": value / fair["value"] if fair else None,
             "kernel_ms_per_step": kms,
+            "launches_per_iteration": pl._engine.last_step_launches(),
             "passes": "1: 2 x optimize(opt_iters=100) untimed (clock and stream warm-up), then 100 iterations with HIP "
                       "events between the kernels (kernel_ms_per_step, roofline); "
                       "2: optimize(opt_iters=W) untimed, then optimize(opt_iters=K) -- the reference's own loop, "
@@ -459,8 +533,6 @@ def main():
                              "runs the call's iterations as two particle-half launch sequences on two streams of "
                              "its own (sgpmp_pipeline_begin/_end): one half's update kernel runs under the other "
                              "half's sampler + sweep launch; bit-identical results"},
-            "single_iteration_calls": {"iterations_per_s": world * args.steps / elapsed_calls,
-                                       "ms_per_step": 1e3 * elapsed_calls / args.steps},
             "iteration_roofline": {"algorithmic_bytes": iter_alg, "moved_bytes": iter_moved,
                                    "k4_rows_read": nnz_rows,
                                    "achieved_GBs": iter_alg / (ms_step * 1e-3) / 1e9,
@@ -472,20 +544,11 @@ def main():
         if world == 1 and not args.no_other_configs and is_headline:
             del pl
             torch.cuda.empty_cache()
-            out["other_configs"] = other_configs(torch, dev)
-        if world == 1 and not args.no_cpu_baseline:
-            t_cpu = time.perf_counter()
-            out["cpu_baseline"] = cpu_baseline(args, torch, S, T, P_local)
-            out["cpu_baseline"]["leg_seconds"] = time.perf_counter() - t_cpu
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-            t_cpu = time.perf_counter()
-            fair = cpu_fair(args, torch, S, T, P_local)
-            if fair:
-                fair["leg_seconds"] = time.perf_counter() - t_cpu
-            if fair:
-                out["cpu_fair"] = fair
-                out["speedup_vs_cpu_fair"] = out["value"] / fair["value"]
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+            out["other_configs"] = other_configs(torch, dev, copy_gbs)
+        line = json.dumps(out)
+        head = line[:1500]
+        assert all(k in head for k in ('"value"', '"single_iteration_calls"', '"roofline"', '"cpu_baseline"')), len(head)
+        os.write(json_fd, (line + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
