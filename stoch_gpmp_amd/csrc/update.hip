@@ -51,6 +51,12 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
     __shared__ int nnz_s;
     const int p = blockIdx.x;
     const cost_t* c = costs + (size_t)p * S;
+    // (issued first, consumed last: the four distinct entries of an isotropic prior's one-step precision -- the tail
+    // below would otherwise pay two dependent global loads per element)
+    const bool iso_tail = nx.out && nx.isotropic;
+    const int nd = 2 * nx.n;
+    const double q00 = iso_tail ? nx.Qinv[0] : 0., q01 = iso_tail ? nx.Qinv[nx.n] : 0.;
+    const double q10 = iso_tail ? nx.Qinv[nx.n * nd] : 0., q11 = iso_tail ? nx.Qinv[nx.n * nd + nx.n] : 0.;
 
     // softmax(-c / temperature) exactly as torch.softmax: exp(z - max z) / sum
     double zmax = -1.7976931348623157e308, csum = 0., cmin = 1.7976931348623157e308;
@@ -88,7 +94,16 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
         w[s] = e;
         part += e;
     }
-    const double Z = block_reduce<double>(part, scratch, false);
+    double Z;
+    {   // (one barrier: `scratch` is written once in this kernel)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (lane == 0) scratch[wave] = part;
+        __syncthreads();
+        Z = scratch[0];
+        for (int i = 1; i < nw; ++i) Z += scratch[i];
+    }
     if (stats) {
         const double tot = csum, mn = cmin;
         if (threadIdx.x == 0) {
@@ -145,20 +160,20 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int i = 0; i < VW; ++i) acc[i] += ws[u] * (double)(v[u][i] - mu_m[i]);
+                for (int i = 0; i < VW; ++i) acc[i] = fma(ws[u], (double)(v[u][i] - mu_m[i]), acc[i]);
         }
         for (; k < nnz; ++k) {
             const int s = idx[k];
             const double ws = w[s];
             const vec v = *reinterpret_cast<const vec*>(X + (size_t)s * M + m);
 #pragma unroll
-            for (int i = 0; i < VW; ++i) acc[i] += ws * (double)(v[i] - mu_m[i]);
+            for (int i = 0; i < VW; ++i) acc[i] = fma(ws, (double)(v[i] - mu_m[i]), acc[i]);
         }
         vec g, mn;
 #pragma unroll
         for (int i = 0; i < VW; ++i) {
             g[i] = (real)acc[i];
-            mn[i] = (real)((double)mu_m[i] + step_size * acc[i]);
+            mn[i] = (real)fma(step_size, acc[i], (double)mu_m[i]);
         }
         if (grad) *reinterpret_cast<vec*>(grad + (size_t)p * M + m) = g;
         if (means_prev) *reinterpret_cast<vec*>(means_prev + (size_t)p * M + m) = mu_m;
@@ -174,8 +189,9 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
         const int d = 2 * nx.n, Tn = M / d;
         const real* mu_new = mu_lds;
         for (int e = threadIdx.x; e < (Tn + 1) * d; e += blockDim.x)
-            nx.out[(size_t)p * (Tn + 1) * d + e] = is_weight_elem<real>(nx.n, Tn, mu_new, nx.Qinv, nx.ks, nx.kg, nx.dt,
-                                                                         temperature, nx.isotropic, e);
+            nx.out[(size_t)p * (Tn + 1) * d + e] =
+                iso_tail ? is_weight_elem_iso<real>(nx.n, Tn, mu_new, q00, q01, q10, q11, nx.ks, nx.kg, nx.dt, temperature, e)
+                         : is_weight_elem<real>(nx.n, Tn, mu_new, nx.Qinv, nx.ks, nx.kg, nx.dt, temperature, nx.isotropic, e);
     }
 }
 

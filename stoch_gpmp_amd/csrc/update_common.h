@@ -42,6 +42,35 @@ __device__ __forceinline__ real is_weight_elem(int n, int T, const real* __restr
     return (real)(temperature * v);
 }
 
+// Importance-sampling weight element for an ISOTROPIC prior with the four distinct entries of its one-step precision
+// Q^-1 = [[q00, q01], [q10, q11]] (x) I_n held in registers -- is_weight_elem's arithmetic (update_common.h) on the
+// same numbers, without its two global loads per element: under the launch's store traffic every dependent
+// vector-memory round trip of the in-launch update costs ~3 us, and the update kernel saves a dependent trip per element.
+template <typename real>
+__device__ __forceinline__ real is_weight_elem_iso(int N, int T, const real* __restrict__ mu, double q00, double q01, double q10,
+                                                   double q11, double ks, double kg, double dt, double temperature, int e) {
+    const int d = 2 * N;
+    const int t = e / d, i = e - t * d;
+    if (t == T) return (real)0;
+    double v;
+    if (t == 0) {
+        v = ks * (double)mu[i];
+    } else {
+        const real* a = mu + (size_t)(t - 1) * d;
+        const real* b = mu + (size_t)t * d;
+        const int k = i < N ? i : i - N;
+        const double ep = (double)b[k] - ((double)a[k] + dt * (double)a[N + k]);
+        const double ev = (double)b[N + k] - (double)a[N + k];
+        v = (i < N ? q00 : q10) * ep + (i < N ? q01 : q11) * ev;
+    }
+    if (kg >= 0.) {
+        const real* last = mu + (size_t)(T - 1) * d;
+        const double k = (double)(T - 1 - t);
+        v += (i < N) ? kg * (double)last[i] : kg * (k * dt * (double)last[i - N] + (double)last[i]);
+    }
+    return (real)(temperature * v);
+}
+
 template <typename real> struct IswNext {            // K4's optional tail (next step's IS weights)
     real* out;               // [P][T+1][d] or null
     const double* Qinv;
