@@ -104,7 +104,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"k3_no_one", &SgpmpToggles::k3_no_one}, {"k3_no_lds_prefetch", &SgpmpToggles::k3_no_lds_prefetch},
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
-    {"tail_update", &SgpmpToggles::tail_update},
+    {"tail_update", &SgpmpToggles::tail_update}, {"comm_packet_event", &SgpmpToggles::comm_packet_event},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {
@@ -906,7 +906,8 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
                 c->last_step_launches += 1;
             }
         HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, Ph, S, c64, SGPMP_F64, X, mu, temperature, step_size, wh, gh, mph,
-                             slot, sh, k4_done[h], &pr, isw, &tail[h]));
+                             slot, sh, c->tg.comm_packet_event ? k4_done[h] : nullptr, &pr, isw, &tail[h]));
+        if (!c->tg.comm_packet_event && k4_done[h]) HIPCHK(hipEventRecord(k4_done[h], sh));
         c->last_step_launches += 1;
     }
     c->isw_ready = tail[0] && tail[1]; c->isw_means = means; c->isw_temperature = temperature;
@@ -1041,8 +1042,10 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         if (c->ms_buf && c->ms_used[slot] && hipEventQuery(c->ms_read[slot]) != hipSuccess)
             HIPCHK(hipStreamWaitEvent(st, c->ms_read[slot], 0));
         HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
-                             temperature, step_size, weights, grad, means_prev, acc_stats, st, k4_done, &pr, c->d_isw,
+                             temperature, step_size, weights, grad, means_prev, acc_stats, st,
+                             c->tg.comm_packet_event ? k4_done : nullptr, &pr, c->d_isw,
                              &isw_written, c->ms_buf ? c->ms_snap[slot] : nullptr));
+        if (!c->tg.comm_packet_event && k4_done) HIPCHK(hipEventRecord(k4_done, st));
         c->last_step_launches += 1;
         if (c->ms_buf) {
             if ((rc = step_mode_stats(c, slot, st)) != SGPMP_OK) return rc;

@@ -107,6 +107,7 @@ struct SgpmpToggles {
     int no_fused_step;        // SGPMP_NO_FUSED_STEP        K2 and K3 as separate kernels inside sgpmp_step
     int no_chunked_sweep;     // SGPMP_NO_CHUNKED_SWEEP     64-lane-pass two-trajectory sweeps instead of the chunked one
     int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
+    int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
     int tail_update;          // SGPMP_TAIL_UPDATE          the update INSIDE the fused launch (fused_tail.inc) instead of update_kernel as a second launch: one launch per iteration; measured slower at config 3, hence opt-in
     long long tail_debug;     // SGPMP_TAIL_DEBUG           timing experiments on the in-launch update (wrong results): 1, 2, 3
     long long pipe_split;     // SGPMP_PIPE_SPLIT           first chain's share of the particles in 16ths (0 = default 8)

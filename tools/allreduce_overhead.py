@@ -1,6 +1,7 @@
 """Cost of the per-iteration statistics all-reduce at one rank (1-rank RCCL group on one GPU):
 off   -- no communicator
-rccl  -- the C-ABI path: sgpmp_step enqueues ncclAllReduce on the context's side stream (event-chained)
+rccl  -- the C-ABI path: sgpmp_step enqueues ncclAllReduce on the context's side stream (chained by an event recorded
+         behind the update kernel; rccl/packet-event: by the update kernel's own stop event, round 2's default)
 torch -- collective='torch': torch.distributed.all_reduce(async_op=True) from Python (round-1 path)
 rccl+modes -- rccl, plus the per-goal mean statistics every step (mode_stats=True: update-kernel snapshot, per-goal
          reduction and a second ncclAllReduce of [G][T d + 1][2] doubles on the side stream)"""
@@ -35,12 +36,14 @@ def timeit(pl, n=300):
 
 
 pls = {m: build(m) for m in ("off", "rccl", "torch", "rccl+modes")}
+pls["rccl/packet-event"] = build("rccl")
+pls["rccl/packet-event"]._engine.set_option("comm_packet_event", 1)
 res = {m: [] for m in pls}
 for rnd in range(5):                       # interleaved rounds in one process
     for m, pl in pls.items():
         res[m].append(timeit(pl))
 base = min(res["off"])
 for m, v in res.items():
-    print(f"{m:10s}: min {min(v)*1e6:7.1f} us  median {sorted(v)[len(v)//2]*1e6:7.1f} us per iteration "
+    print(f"{m:16s}: min {min(v)*1e6:7.1f} us  median {sorted(v)[len(v)//2]*1e6:7.1f} us per iteration "
           f"(+{(min(v)-base)*1e6:5.1f} us vs off)")
 dist.destroy_process_group()
