@@ -118,6 +118,7 @@ static void toggles_from_env(SgpmpToggles& tg) {
     if (const char* e = getenv("SGPMP_K3_BLOCKS")) tg.k3_blocks = atoll(e);
     if (const char* e = getenv("SGPMP_PIPE_SPLIT")) tg.pipe_split = atoll(e);
     if (const char* e = getenv("SGPMP_TAIL_DEBUG")) tg.tail_debug = atoll(e);
+    if (const char* e = getenv("SGPMP_PLANAR_SLABS")) tg.planar_slabs = atoll(e);
 }
 
 extern "C" int sgpmp_abi_version(void) { return SGPMP_ABI_VERSION; }
@@ -132,6 +133,7 @@ static int alloc_prior(sgpmp_ctx* c, PriorDev& p) {
     HIPCHK(hipMalloc(&p.H, sizeof(double) * T * d * d));
     HIPCHK(hipMalloc(&p.iso64, sizeof(double) * T * 8));
     HIPCHK(hipMalloc(&p.iso32, sizeof(float) * T * 8));
+    HIPCHK(hipMalloc(&p.slabpre, sizeof(float) * 3 * T * 4));
     HIPCHK(hipMalloc(&p.Qinv, sizeof(double) * d * d));
     HIPCHK(hipMalloc(&p.G32, sizeof(float) * T * d * d));
     HIPCHK(hipMalloc(&p.H32, sizeof(float) * T * d * d));
@@ -140,7 +142,7 @@ static int alloc_prior(sgpmp_ctx* c, PriorDev& p) {
 }
 
 static void free_prior(PriorDev& p) {
-    hipFree(p.blocks); hipFree(p.G); hipFree(p.H); hipFree(p.iso64); hipFree(p.iso32);
+    hipFree(p.blocks); hipFree(p.G); hipFree(p.H); hipFree(p.iso64); hipFree(p.iso32); hipFree(p.slabpre);
     hipFree(p.Qinv); hipFree(p.G32); hipFree(p.H32); hipFree(p.status); hipFree(p.Dm); hipFree(p.Em);
     std::memset(&p, 0, sizeof(p));
 }
@@ -197,6 +199,7 @@ extern "C" int sgpmp_set_option(sgpmp_ctx* c, const char* name, long long value)
     if (!c || !name) return fail(SGPMP_EINVAL, "sgpmp_set_option: null argument");
     if (std::strcmp(name, "k3_blocks") == 0) { c->tg.k3_blocks = value; return SGPMP_OK; }
     if (std::strcmp(name, "pipe_split") == 0) { c->tg.pipe_split = value; return SGPMP_OK; }
+    if (std::strcmp(name, "planar_slabs") == 0) { c->tg.planar_slabs = value; return SGPMP_OK; }
     for (const auto& t : kToggleNames)
         if (std::strcmp(name, t.name) == 0) { c->tg.*(t.flag) = value != 0; return SGPMP_OK; }
     return fail(SGPMP_EINVAL, std::string("sgpmp_set_option: unknown option ") + name);
@@ -350,6 +353,37 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     delete c;
 }
 
+// Prefix products of the scan's 2 x 2 propagators H_t = [[h11, h12], [h21, h22]] from the start of a time slab, for 2 and
+// for 4 slabs per trajectory: what the slab-parallel planar launch (fused_planar_slab.inc) needs to carry a slab's true
+// start state through the slab.  Once per factorisation, in fp64 on the host from K1's coefficients (T x 8 doubles).
+static int upload_slab_prefix(sgpmp_ctx* c, PriorDev& p, hipStream_t st) {
+    if (!p.isotropic) return SGPMP_OK;
+    const int T = c->dims.traj_len;
+    std::vector<double> iso((size_t)T * 8);
+    HIPCHK(hipMemcpyAsync(iso.data(), p.iso64, sizeof(double) * T * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<float> tab((size_t)3 * T * 4, 0.f);
+    for (int wi = 0; wi < 3; ++wi) {                                 // tables: 2 slabs, 4 slabs, the scan's own segments
+        const int W = wi == 0 ? 2 : 4;
+        if (wi < 2 && T % W) continue;
+        // (segments of the in-chunk scan: 16-waypoint chunks cut into 4 segments for n = 2, 2 for n = 3: fused_planar.inc)
+        const int L = wi < 2 ? T / W : (c->dims.n_dof == 2 ? 4 : 8);
+        double p00 = 1., p01 = 0., p10 = 0., p11 = 1.;
+        for (int t = 0; t < T; ++t) {
+            if (t % L == 0) { p00 = 1.; p01 = 0.; p10 = 0.; p11 = 1.; }
+            const double* h = &iso[(size_t)t * 8];                   // g11 g21 g22 h11 h12 h21 h22 -
+            const double n00 = h[3] * p00 + h[4] * p10, n01 = h[3] * p01 + h[4] * p11;
+            const double n10 = h[5] * p00 + h[6] * p10, n11 = h[5] * p01 + h[6] * p11;
+            p00 = n00; p01 = n01; p10 = n10; p11 = n11;
+            float* o = &tab[((size_t)wi * T + t) * 4];
+            o[0] = (float)p00; o[1] = (float)p01; o[2] = (float)p10; o[3] = (float)p11;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(p.slabpre, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return SGPMP_OK;
+}
+
 extern "C" int sgpmp_set_prior(sgpmp_ctx* c, int which, double dt, double sigma_start, double sigma_gp,
                                double sigma_goal, const double* qc_inv, void* stream) {
     if (!c || (which != 0 && which != 1)) return fail(SGPMP_EINVAL, "sgpmp_set_prior: bad argument");
@@ -375,6 +409,8 @@ extern "C" int sgpmp_set_prior(sgpmp_ctx* c, int which, double dt, double sigma_
     HIPCHK(hipStreamSynchronize(st));
     if (status != 0)
         return fail(SGPMP_ENOTPD, "sgpmp_set_prior: prior precision matrix is not positive definite");
+    int rcs;
+    if ((rcs = upload_slab_prefix(c, p, st)) != SGPMP_OK) return rcs;
     p.valid = 1;
     return SGPMP_OK;
 }
@@ -417,6 +453,8 @@ extern "C" int sgpmp_set_priors(sgpmp_ctx* c, double dt, const double* sigma_sta
     HIPCHK(hipStreamSynchronize(st));
     for (int w = 0; w < 2; ++w) {
         if (status[w] != 0) return fail(SGPMP_ENOTPD, "sgpmp_set_priors: prior precision matrix is not positive definite");
+        int rcs;
+        if ((rcs = upload_slab_prefix(c, c->prior[w], st)) != SGPMP_OK) return rcs;
         c->prior[w].valid = 1;
     }
     return SGPMP_OK;

@@ -497,6 +497,7 @@ static bool make_flat(const CostProgram& p, FlatProg<real>& f) {
 #include "cost_sweep_dual.inc"
 #include "fused_step.inc"
 #include "fused_planar.inc"
+#include "fused_planar_slab.inc"
 
 // Does a step qualify for a fused launch?  1: chain-code program (fused_step.inc), 2: program without forward
 // kinematics (fused_planar.inc), 0: no.
@@ -593,6 +594,28 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     if (tg.k3_blocks > 0) cap = tg.k3_blocks;
     if (blocks > cap) blocks = cap;
     if (kind == 2) {
+        // Opt-in (planar_slabs = 2 / 4): the trajectory split into W time slabs over the waves of a workgroup
+        // (fused_planar_slab.inc), when the slabs are whole 16-waypoint chunks of at most 64 waypoints and the items
+        // fill the workgroups.  Same results; measured level with fused_planar_kernel at config 2 (23.2 vs 22.4 us:
+        // 35 % more vector instructions and two rounds of workgroups eat what the shorter chains gain).
+        int W = 0;
+        const long long force = tg.planar_slabs;
+        auto fits = [&](int w) { return T % (SGPMP_FUSED_TC * w) == 0 && T / w <= 64 && nitems % (4 / w) == 0 && nitems * w / 4 <= cap; };
+        if (force == 4 && fits(4)) W = 4;
+        else if ((force == 2 || force == 4) && fits(2)) W = 2;
+        if (W) {
+            const int d = 2 * n, head = ((d + 3) / 4) * 4, L = T / W;
+            const size_t lds = (size_t)4 * ((size_t)SGPMP_FUSED_SPW * (head + L * d) + (size_t)2 * L * d + (size_t)L * 16) * sizeof(float);
+            const float* tab = prior.slabpre + (size_t)(W == 4 ? 1 : 0) * T * 4;
+            const unsigned wgs = (unsigned)(nitems * W / 4);
+#define SLAB_LAUNCH(NN, WW) hipLaunchKernelGGL((fused_planar_slab_kernel<NN, WW>), dim3(wgs), dim3(256), (unsigned)lds, stream, a, F, fs, tab)
+            if (n == 2) { if (W == 4) SLAB_LAUNCH(2, 4); else SLAB_LAUNCH(2, 2); }
+            else { if (W == 4) SLAB_LAUNCH(3, 4); else SLAB_LAUNCH(3, 2); }
+#undef SLAB_LAUNCH
+            if (picked) *picked = W == 4 ? "fused_planar_slab_kernel<4 slabs>" : "fused_planar_slab_kernel<2 slabs>";
+            *launched = true;
+            return hipGetLastError();
+        }
         if (n == 2) hipLaunchKernelGGL((fused_planar_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);
         else hipLaunchKernelGGL((fused_planar_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);
         if (picked) *picked = "fused_planar_kernel";

@@ -18,6 +18,9 @@ struct PriorDev {
     double* H;         // [T][d][d]
     double* iso64;     // [T][8]  g11 g21 g22 h11 h12 h21 h22 0   (valid when isotropic)
     float* iso32;      // [T][8]
+    float* slabpre;    // [3][T][4]  isotropic priors: prefix products H_t .. H_{start} of the scan's 2 x 2 propagators from the
+                       //            start of t's time slab (2 slabs, 4 slabs) and of its in-chunk segment
+                       //            (fused_planar_slab.inc), built by the host in fp64
     double* Qinv;      // [d][d]   one-step GP precision of this prior
     float* G32;        // [T][d][d] fp32 copies for the dense sampler
     float* H32;
@@ -108,6 +111,7 @@ struct SgpmpToggles {
     int no_chunked_sweep;     // SGPMP_NO_CHUNKED_SWEEP     64-lane-pass two-trajectory sweeps instead of the chunked one
     int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
+    long long planar_slabs;   // SGPMP_PLANAR_SLABS         time slabs of the planar one-launch step: 0 none (fused_planar_kernel, default), 2, 4 (fused_planar_slab.inc, where the shape allows)
     int tail_update;          // SGPMP_TAIL_UPDATE          the update INSIDE the fused launch (fused_tail.inc) instead of update_kernel as a second launch: one launch per iteration; measured slower at config 3, hence opt-in
     long long tail_debug;     // SGPMP_TAIL_DEBUG           timing experiments on the in-launch update (wrong results): 1, 2, 3
     long long pipe_split;     // SGPMP_PIPE_SPLIT           first chain's share of the particles in 16ths (0 = default 8)
