@@ -549,6 +549,10 @@ def main():
         head = line[:1500]
         assert all(k in head for k in ('"value"', '"single_iteration_calls"', '"roofline"', '"cpu_baseline"')), len(head)
         os.write(json_fd, (line + "\n").encode())
+    # the context (and its RCCL communicator) goes before torch's process group does
+    pl = None
+    import gc
+    gc.collect()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

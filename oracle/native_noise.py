@@ -2,13 +2,13 @@
 
 The reference draws eps = randn(S, P, M) from torch's sequential global generator (planner.py:48-49,
 torch multivariate_normal.py:250-253); the HIP sampler's default mode replaces that by a counter-based
-stream (csrc/rng.h): Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3",
+stream (csrc/rng.h): Philox4x32-R, R = 7 by default, 10 as a build option (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3",
 SC'11 -- the generator behind curand / torch.cuda) + Box-Muller, keyed on
 (seed, draw, global particle, sample, waypoint pair, dof).  This file restates that stream so that the
 native mode has a deterministic checker too: `native_eps(...)` returns the noise in torch's
 `randn(S, P, M)` layout, ready for `oracle.ref_equiv.TrajPrior.sample(eps=...)`.
 
-Pinned by the Random123 known-answer vectors for philox4x32-10 (tests/test_oracle_golden.py).
+Pinned by the Random123 known-answer vectors for philox4x32 with 7 and with 10 rounds (tests/test_oracle_golden.py).
 """
 import numpy as np
 
