@@ -104,7 +104,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"k3_no_one", &SgpmpToggles::k3_no_one}, {"k3_no_lds_prefetch", &SgpmpToggles::k3_no_lds_prefetch},
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
-    {"tail_update", &SgpmpToggles::tail_update}, {"comm_packet_event", &SgpmpToggles::comm_packet_event},
+    {"tail_update", &SgpmpToggles::tail_update}, {"small_step", &SgpmpToggles::small_step}, {"comm_packet_event", &SgpmpToggles::comm_packet_event},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {
@@ -1042,6 +1042,29 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, means, P, temperature, c->d_isw, acc_stats, st));
     if (se) { HIPCHK(hipEventRecord(se->ev[1], st)); se->has[0] = !prepared; }
     c->last_step_launches = prepared ? 0 : 1;
+    // Small problem without forward kinematics: the whole iteration -- sampler, costs, update, next step's weights --
+    // as ONE launch, a workgroup per particle (small_step.inc); bit-identical to the separate launches
+    if (!eps && samples && small_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, P, S, c->tg)) {
+        const int slot = (int)(c->ms_step & 1);
+        if (c->ms_buf && c->ms_used[slot] && hipEventQuery(c->ms_read[slot]) != hipSuccess)
+            HIPCHK(hipStreamWaitEvent(st, c->ms_read[slot], 0));
+        FusedTailHost th = {nullptr, c->d_done, c->d_tail_acc, acc_stats, weights, grad, means_prev, temperature, step_size};
+        if (se) { HIPCHK(hipEventRecord(se->ev[2], st)); se->has[1] = false; }
+        HIPCHK(launch_small_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, seed, draw, means, P, D.particle_offset, S, samples,
+                                 c->d_isw, costs, c->d_costs64, th, c->d_isw, c->ms_buf ? c->ms_snap[slot] : nullptr, st,
+                                 c->tg.comm_packet_event ? k4_done : nullptr));
+        if (!c->tg.comm_packet_event && k4_done) HIPCHK(hipEventRecord(k4_done, st));
+        c->last_cost_kernel = "small_step_kernel";
+        c->last_step_launches += 1;
+        c->isw_ready = true; c->isw_means = means; c->isw_temperature = temperature;
+        if (se) { HIPCHK(hipEventRecord(se->ev[3], st)); HIPCHK(hipEventRecord(se->ev[4], st)); se->has[3] = false; }
+        if (c->ms_buf) {
+            if ((rc = step_mode_stats(c, slot, st)) != SGPMP_OK) return rc;
+            c->ms_step += 1;
+        }
+        if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats, false));
+        return SGPMP_OK;
+    }
     bool tail_ran = false;                                       // the update ran inside the fused launch
     if (fused) {
         if (se) { HIPCHK(hipEventRecord(se->ev[2], st)); se->has[1] = false; }   // (fused: the whole launch is booked on the sweep)

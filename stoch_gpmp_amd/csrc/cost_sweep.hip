@@ -498,6 +498,7 @@ static bool make_flat(const CostProgram& p, FlatProg<real>& f) {
 #include "fused_step.inc"
 #include "fused_planar.inc"
 #include "fused_planar_slab.inc"
+#include "small_step.inc"
 
 // Does a step qualify for a fused launch?  1: chain-code program (fused_step.inc), 2: program without forward
 // kinematics (fused_planar.inc), 0: no.
@@ -544,6 +545,65 @@ bool fused_tail_eligible(int dtype, int n, int T, const PriorDev& prior, const C
     const size_t tile_bytes = (size_t)SGPMP_FUSED_SPW * ((((2 * n + 3) / 4) * 4) + SGPMP_FUSED_TC * 2 * n) * 4;
     if (((long long)P * S / SGPMP_FUSED_SPW + 3) / 4 > (tg.k3_blocks > 0 ? tg.k3_blocks : (1LL << 18))) return false;   // one item per wave
     return T <= 64 * SGPMP_TAIL_MAX_BLOCKS && S <= SGPMP_TAIL_MAX_S && tail_lds_bytes(S, T * 2 * n, 2 * n) <= tile_bytes;
+}
+
+// ---- the whole iteration in one launch for small problems without forward kinematics (small_step.inc)
+static size_t small_step_lds(int n, int T, int S, size_t esz) {
+    const size_t M = (size_t)T * 2 * n;
+    const size_t upd = (((size_t)S * 12 + 15) & ~(size_t)15) + M * esz;                 // update_particle's scratch ...
+    const size_t scan = ((size_t)T * 4 + (size_t)S * n * 8 * 2) * esz;                   // ... which the slab scan uses first
+    return (size_t)S * (M + 4) * esz + (size_t)T * 8 * esz + (M + (size_t)(T + 1) * 2 * n + 4 * n + 2) * esz + (size_t)S * 8 +
+           (upd > scan ? upd : scan) + 64;
+}
+
+bool small_step_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, int P, int S,
+                         const SgpmpToggles& tg) {
+    if (!tg.small_step || !prior.isotropic || h_prog.needs_fk || h_prog.n_ee > 0 || (n != 2 && n != 3) || P < 1) return false;
+    if (dtype == SGPMP_F32) { FlatProg<float> F; if (!make_flat<float>(h_prog, F) || (F.has_gp && (float)prior.dt != F.gp.dt)) return false; }
+    else { FlatProg<double> F; if (!make_flat<double>(h_prog, F) || (F.has_gp && prior.dt != F.gp.dt)) return false; }
+    // one workgroup per particle holds its S x T x d samples in LDS; worth it while the launch is a handful of
+    // workgroups per CU (beyond that the per-kernel launches are not latency-bound any more)
+    return small_step_lds(n, T, S, dtype == SGPMP_F64 ? 8 : 4) <= 64 * 1024 && P <= 1024;
+}
+
+template <typename real>
+static hipError_t small_step_launch(int n, int T, const PriorDev& prior, const CostProgram& h_prog, uint64_t seed, uint64_t draw,
+                                    void* means, int P, int mode_offset, int S, void* samples, const void* isw, void* costs,
+                                    double* costs64, const FusedTailHost& th, void* isw_next, void* means_copy,
+                                    hipStream_t stream, hipEvent_t done) {
+    FlatProg<real> F;
+    make_flat<real>(h_prog, F);
+    CostArgs<real> a;
+    std::memset(&a, 0, sizeof(a));
+    a.T = T; a.batch = (long long)P * S; a.batch_offset = (long long)mode_offset * S; a.isw = (const real*)isw;
+    a.rows_per_particle = S; a.is_dt = (real)prior.dt; a.costs = (real*)costs; a.costs64 = costs64;
+    a.rpp_shift = a.rpg_shift = -1;
+    SmallArgs s;
+    std::memset(&s, 0, sizeof(s));
+    s.coef = sizeof(real) == 8 ? (const void*)prior.iso64 : (const void*)prior.iso32;
+    s.means = means; s.samples = samples; s.seed = seed; s.draw = draw; s.mode_offset = mode_offset; s.S = S; s.P = P;
+    s.temperature = th.temperature; s.step_size = th.step_size; s.weights = th.weights; s.grad = th.grad;
+    s.means_prev = th.means_prev; s.done = th.done; s.acc = th.acc; s.stats_out = th.stats_out; s.means_copy = means_copy;
+    IswNext<real> nx{(real*)isw_next, prior.Qinv, prior.ks, prior.kg, prior.dt, n, prior.isotropic};
+    const size_t lds = small_step_lds(n, T, S, sizeof(real));
+    if (n == 2)
+        hipExtLaunchKernelGGL((small_step_kernel<real, 2>), dim3((unsigned)P), dim3(SGPMP_SMALL_THREADS), (unsigned)lds, stream, (hipEvent_t) nullptr, done,
+                              0u, a, F, s, nx);
+    else
+        hipExtLaunchKernelGGL((small_step_kernel<real, 3>), dim3((unsigned)P), dim3(SGPMP_SMALL_THREADS), (unsigned)lds, stream, (hipEvent_t) nullptr, done,
+                              0u, a, F, s, nx);
+    return hipGetLastError();
+}
+
+hipError_t launch_small_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, uint64_t seed,
+                             uint64_t draw, void* means, int P, int mode_offset, int S, void* samples, const void* isw,
+                             void* costs, double* costs64, const FusedTailHost& th, void* isw_next, void* means_copy,
+                             hipStream_t stream, hipEvent_t done) {
+    if (dtype == SGPMP_F64)
+        return small_step_launch<double>(n, T, prior, h_prog, seed, draw, means, P, mode_offset, S, samples, isw, costs, costs64,
+                                         th, isw_next, means_copy, stream, done);
+    return small_step_launch<float>(n, T, prior, h_prog, seed, draw, means, P, mode_offset, S, samples, isw, costs, costs64, th,
+                                    isw_next, means_copy, stream, done);
 }
 
 // K2 + K3 in one launch when the step qualifies; *launched says whether it did.

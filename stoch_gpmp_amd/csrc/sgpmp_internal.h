@@ -112,6 +112,7 @@ struct SgpmpToggles {
     int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
     long long planar_slabs;   // SGPMP_PLANAR_SLABS         time slabs of the planar one-launch step: 0 none (fused_planar_kernel, default), 2, 4 (fused_planar_slab.inc, where the shape allows)
+    int small_step;           // SGPMP_SMALL_STEP           small no-FK problems as ONE launch, a workgroup per particle (small_step.inc); measured slower than the separate launches, hence opt-in
     int tail_update;          // SGPMP_TAIL_UPDATE          the update INSIDE the fused launch (fused_tail.inc) instead of update_kernel as a second launch: one launch per iteration; measured slower at config 3, hence opt-in
     long long tail_debug;     // SGPMP_TAIL_DEBUG           timing experiments on the in-launch update (wrong results): 1, 2, 3
     long long pipe_split;     // SGPMP_PIPE_SPLIT           first chain's share of the particles in 16ths (0 = default 8)
@@ -171,6 +172,13 @@ struct FusedTailHost {
 bool fused_tail_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                          const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
                          const SgpmpToggles& tg);
+// The whole iteration in ONE launch for small problems without forward kinematics (small_step.inc)
+bool small_step_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, int P, int S,
+                         const SgpmpToggles& tg);
+hipError_t launch_small_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, uint64_t seed,
+                             uint64_t draw, void* means, int P, int mode_offset, int S, void* samples, const void* isw,
+                             void* costs, double* costs64, const FusedTailHost& th, void* isw_next, void* means_copy,
+                             hipStream_t stream, hipEvent_t done);
 // K2 + K3 fused (cost_sweep.hip / fused_step.inc): launches only when the step qualifies (*launched)
 hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                              const ChainDev& h_chain, uint64_t seed, uint64_t draw, const void* means, int P,

@@ -19,182 +19,6 @@
 #include "sgpmp_internal.h"
 #include "update_common.h"
 
-template <typename T> __device__ __forceinline__ T block_reduce(T v, T* scratch, bool is_min) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const T o = __shfl_xor(v, off, 64);
-        v = is_min ? (o < v ? o : v) : (v + o);
-    }
-    __syncthreads();
-    if (lane == 0) scratch[wave] = v;
-    __syncthreads();
-    T r = scratch[0];
-    for (int i = 1; i < nw; ++i) r = is_min ? (scratch[i] < r ? scratch[i] : r) : (r + scratch[i]);
-    __syncthreads();
-    return r;
-}
-
-// VW = elements per thread and load (4 when M % 4 == 0, else 2; M = T * 2n is always even).
-template <typename real, typename cost_t, int VW>
-__global__ void __launch_bounds__(256)
-update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __restrict__ samples,
-              real* __restrict__ means, double temperature, double step_size,
-              real* __restrict__ weights, real* __restrict__ grad, real* __restrict__ means_prev,
-              double* __restrict__ stats, IswNext<real> nx, real* __restrict__ means_copy) {
-    typedef real vec __attribute__((ext_vector_type(VW)));
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    double* w = reinterpret_cast<double*>(lds_raw);                  // [S] weights
-    int* idx = reinterpret_cast<int*>(lds_raw + (size_t)S * 8);      // [S] samples with weight != 0
-    real* mu_lds = reinterpret_cast<real*>(lds_raw + (((size_t)S * 12 + 15) & ~(size_t)15));   // [M] new means (tail)
-    __shared__ double scratch[8];
-    __shared__ int nnz_s;
-    const int p = blockIdx.x;
-    const cost_t* c = costs + (size_t)p * S;
-    // (issued first, consumed last: the four distinct entries of an isotropic prior's one-step precision -- the tail
-    // below would otherwise pay two dependent global loads per element)
-    const bool iso_tail = nx.out && nx.isotropic;
-    const int nd = 2 * nx.n;
-    const double q00 = iso_tail ? nx.Qinv[0] : 0., q01 = iso_tail ? nx.Qinv[nx.n] : 0.;
-    const double q10 = iso_tail ? nx.Qinv[nx.n * nd] : 0., q11 = iso_tail ? nx.Qinv[nx.n * nd + nx.n] : 0.;
-
-    // softmax(-c / temperature) exactly as torch.softmax: exp(z - max z) / sum
-    double zmax = -1.7976931348623157e308, csum = 0., cmin = 1.7976931348623157e308;
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        const double cv = (double)c[s];
-        const double z = -cv / temperature;
-        w[s] = z;
-        zmax = z > zmax ? z : zmax;
-        cmin = cv < cmin ? cv : cmin;
-        csum += cv;
-    }
-    // one combined reduction for (max z, sum c, min c): three block reductions cost nine barriers
-    {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double oz = __shfl_xor(zmax, off, 64), os = __shfl_xor(csum, off, 64), om = __shfl_xor(cmin, off, 64);
-            zmax = oz > zmax ? oz : zmax;
-            csum += os;
-            cmin = om < cmin ? om : cmin;
-        }
-        __shared__ double red3[3 * 4];
-        if (lane == 0) { red3[wave] = zmax; red3[4 + wave] = csum; red3[8 + wave] = cmin; }
-        __syncthreads();
-        zmax = red3[0]; csum = red3[4]; cmin = red3[8];
-        for (int i = 1; i < nw; ++i) {
-            zmax = red3[i] > zmax ? red3[i] : zmax;
-            csum += red3[4 + i];
-            cmin = red3[8 + i] < cmin ? red3[8 + i] : cmin;
-        }
-    }
-    double part = 0.;
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        const double e = exp(w[s] - zmax);
-        w[s] = e;
-        part += e;
-    }
-    double Z;
-    {   // (one barrier: `scratch` is written once in this kernel)
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
-        if (lane == 0) scratch[wave] = part;
-        __syncthreads();
-        Z = scratch[0];
-        for (int i = 1; i < nw; ++i) Z += scratch[i];
-    }
-    if (stats) {
-        const double tot = csum, mn = cmin;
-        if (threadIdx.x == 0) {
-            // 64 shards of 4 doubles: a thousand workgroups adding to one address serialise
-            // at the memory side (~30 us); the consumer sums the shards
-            double* sh = stats + (blockIdx.x & (SGPMP_STAT_SHARDS - 1)) * 4;
-            atomicAdd(&sh[0], tot);
-            atomicAdd(&sh[1], mn);
-            atomicAdd(&sh[2], 1.0);
-        }
-    }
-    const double invZ = 1. / Z;
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        const double ws = w[s] * invZ;
-        w[s] = ws;
-        if (weights) weights[(size_t)p * S + s] = (real)ws;
-    }
-    __syncthreads();
-    // Samples whose weight underflowed to exactly 0 contribute exactly 0 to the sum below, so their
-    // rows need not be read at all (with the reference's hyper-parameters the softmax is one-hot
-    // and this turns a pass over [S, M] into a pass over one row).  Order-preserving compaction.
-    if (threadIdx.x < 64) {
-        int base = 0;
-        for (int s0 = 0; s0 < S; s0 += 64) {
-            const int s = s0 + (int)threadIdx.x;
-            const bool nz = s < S && w[s] != 0.;
-            const unsigned long long mask = __ballot(nz);
-            const int pos = base + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
-            if (nz) idx[pos] = s;
-            base += __popcll(mask);
-        }
-        if (threadIdx.x == 0) nnz_s = base;
-    }
-    __syncthreads();
-    const int nnz = nnz_s;
-
-    const real* X = samples + (size_t)p * S * M;
-    real* mu = means + (size_t)p * M;
-    for (int m = threadIdx.x * VW; m < M; m += blockDim.x * VW) {
-        const vec mu_m = *reinterpret_cast<const vec*>(mu + m);
-        double acc[VW];
-#pragma unroll
-        for (int i = 0; i < VW; ++i) acc[i] = 0.;
-        int k = 0;
-        for (; k + 4 <= nnz; k += 4) {                   // four rows in flight per thread
-            vec v[4];
-            double ws[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = idx[k + u];
-                ws[u] = w[s];
-                v[u] = *reinterpret_cast<const vec*>(X + (size_t)s * M + m);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int i = 0; i < VW; ++i) acc[i] = fma(ws[u], (double)(v[u][i] - mu_m[i]), acc[i]);
-        }
-        for (; k < nnz; ++k) {
-            const int s = idx[k];
-            const double ws = w[s];
-            const vec v = *reinterpret_cast<const vec*>(X + (size_t)s * M + m);
-#pragma unroll
-            for (int i = 0; i < VW; ++i) acc[i] = fma(ws, (double)(v[i] - mu_m[i]), acc[i]);
-        }
-        vec g, mn;
-#pragma unroll
-        for (int i = 0; i < VW; ++i) {
-            g[i] = (real)acc[i];
-            mn[i] = (real)fma(step_size, acc[i], (double)mu_m[i]);
-        }
-        if (grad) *reinterpret_cast<vec*>(grad + (size_t)p * M + m) = g;
-        if (means_prev) *reinterpret_cast<vec*>(means_prev + (size_t)p * M + m) = mu_m;
-        *reinterpret_cast<vec*>(mu + m) = mn;
-        if (means_copy) *reinterpret_cast<vec*>(means_copy + (size_t)p * M + m) = mn;   // (snapshot for the side stream's statistics)
-        if (nx.out) *reinterpret_cast<vec*>(mu_lds + m) = mn;
-    }
-    // The NEXT iteration's importance-sampling weights, from the means just written (K5's arithmetic, same
-    // function): sgpmp_step then starts with the sampler + sweep launch instead of a K5 launch, provided the
-    // caller vouches that nobody touched the means in between (SGPMP_STEP_MEANS_KEPT).
-    if (nx.out) {
-        __syncthreads();                                  // the new means of this particle are in LDS
-        const int d = 2 * nx.n, Tn = M / d;
-        const real* mu_new = mu_lds;
-        for (int e = threadIdx.x; e < (Tn + 1) * d; e += blockDim.x)
-            nx.out[(size_t)p * (Tn + 1) * d + e] =
-                iso_tail ? is_weight_elem_iso<real>(nx.n, Tn, mu_new, q00, q01, q10, q11, nx.ks, nx.kg, nx.dt, temperature, e)
-                         : is_weight_elem<real>(nx.n, Tn, mu_new, nx.Qinv, nx.ks, nx.kg, nx.dt, temperature, nx.isotropic, e);
-    }
-}
-
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int costs_dtype,
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,

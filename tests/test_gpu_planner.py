@@ -572,6 +572,57 @@ def test_fused_step_random_shapes_match_the_two_launch_path():
             b.particle_means.copy_(a.particle_means)
 
 
+# --------------------------------------------------------------------------- small problems: one launch per iteration
+@pytest.mark.parametrize("ta,nppg,G,S,T,n", [
+    (F64, 2, 2, 16, 64, 2),                   # BASELINE config 1
+    (F32, 2, 2, 16, 64, 2),
+    (F32, 3, 4, 24, 128, 2),                  # two 64-waypoint passes per sample in the cost phase
+    (F64, 1, 1, 5, 31, 2),                    # odd S and T, one particle
+    (F32, 5, 1, 7, 48, 3),                    # n = 3
+    (F32, 4, 2, 100, 16, 2),                  # more samples than a workgroup has waves x passes, short trajectories
+])
+def test_small_problem_iteration_in_one_launch_equals_the_separate_launches(golden, ta, nppg, G, S, T, n):
+    """small_step_kernel (csrc/small_step.inc): sampler, cost sweep, update and the next step's importance-sampling
+    weights of a small no-FK problem as ONE launch, a workgroup per particle with its samples in LDS.  Noise, cost terms
+    scan and update are the separate kernels' code on the same data in the same order.  Against the multi-launch step
+    (sampler + generic sweep + update_kernel): the compiler may contract the scan's multiply-adds differently in the two
+    samplers (as it already does between sample_iso_kernel and sample_iso_small_kernel in fp32), so samples and means
+    agree to a few ulp, costs to rounding, with the same arg-min and the same statistics.  (Opt-in: "small_step".)"""
+    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]][:G]
+    c = SC.PLANAR
+    if n == 3:
+        c = dict(SC.PLANAR, n_dof=3, start=[-9., -9., 0.5, 0., 0., 0.])
+        goals = [g[:2] + [0.3 * (i + 1), 0., 0., 0.] for i, g in enumerate(goals)]
+    om = planar_map(golden, ta)
+    a = hip_planar_planner(c, T, goals, nppg, S, om, ta, seed=61)
+    b = hip_planar_planner(c, T, goals, nppg, S, om, ta, seed=61)
+    a._engine.set_option("small_step", 1)
+    b._engine.set_option("no_fused_step", 1)
+    eps = 2.3e-16 if ta is F64 else 1.2e-7
+    sequential = False
+    for it in range(4):
+        ra = a.optimize()
+        rb = b.optimize()
+        assert a._engine.last_cost_kernel() == "small_step_kernel" and a._engine.last_step_launches() == (2 if it == 0 else 1)
+        assert b._engine.last_cost_kernel().startswith("cost_sweep_kernel")
+        sa, sb = a.global_stats(), b.global_stats()
+        scale = float(b.state_samples.abs().max())
+        if sequential and ta is F64:
+            assert torch.equal(a.state_samples, b.state_samples) and torch.equal(a._costs, b._costs), it
+            assert torch.equal(a._weights_buf, b._weights_buf) and torch.equal(a._grad, b._grad), it
+            assert torch.equal(a.particle_means, b.particle_means), it
+            for x, y in zip(ra, rb):
+                assert torch.equal(x, y)
+        assert float((a.state_samples - b.state_samples).abs().max()) <= 8 * eps * scale
+        assert rel_err(a._costs, b._costs) < (1e-9 if ta is F64 else 2e-5)
+        assert torch.equal(a._costs.argmin(1), b._costs.argmin(1)) and torch.equal(a._means_prev, b._means_prev)
+        assert float((a.particle_means - b.particle_means).abs().max()) <= 8 * eps * scale
+        assert abs(sa[0] / sb[0] - 1) < (1e-9 if ta is F64 else 1e-5) and abs(sa[1] / sb[1] - 1) < (1e-9 if ta is F64 else 1e-5)
+        b.particle_means.copy_(a.particle_means)          # (keep both on one trajectory: later iterations stay comparable)
+    a.optimize(opt_iters=5)                               # several iterations per call
+    assert a._engine.last_step_launches() == 1 and torch.isfinite(a.particle_means).all()
+
+
 # --------------------------------------------------------------------------- the update inside the fused launch
 def _one_vs_two_launches(build, iters, obs, soft=None, expect_one=True):
     """The same planner twice: `a` lets the fused launch update the particles itself (csrc/fused_tail.inc, the last
