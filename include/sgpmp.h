@@ -124,8 +124,9 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
 /* Development switches (kernel-variant A/B, tests of the fallback paths).  Every switch has an
  * environment variable SGPMP_<NAME> that is read ONCE, in sgpmp_create; this call changes a switch
  * on a live context.  Names: force_generic_fk, no_flat_program, no_chain_codegen, no_dual_sweep,
- * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, tail_update (0/1) and k3_blocks
- * (count).
+ * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, comm_packet_event,
+ * tail_update, small_step (0/1; the last two: whole-iteration-in-one-launch variants that measured slower),
+ * planar_slabs (0, 2, 4), pipe_split (1..15) and k3_blocks (count).
  * No reference counterpart. */
 int sgpmp_set_option(sgpmp_ctx* ctx, const char* name, long long value);
 /* Name of the cost-sweep kernel the dispatcher chose at the last sgpmp_cost_eval / sgpmp_step
