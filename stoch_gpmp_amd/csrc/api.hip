@@ -357,7 +357,8 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
 // for 4 slabs per trajectory: what the slab-parallel planar launch (fused_planar_slab.inc) needs to carry a slab's true
 // start state through the slab.  Once per factorisation, in fp64 on the host from K1's coefficients (T x 8 doubles).
 static int upload_slab_prefix(sgpmp_ctx* c, PriorDev& p, hipStream_t st) {
-    if (!p.isotropic) return SGPMP_OK;
+    // (only the point-mass launches use the tables: programs without forward kinematics run for n = 2, 3)
+    if (!p.isotropic || (c->dims.n_dof != 2 && c->dims.n_dof != 3)) return SGPMP_OK;
     const int T = c->dims.traj_len;
     std::vector<double> iso((size_t)T * 8);
     HIPCHK(hipMemcpyAsync(iso.data(), p.iso64, sizeof(double) * T * 8, hipMemcpyDeviceToHost, st));
