@@ -968,6 +968,16 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         // A rank whose shard is empty (more ranks than particles) has no kernels to run, but the per-step
         // statistics all-reduce is a collective: it contributes a zeroed slot, or the other ranks' all-reduce
         // never completes.
+        // The collectives of a step, in the order the ranks WITH particles issue them (below: the per-goal mean
+        // statistics behind the update kernel, then the cost statistics) -- a communicator matches collectives by
+        // their order of issue, not by their buffers.
+        if (c->comm && c->ms_buf) {                              // (per-goal mean statistics: all zeros from here)
+            hipStream_t side = comm_side_stream(c->comm);
+            HIPCHK(hipEventRecord(c->ms_ready, (hipStream_t)stream));
+            HIPCHK(hipStreamWaitEvent(side, c->ms_ready, 0));
+            HIPCHK(hipMemsetAsync(c->ms_buf, 0, mode_stats_count(c) * sizeof(double), side));
+            COMMCHK(comm_allreduce_f64(c->comm, c->ms_buf, mode_stats_count(c), side));
+        }
         if (c->comm && stats) {
             hipStream_t st0 = (hipStream_t)stream;
             if (c->pipe.active) { int rcj = pipe_join(c, st0); if (rcj != SGPMP_OK) return rcj; }
@@ -977,13 +987,6 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
             HIPCHK(hipMemsetAsync(slot, 0, sizeof(double) * SGPMP_STAT_SHARDS * 4, st0));
             HIPCHK(hipEventRecord(done, st0));
             COMMCHK(comm_step_end(c->comm, stats, false));
-        }
-        if (c->comm && c->ms_buf) {                              // (and the per-goal mean statistics: all zeros from here)
-            hipStream_t side = comm_side_stream(c->comm);
-            HIPCHK(hipEventRecord(c->ms_ready, (hipStream_t)stream));
-            HIPCHK(hipStreamWaitEvent(side, c->ms_ready, 0));
-            HIPCHK(hipMemsetAsync(c->ms_buf, 0, mode_stats_count(c) * sizeof(double), side));
-            COMMCHK(comm_allreduce_f64(c->comm, c->ms_buf, mode_stats_count(c), side));
         }
         return SGPMP_OK;
     }

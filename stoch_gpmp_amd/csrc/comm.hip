@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -38,9 +39,15 @@ static RcclApi g_rccl = {};
 static const char* load_rccl() {
     if (g_rccl.handle) return nullptr;
     void* h = nullptr;
+    // SGPMP_RCCL_LIB: a library with RCCL's entry points to bind instead (tests/fake_rccl: the shared-memory test double
+    // that lets several ranks share ONE GPU, which real RCCL refuses -- the only way the N > 1 protocol runs on a 1-GPU box)
+    if (const char* over = getenv("SGPMP_RCCL_LIB")) {
+        h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return "SGPMP_RCCL_LIB is set but cannot be loaded";
+    }
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!h) return "librccl.so.1 not found (dlopen)";
 #define SYM(field, name)                                            \

@@ -360,8 +360,10 @@ class StochGPMP:
             return                                       # a shard run stand-alone: no peers to reduce with
         box = [self._engine.comm_unique_id() if dist.get_rank(group) == 0 else None]
         src = dist.get_global_rank(group, 0) if group is not None else 0
+        # (the id travels through whatever backend the group has: device tensors for nccl, host tensors for gloo)
+        on_host = dist.get_backend(group) == 'gloo'
         dist.broadcast_object_list(box, src=src, group=group,
-                                   device=torch.device(self.tensor_args['device']))
+                                   device=torch.device('cpu') if on_host else torch.device(self.tensor_args['device']))
         self._engine.comm_init(box[0], self.world_size, dist.get_rank(group))
         self._comm_attached = True
 

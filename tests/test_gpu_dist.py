@@ -185,6 +185,27 @@ def test_torch_collective_fallback_matches(one_rank_group):
     assert a.global_stats() == b.global_stats()
 
 
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_ranks_sharing_one_gpu_through_the_rccl_test_double(world):
+    """The library's N > 1 protocol on a 1-GPU box: `world` processes on cuda:0, libsgpmp.so bound to
+    tests/fake_rccl/libfakerccl.so (stream-ordered shared-memory all-reduce / all-gather) through SGPMP_RCCL_LIB.  The
+    worker checks shards against the unsharded run bit for bit, all-reduced cost and per-goal mean statistics, ring-slot
+    reuse, two-chain steps, the all-gather and a rank with an empty shard (world = 3: ragged shards too)."""
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
+    if not os.path.exists(fake):
+        subprocess.run(["make", "-C", os.path.dirname(fake)], check=True, capture_output=True)
+    env = dict(os.environ, SGPMP_RCCL_LIB=fake)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "fake_rccl_worker.py")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and f"FAKE_RCCL_OK world={world}" in p.stdout, p.stdout[-2000:] + p.stderr[-6000:]
+    if world == 2:                         # and the double is not blind: ranks that disagree about a collective fail
+        p = subprocess.run(cmd, env=dict(env, FAKE_RCCL_NEGATIVE="1"), capture_output=True, text=True, timeout=900)
+        assert p.returncode != 0 and "different collectives in the same position" in p.stderr, p.stderr[-4000:]
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_two_process_rccl_shards_equal_the_unsharded_run():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
