@@ -390,14 +390,25 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     use_dist = world > 1 or os.environ.get("SGPMP_BENCH_FORCE_DIST") == "1"   # (1-rank RCCL smoke test)
+    # TEST HOOK (tests/test_gpu_dist.py): every rank on cuda:0, gloo process group, libsgpmp.so bound to the
+    # shared-memory test double (SGPMP_RCCL_LIB) -- runs THIS script's N > 1 code on a 1-GPU box.  The line it prints
+    # says so ("shared_gpu_test_double": true) and is not a scaling measurement.
+    shared_gpu = os.environ.get("SGPMP_BENCH_SHARED_GPU") == "1"
+    if shared_gpu and not os.environ.get("SGPMP_RCCL_LIB"):
+        raise SystemExit("bench.py: SGPMP_BENCH_SHARED_GPU needs SGPMP_RCCL_LIB (real RCCL refuses ranks that share a GPU)")
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (before the first HIP call: dmabuf IPC only)
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     if args.workload == "panda":
@@ -434,7 +445,7 @@ def main():
     elapsed_calls = time_loop(torch, pl, obs, args.steps, args.warmup, barrier, one_call=False)
     rank_rates = None
     if use_dist:
-        mine = torch.tensor([elapsed, elapsed_calls], device=dev, dtype=torch.float64)
+        mine = torch.tensor([elapsed, elapsed_calls], device="cpu" if shared_gpu else dev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         rank_rates = [args.steps / float(e[0]) for e in every]           # each rank's own clock, before the max
@@ -511,6 +522,7 @@ def main():
             "rccl": {"ranks": comm_world, "rank": comm_rank, "version": rccl_version,
                      "how": "ncclCommCount / ncclCommUserRank / ncclGetVersion of the communicator sgpmp_step all-reduces on "
                             "(0 ranks: no communicator attached, single GPU)"},
+            "shared_gpu_test_double": shared_gpu,
             "per_rank_iterations_per_s": None if rank_rates is None else
             {"min": min(rank_rates), "max": max(rank_rates), "all": rank_rates},
             "planner_iterations_per_s": args.steps / elapsed,

@@ -228,6 +228,33 @@ def test_bench_launches_its_own_ranks():
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
 
 
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_bench_multi_rank_code_on_one_gpu_through_the_test_double(gpus):
+    """bench.py's N > 1 code (own launcher, barriers, max over ranks, per-rank rates, the communicator's own rank
+    count, the whole-job value) with `gpus` ranks sharing cuda:0 through tests/fake_rccl: exactly what the driver runs
+    as `bench.py --gpus N`, minus RCCL and the other GPUs.  Not a measurement -- the line says so."""
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
+    if not os.path.exists(fake):
+        subprocess.run(["make", "-C", os.path.dirname(fake)], check=True, capture_output=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(SGPMP_BENCH_SHARED_GPU="1", SGPMP_RCCL_LIB=fake)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20",
+                        "--warmup", "5", "--particles", "128"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-6000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == gpus and line["scaling"] == "weak" and line["shared_gpu_test_double"] is True
+    assert line["rccl"]["ranks"] == gpus and line["rccl"]["rank"] == 0 and line["rccl"]["version"] == 1
+    rates = line["per_rank_iterations_per_s"]["all"]
+    assert len(rates) == gpus and min(rates) > 0
+    # whole-job value = shard-iterations/s summed over the ranks at the SLOWEST rank's clock (weak scaling)
+    assert abs(line["value"] - gpus * min(rates)) <= 1e-6 * line["value"]
+    assert line["config"]["particles_total"] == 128 * gpus and line["config"]["particles_per_gpu"] == 128
+    assert line["last_iteration"]["mean_cost_sum"] > 0
+    assert line["cpu_baseline"] is None               # (rank 0 at N = 1 only)
+
+
 def test_bench_single_rank_rccl_smoke():
     """bench.py as a child process with the 1-rank RCCL path forced: the line carries roofline and the
     dispatcher's kernel name (not a Python re-derivation)."""
