@@ -105,6 +105,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
     {"tail_update", &SgpmpToggles::tail_update}, {"small_step", &SgpmpToggles::small_step}, {"comm_packet_event", &SgpmpToggles::comm_packet_event},
+    {"no_planar_seg", &SgpmpToggles::no_planar_seg},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {
@@ -133,7 +134,7 @@ static int alloc_prior(sgpmp_ctx* c, PriorDev& p) {
     HIPCHK(hipMalloc(&p.H, sizeof(double) * T * d * d));
     HIPCHK(hipMalloc(&p.iso64, sizeof(double) * T * 8));
     HIPCHK(hipMalloc(&p.iso32, sizeof(float) * T * 8));
-    HIPCHK(hipMalloc(&p.slabpre, sizeof(float) * 3 * T * 4));
+    HIPCHK(hipMalloc(&p.slabpre, sizeof(float) * 5 * T * 4));
     HIPCHK(hipMalloc(&p.Qinv, sizeof(double) * d * d));
     HIPCHK(hipMalloc(&p.G32, sizeof(float) * T * d * d));
     HIPCHK(hipMalloc(&p.H32, sizeof(float) * T * d * d));
@@ -363,12 +364,13 @@ static int upload_slab_prefix(sgpmp_ctx* c, PriorDev& p, hipStream_t st) {
     std::vector<double> iso((size_t)T * 8);
     HIPCHK(hipMemcpyAsync(iso.data(), p.iso64, sizeof(double) * T * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    std::vector<float> tab((size_t)3 * T * 4, 0.f);
-    for (int wi = 0; wi < 3; ++wi) {                                 // tables: 2 slabs, 4 slabs, the scan's own segments
+    std::vector<float> tab((size_t)5 * T * 4, 0.f);
+    for (int wi = 0; wi < 5; ++wi) {       // tables: 2 slabs, 4 slabs, the scan's own segments, segments of 8, of 16
         const int W = wi == 0 ? 2 : 4;
         if (wi < 2 && T % W) continue;
-        // (segments of the in-chunk scan: 16-waypoint chunks cut into 4 segments for n = 2, 2 for n = 3: fused_planar.inc)
-        const int L = wi < 2 ? T / W : (c->dims.n_dof == 2 ? 4 : 8);
+        // (segments of the in-chunk scan: 16-waypoint chunks cut into 4 segments for n = 2, 2 for n = 3: fused_planar.inc;
+        // segments of 8 / 16 waypoints: one wave each in fused_planar_seg.inc)
+        const int L = wi < 2 ? T / W : wi == 2 ? (c->dims.n_dof == 2 ? 4 : 8) : wi == 3 ? 8 : 16;
         double p00 = 1., p01 = 0., p10 = 0., p11 = 1.;
         for (int t = 0; t < T; ++t) {
             if (t % L == 0) { p00 = 1.; p01 = 0.; p10 = 0.; p11 = 1.; }
@@ -1007,8 +1009,12 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     if (c->pipe.active) {
         // both halves big enough to fill the chip on their own (256 workgroups of 4 items of 8 rows) and fused
         const int P0 = pipe_first_half(c);
+        // (fused_planar_seg_kernel: a workgroup is 16 waves, one per particle and 64 samples -- a half must still
+        // bring a workgroup for every CU, or two half-empty launches take turns: 40.3 k against 44.4 k it/s at config 2)
+        const bool seg = planar_seg_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P, D.particle_offset, S,
+                                         n_spheres, c->tg);
         const bool split = !eps && !c->profiling && !c->tg.no_step_pipeline && !c->ms_buf &&
-                           (long long)(P0 < P - P0 ? P0 : P - P0) * S >= 256 * 4 * 8 &&
+                           (long long)(P0 < P - P0 ? P0 : P - P0) * S >= (seg ? 256 * 64 : 256 * 4 * 8) &&
                            fused_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P0, D.particle_offset,
                                                S, n_spheres, c->tg) &&
                            fused_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P - P0,

@@ -498,6 +498,7 @@ static bool make_flat(const CostProgram& p, FlatProg<real>& f) {
 #include "fused_step.inc"
 #include "fused_planar.inc"
 #include "fused_planar_slab.inc"
+#include "fused_planar_seg.inc"
 #include "small_step.inc"
 
 // Does a step qualify for a fused launch?  1: chain-code program (fused_step.inc), 2: program without forward
@@ -531,6 +532,22 @@ bool fused_step_eligible(int dtype, int n, int T, const PriorDev& prior, const C
                          const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
                          const SgpmpToggles& tg) {
     return fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg) != 0;
+}
+
+// Shape of the lane-per-sample launch (fused_planar_seg.inc): waypoints per wave, 0 when (S, T, n) does not fit.
+// Never a function of the particle count.
+static int planar_seg_len(int n, int T, int S, const SgpmpToggles& tg) {
+    if (tg.no_planar_seg || S % 64 != 0) return 0;
+    const int L = T <= 128 ? 8 : 16;
+    if (T % L != 0 || T / L > 16 || (L == 16 && n != 2)) return 0;
+    return L;
+}
+
+// Does the step run as fused_planar_seg_kernel (1024-thread workgroups, one per particle and 64 samples)?
+bool planar_seg_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
+                     int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg) {
+    return fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg) == 2 &&
+           planar_seg_len(n, T, S, tg) != 0;
 }
 
 // Can the fused launch also do the update (K4 by the last wave of every particle, fused_tail.inc)?  The step must
@@ -675,6 +692,23 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
             if (picked) *picked = W == 4 ? "fused_planar_slab_kernel<4 slabs>" : "fused_planar_slab_kernel<2 slabs>";
             *launched = true;
             return hipGetLastError();
+        }
+        // lane = sample, wave = time segment (fused_planar_seg.inc) where the shape allows; picked from (S, T, n) alone
+        {
+            const int L = planar_seg_len(n, T, S, tg), G = L ? T / L : 0;
+            const long long wgs = batch / 64;
+            if (L && wgs <= (1LL << 20)) {
+                const size_t lds = (size_t)G * 64 * (16 * n + 8) + (size_t)G * 64 * 20 * sizeof(float) + (size_t)G * 16;
+                fs.gpp = S / 64; fs.gpp_shift = log2_exact(fs.gpp);
+                const float* tab = prior.slabpre + (size_t)(L == 8 ? 3 : 4) * T * 4;
+#define SEG_LAUNCH(NN, LL) hipLaunchKernelGGL((fused_planar_seg_kernel<NN, LL>), dim3((unsigned)wgs), dim3(64 * G), (unsigned)lds, stream, a, F, fs, tab)
+                if (n == 2) { if (L == 8) SEG_LAUNCH(2, 8); else SEG_LAUNCH(2, 16); }
+                else SEG_LAUNCH(3, 8);
+#undef SEG_LAUNCH
+                if (picked) *picked = "fused_planar_seg_kernel";
+                *launched = true;
+                return hipGetLastError();
+            }
         }
         if (n == 2) hipLaunchKernelGGL((fused_planar_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);
         else hipLaunchKernelGGL((fused_planar_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, stream, a, F, fs);

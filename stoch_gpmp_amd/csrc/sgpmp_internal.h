@@ -18,7 +18,7 @@ struct PriorDev {
     double* H;         // [T][d][d]
     double* iso64;     // [T][8]  g11 g21 g22 h11 h12 h21 h22 0   (valid when isotropic)
     float* iso32;      // [T][8]
-    float* slabpre;    // [3][T][4]  isotropic priors: prefix products H_t .. H_{start} of the scan's 2 x 2 propagators from the
+    float* slabpre;    // [5][T][4] (tables 3, 4: segments of 8 and of 16 waypoints, fused_planar_seg.inc)  isotropic priors: prefix products H_t .. H_{start} of the scan's 2 x 2 propagators from the
                        //            start of t's time slab (2 slabs, 4 slabs) and of its in-chunk segment
                        //            (fused_planar_slab.inc), built by the host in fp64
     double* Qinv;      // [d][d]   one-step GP precision of this prior
@@ -112,6 +112,7 @@ struct SgpmpToggles {
     int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
     long long planar_slabs;   // SGPMP_PLANAR_SLABS         time slabs of the planar one-launch step: 0 none (fused_planar_kernel, default), 2, 4 (fused_planar_slab.inc, where the shape allows)
+    int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
     int small_step;           // SGPMP_SMALL_STEP           small no-FK problems as ONE launch, a workgroup per particle (small_step.inc); measured slower than the separate launches, hence opt-in
     int tail_update;          // SGPMP_TAIL_UPDATE          the update INSIDE the fused launch (fused_tail.inc) instead of update_kernel as a second launch: one launch per iteration; measured slower at config 3, hence opt-in
     long long tail_debug;     // SGPMP_TAIL_DEBUG           timing experiments on the in-launch update (wrong results): 1, 2, 3
@@ -186,6 +187,8 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                              const void* isw, double* zero_stats, void* costs, double* costs64,
                              hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched,
                              const FusedTailHost* tail = nullptr, hipEvent_t done = nullptr, bool* tail_ran = nullptr);
+bool planar_seg_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
+                     int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg);
 // does the step qualify for the fused launch? (same conditions, no launch)
 bool fused_step_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                          const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,

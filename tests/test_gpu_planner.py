@@ -778,18 +778,61 @@ def test_planar_time_slab_launch_matches_the_sequential_launch(golden, slabs, np
         b.particle_means.copy_(a.particle_means)
 
 
-@pytest.mark.parametrize("kind", ["panda", "panda_two_goals_sdf", "panda_ee_goal", "planar"])
+@pytest.mark.parametrize("nppg,G,S,T,n", [(3, 2, 64, 64, 2), (2, 4, 64, 128, 2), (1, 3, 128, 32, 2), (5, 1, 64, 256, 2),
+                                            (2, 2, 64, 16, 2), (2, 2, 192, 16, 2), (3, 1, 64, 96, 3), (2, 2, 64, 128, 3),
+                                            (2, 2, 32, 64, 2), (2, 1, 64, 144, 2)])
+def test_planar_launch_with_a_lane_per_sample_matches_the_tile_launch(golden, nppg, G, S, T, n):
+    """fused_planar_seg.inc: lane = sample, wave = segment of 8 (16) waypoints, everything indexed by the waypoint in
+    scalar registers, three barriers and a few LDS words per lane -- against fused_planar_kernel (8 samples per wave
+    through an LDS tile; `no_planar_seg`) and, every iteration, against the sampler + generic sweep as two launches: same
+    noise keys, samples to rounding, costs to fp32 rounding, same arg-min, same means after the update.  The last two
+    shapes (S = 32; T = 144 = 18 segments) do not fit and run the tile launch."""
+    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]][:G]
+    c = SC.PLANAR
+    if n == 3:
+        goals = [g[:2] + [1.0] + [0., 0., 0.] for g in goals]
+        c = dict(SC.PLANAR, n_dof=3, start=[-9., -9., 0.5, 0., 0., 0.])
+    om = planar_map(golden, F32)
+    mk = lambda: hip_planar_planner(c, T, goals, nppg, S, om, F32, seed=59)   # noqa: E731
+    a, b, two = mk(), mk(), mk()
+    b._engine.set_option("no_planar_seg", 1)
+    two._engine.set_option("no_fused_step", 1)
+    fits = S % 64 == 0 and T % 8 == 0 and T // (8 if T <= 128 else 16) <= 16
+    for it in range(3):
+        a.optimize()
+        b.optimize()
+        two.optimize()
+        assert a._engine.last_cost_kernel() == ("fused_planar_seg_kernel" if fits else "fused_planar_kernel")
+        assert b._engine.last_cost_kernel() == "fused_planar_kernel"
+        assert two._engine.last_cost_kernel() == "cost_sweep_kernel<f32, no FK>"
+        scale = float(two.state_samples.abs().max())
+        for ref in (b, two):
+            assert float((a.state_samples - ref.state_samples).abs().max()) <= 1e-6 * scale, it
+            assert rel_err(a._costs, ref._costs) < 2e-5
+            assert torch.equal(a._costs.argmin(1), ref._costs.argmin(1))
+            assert float((a.particle_means - ref.particle_means).abs().max()) <= 2e-5 * float(ref.particle_means.abs().max())
+            ref.particle_means.copy_(a.particle_means)
+
+
+@pytest.mark.parametrize("kind", ["panda", "panda_two_goals_sdf", "panda_ee_goal", "planar", "planar_tile"])
 def test_pipelined_optimize_equals_single_steps_bitwise(golden, kind):
     """optimize(opt_iters=K) runs its iterations as two particle-half chains on the context's own streams
     (sgpmp_pipeline_begin / _end); a twin that takes the same iterations one optimize(opt_iters=1) at a time -- one
     chain, every step on the caller's stream -- must end with the same bits in every buffer, through several calls,
     a single-iteration call in between, moved obstacles and an edit of the means between two calls."""
-    if kind == "planar":
+    if kind.startswith("planar"):
         goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
         om = planar_map(golden, F32)
-        mk = lambda **kw: hip_planar_planner(SC.PLANAR, 64, goals, 64, 64, om, F32, seed=41, **kw)   # noqa: E731
+        tile = kind == "planar_tile"
+        # (fused_planar_seg_kernel splits once a half brings a 16-wave workgroup per CU: 2 x 256 particles of 64 samples;
+        # fused_planar_kernel, 8 samples per wave, from 2 x 128)
+
+        def mk(**kw):
+            pl = hip_planar_planner(SC.PLANAR, 64, goals, 64 if tile else 128, 64, om, F32, seed=41, **kw)
+            pl._engine.set_option("no_planar_seg", 1 if tile else 0)
+            return pl
         obs1 = obs2 = {}
-        name = "fused_planar"
+        name = "fused_planar_kernel" if tile else "fused_planar_seg_kernel"
     else:
         c, n = SC.PANDA, 7
         two = kind == "panda_two_goals_sdf"
