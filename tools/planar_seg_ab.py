@@ -11,9 +11,10 @@ goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.
 om = synthetic_obstacle_map(seed=0, tensor_args=ta)
 P, S, T = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (64, 64, 128)))
 pls = {}
-for name in ("tile", "seg"):
+for name in ("tile", "seg", "seg+upd"):
     pl = W.hip_planar_planner(W.PLANAR, T, goals, P, S, om, ta, seed=0)
     pl._engine.set_option("no_planar_seg", 1 if name == "tile" else 0)
+    pl._engine.set_option("planar_seg_update", 1 if name == "seg+upd" else 0)
     for _ in range(3):
         pl.optimize(opt_iters=100)
     pls[name] = pl
@@ -36,5 +37,5 @@ for rnd in range(5):
 print(f"planar {4 * P} particles x {S} samples x {T} waypoints")
 for name, v in res.items():
     best = max(v, key=lambda r: r[1])
-    print(f"{name:5s} {pls[name]._engine.last_cost_kernel():26s} single calls {max(r[0] for r in v):8.0f} it/s  "
+    print(f"{name:8s} {pls[name]._engine.last_cost_kernel():26s} single calls {max(r[0] for r in v):8.0f} it/s  "
           f"in one call {max(r[1] for r in v):8.0f} it/s  kernels (us) {best[2]}")
