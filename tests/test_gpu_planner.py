@@ -836,24 +836,25 @@ def test_update_inside_the_lane_per_sample_launch_equals_the_update_kernel_bitwi
     mk = lambda: hip_planar_planner(c, T, goals, nppg, 64, om, F32, seed=67)   # noqa: E731
     a, b = mk(), mk()
     a._engine.set_option("planar_seg_update", 1)
-    if temp == "soft":                                   # a sixth of the typical cost spread over a particle's samples
+    if temp == "soft":                                   # the typical distance of a particle's second-best sample, times 4
         probe = mk()
         probe.optimize()
-        cp = probe._costs.double()
-        a.temperature = b.temperature = float((cp.max(1)[0] - cp.min(1)[0]).median()) / 6.0
+        cp = probe._costs.double().sort(1)[0]
+        a.temperature = b.temperature = 4.0 * float((cp[:, 1] - cp[:, 0]).median())
+    soft_seen = 0
     for it in range(4):
         a.optimize()
         b.optimize()
         assert a._engine.last_cost_kernel() == "fused_planar_seg_kernel" == b._engine.last_cost_kernel()
         k5 = 1 if it == 0 else 0                         # (the first iteration prepares its importance-sampling weights itself)
         assert a._engine.last_step_launches() == 1 + k5 and b._engine.last_step_launches() == 2 + k5
-        if temp == "soft":
-            assert int((a._weights_buf != 0).sum(1).max()) >= 3
+        soft_seen = max(soft_seen, int((a._weights_buf != 0).sum(1).max()))
         for x, y in ((a.state_samples, b.state_samples), (a._costs, b._costs), (a._weights_buf, b._weights_buf),
                      (a._grad, b._grad), (a._means_prev, b._means_prev), (a.particle_means, b.particle_means)):
             assert torch.equal(x, y), it
         sa, sb = a.global_stats(), b.global_stats()
         assert sa == sb, (sa, sb)
+    assert temp != "soft" or soft_seen >= 3, soft_seen  # (the case is only a test if several samples carried weight)
     a.optimize(opt_iters=5)                              # (one call: still one launch per iteration)
     for _ in range(5):
         b.optimize()

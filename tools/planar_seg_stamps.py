@@ -19,7 +19,7 @@ c = pl._costs.reshape(-1, 8, 8).double().cpu()          # [workgroup][recorded w
 start = c[:, :, 0]
 k0 = start.min()
 rel = (start - k0) % (1 << 23)
-names = ["phase 1 (noise + scan)", "barrier 1", "phase 2 arithmetic", "gathers + stores issued", "barrier 2", "phase 3 (costs)",
+names = ["phase 1 (noise + scan)", "barrier 1", "phase 2 arithmetic", "gathers issued", "barrier 2", "stores + costs",
          "barrier 3"]
 dur = c[:, :, 1:].clone()
 dur[:, :, 1:] -= c[:, :, 1:-1]
