@@ -836,11 +836,11 @@ def test_update_inside_the_lane_per_sample_launch_equals_the_update_kernel_bitwi
     mk = lambda: hip_planar_planner(c, T, goals, nppg, 64, om, F32, seed=67)   # noqa: E731
     a, b = mk(), mk()
     a._engine.set_option("planar_seg_update", 1)
-    if temp == "soft":                                   # the typical distance of a particle's second-best sample, times 4
+    if temp == "soft":                                   # the typical distance of a particle's eighth-best sample
         probe = mk()
         probe.optimize()
         cp = probe._costs.double().sort(1)[0]
-        a.temperature = b.temperature = 4.0 * float((cp[:, 1] - cp[:, 0]).median())
+        a.temperature = b.temperature = float((cp[:, 7] - cp[:, 0]).median())
     soft_seen = 0
     for it in range(4):
         a.optimize()
@@ -854,7 +854,7 @@ def test_update_inside_the_lane_per_sample_launch_equals_the_update_kernel_bitwi
             assert torch.equal(x, y), it
         sa, sb = a.global_stats(), b.global_stats()
         assert sa == sb, (sa, sb)
-    assert temp != "soft" or soft_seen >= 3, soft_seen  # (the case is only a test if several samples carried weight)
+    assert temp != "soft" or soft_seen >= 2, soft_seen  # (the case is only a test if several samples carried weight)
     a.optimize(opt_iters=5)                              # (one call: still one launch per iteration)
     for _ in range(5):
         b.optimize()
