@@ -698,29 +698,14 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
             const int L = planar_seg_len(n, T, S, tg), G = L ? T / L : 0;
             const long long wgs = batch / 64;
             if (L && wgs <= (1LL << 20)) {
-                size_t lds = (size_t)G * 64 * (16 * n + 8) + (size_t)G * 64 * 20 * sizeof(float) + (size_t)G * 16;
+                const size_t lds = (size_t)G * 64 * (16 * n + 8) + (size_t)G * 64 * 20 * sizeof(float) + (size_t)G * 16;
                 fs.gpp = S / 64; fs.gpp_shift = log2_exact(fs.gpp);
-                // the update inside the launch when a particle's samples are one workgroup's (S == 64): seg_update
-                std::memset(&fs.tail, 0, sizeof(fs.tail));
-                const bool upd = tail && S == 64 && tg.planar_seg_update && prior.isotropic;
-                if (upd) {
-                    TailArgs& t = fs.tail;
-                    t.arrive = nullptr; t.done = tail->done; t.acc = tail->acc; t.stats_out = tail->stats_out;
-                    t.means = (float*)const_cast<void*>(means); t.weights = (float*)tail->weights; t.grad = (float*)tail->grad;
-                    t.means_prev = (float*)tail->means_prev; t.isw_next = (float*)const_cast<void*>(isw);
-                    t.Qinv = prior.Qinv; t.ks = prior.ks; t.kg = prior.kg; t.dt = prior.dt;
-                    t.temperature = tail->temperature; t.step_size = tail->step_size; t.isotropic = 1; t.P = P;
-                    fs.zero_stats = nullptr;                      // (the launch's last particle writes the statistics)
-                    lds += (size_t)T * 2 * n * sizeof(float);
-                }
                 const float* tab = prior.slabpre + (size_t)(L == 8 ? 3 : 4) * T * 4;
 #define SEG_LAUNCH(NN, LL) hipLaunchKernelGGL((fused_planar_seg_kernel<NN, LL>), dim3((unsigned)wgs), dim3(64 * G), (unsigned)lds, stream, a, F, fs, tab)
                 if (n == 2) { if (L == 8) SEG_LAUNCH(2, 8); else SEG_LAUNCH(2, 16); }
                 else SEG_LAUNCH(3, 8);
 #undef SEG_LAUNCH
                 if (picked) *picked = "fused_planar_seg_kernel";
-                if (tail_ran) *tail_ran = upd;
-                if (upd && done) { hipError_t e = hipEventRecord(done, stream); if (e != hipSuccess) return e; }
                 *launched = true;
                 return hipGetLastError();
             }

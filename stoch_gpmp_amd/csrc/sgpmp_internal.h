@@ -113,7 +113,6 @@ struct SgpmpToggles {
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
     long long planar_slabs;   // SGPMP_PLANAR_SLABS         time slabs of the planar one-launch step: 0 none (fused_planar_kernel, default), 2, 4 (fused_planar_slab.inc, where the shape allows)
     int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
-    int planar_seg_update;    // SGPMP_PLANAR_SEG_UPDATE    the update INSIDE fused_planar_seg_kernel where a particle has 64 samples (seg_update: one launch per iteration, bit-identical); measured level-to-slower at config 2 (the update queues behind the launch's own sample stores), hence opt-in
     int small_step;           // SGPMP_SMALL_STEP           small no-FK problems as ONE launch, a workgroup per particle (small_step.inc); measured slower than the separate launches, hence opt-in
     int tail_update;          // SGPMP_TAIL_UPDATE          the update INSIDE the fused launch (fused_tail.inc) instead of update_kernel as a second launch: one launch per iteration; measured slower at config 3, hence opt-in
     long long tail_debug;     // SGPMP_TAIL_DEBUG           timing experiments on the in-launch update (wrong results): 1, 2, 3

@@ -814,53 +814,6 @@ def test_planar_launch_with_a_lane_per_sample_matches_the_tile_launch(golden, np
             ref.particle_means.copy_(a.particle_means)
 
 
-@pytest.mark.parametrize("nppg,G,T,n,temp", [(3, 2, 64, 2, None), (64, 4, 128, 2, None), (2, 1, 256, 2, None), (3, 1, 96, 3, None),
-                                               (5, 2, 32, 2, "soft"), (2, 2, 128, 3, "soft"), (1, 1, 16, 2, None)])
-def test_update_inside_the_lane_per_sample_launch_equals_the_update_kernel_bitwise(golden, nppg, G, T, n, temp):
-    """With 64 samples per particle a workgroup of fused_planar_seg_kernel holds ALL samples of its particle and runs the
-    update itself (seg_update: update_particle's arithmetic in the same order) -- ONE launch per iteration.  Against a
-    twin whose update is update_kernel as a second launch (the default; `planar_seg_update` opts in): samples, costs, weights, gradient,
-    previous means, new means, statistics and -- through the following iterations -- the prepared importance-sampling
-    weights, bit for bit; one-hot softmax (the reference's temperature) and a soft one (many samples with weight)."""
-    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]][:G]
-    c = SC.PLANAR
-    if n == 3:
-        goals = [g[:2] + [1.0] + [0., 0., 0.] for g in goals]
-        c = dict(SC.PLANAR, n_dof=3, start=[-9., -9., 0.5, 0., 0., 0.])
-    om = planar_map(golden, F32)
-    if temp == "soft":
-        # (the importance-sampling term scales WITH the temperature and its spread over the samples is ~ |mu_0| / sigma_start:
-        # start and goals at the origin keep it small, so that the weights follow the other costs)
-        c = dict(c, start=[0.] * (2 * n))
-        goals = [[0.3 * (-1) ** i, 0.2 + 0.1 * i] + [0.] * (2 * n - 2) for i in range(G)]
-    mk = lambda: hip_planar_planner(c, T, goals, nppg, 64, om, F32, seed=67)   # noqa: E731
-    a, b = mk(), mk()
-    a._engine.set_option("planar_seg_update", 1)
-    if temp == "soft":                                   # the typical distance of a particle's eighth-best sample
-        probe = mk()
-        probe.optimize()
-        cp = probe._costs.double().sort(1)[0]
-        a.temperature = b.temperature = float((cp[:, 7] - cp[:, 0]).median())
-    soft_seen = 0
-    for it in range(4):
-        a.optimize()
-        b.optimize()
-        assert a._engine.last_cost_kernel() == "fused_planar_seg_kernel" == b._engine.last_cost_kernel()
-        k5 = 1 if it == 0 else 0                         # (the first iteration prepares its importance-sampling weights itself)
-        assert a._engine.last_step_launches() == 1 + k5 and b._engine.last_step_launches() == 2 + k5
-        soft_seen = max(soft_seen, int((a._weights_buf != 0).sum(1).max()))
-        for x, y in ((a.state_samples, b.state_samples), (a._costs, b._costs), (a._weights_buf, b._weights_buf),
-                     (a._grad, b._grad), (a._means_prev, b._means_prev), (a.particle_means, b.particle_means)):
-            assert torch.equal(x, y), it
-        sa, sb = a.global_stats(), b.global_stats()
-        assert sa == sb, (sa, sb)
-    assert temp != "soft" or soft_seen >= 2, soft_seen  # (the case is only a test if several samples carried weight)
-    a.optimize(opt_iters=5)                              # (one call: still one launch per iteration)
-    for _ in range(5):
-        b.optimize()
-    assert torch.equal(a.particle_means, b.particle_means) and torch.equal(a._costs, b._costs)
-
-
 @pytest.mark.parametrize("kind", ["panda", "panda_two_goals_sdf", "panda_ee_goal", "planar", "planar_tile"])
 def test_pipelined_optimize_equals_single_steps_bitwise(golden, kind):
     """optimize(opt_iters=K) runs its iterations as two particle-half chains on the context's own streams

@@ -11,10 +11,9 @@ goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.
 om = synthetic_obstacle_map(seed=0, tensor_args=ta)
 P, S, T = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (64, 64, 128)))
 pls = {}
-for name in ("tile", "seg", "seg+upd"):
+for name in ("tile", "seg"):
     pl = W.hip_planar_planner(W.PLANAR, T, goals, P, S, om, ta, seed=0)
     pl._engine.set_option("no_planar_seg", 1 if name == "tile" else 0)
-    pl._engine.set_option("planar_seg_update", 1 if name == "seg+upd" else 0)
     for _ in range(3):
         pl.optimize(opt_iters=100)
     pls[name] = pl
