@@ -125,6 +125,7 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * environment variable SGPMP_<NAME> that is read ONCE, in sgpmp_create; this call changes a switch
  * on a live context.  Names: force_generic_fk, no_flat_program, no_chain_codegen, no_dual_sweep,
  * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, comm_packet_event,
+ * no_planar_seg (planar one-launch step through the LDS tile, fused_planar_kernel, even where the lane-per-sample launch applies),
  * tail_update, small_step (0/1; the last two: whole-iteration-in-one-launch variants that measured slower),
  * planar_slabs (0, 2, 4), pipe_split (1..15) and k3_blocks (count).
  * No reference counterpart. */
