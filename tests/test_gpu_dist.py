@@ -185,7 +185,7 @@ def test_torch_collective_fallback_matches(one_rank_group):
     assert a.global_stats() == b.global_stats()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_ranks_sharing_one_gpu_through_the_rccl_test_double(world):
     """The library's N > 1 protocol on a 1-GPU box: `world` processes on cuda:0, libsgpmp.so bound to
     tests/fake_rccl/libfakerccl.so (stream-ordered shared-memory all-reduce / all-gather) through SGPMP_RCCL_LIB.  The
@@ -228,7 +228,7 @@ def test_bench_launches_its_own_ranks():
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
 
 
-@pytest.mark.parametrize("gpus", [2, 4])
+@pytest.mark.parametrize("gpus", [2, 4, 8])
 def test_bench_multi_rank_code_on_one_gpu_through_the_test_double(gpus):
     """bench.py's N > 1 code (own launcher, barriers, max over ranks, per-rank rates, the communicator's own rank
     count, the whole-job value) with `gpus` ranks sharing cuda:0 through tests/fake_rccl: exactly what the driver runs
