@@ -451,7 +451,7 @@ def test_config5_share_particles_match_the_banded_oracle():
 
 
 def test_config2_full_size_particles_match_the_dense_oracle(golden):
-    """BASELINE configs[1]: 2-D point mass, 4 goals x 64 particles, 64 samples, T = 128, fp32, fused_planar_kernel.
+    """BASELINE configs[1]: 2-D point mass, 4 goals x 64 particles, 64 samples, T = 128, fp32, fused_planar_seg_kernel.
     Two particles of every goal against the dense fp64 oracle, three iterations."""
     from oracle.native_noise import native_eps
     z = golden("g2_planar_e2e.npz")
@@ -468,7 +468,7 @@ def test_config2_full_size_particles_match_the_dense_oracle(golden):
         eps = torch.from_numpy(native_eps(seed, draw, gidx, S, T, n, "float32")).double()
         costs, _ = ora.step(eps=eps)
         return costs, ora.state_samples.clone(), ora.particle_means.clone()
-    _check_subset("config 2: planar 256 x 64 x 128 fp32 (fused_planar_kernel)", pl, sub, step, 3, {}, "fused_planar")
+    _check_subset("config 2: planar 256 x 64 x 128 fp32 (fused_planar_seg_kernel)", pl, sub, step, 3, {}, "fused_planar_seg")
 
 
 # --------------------------------------------------------------------------- API surface
