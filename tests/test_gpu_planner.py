@@ -1068,6 +1068,36 @@ def _full_panda(P, S, T, ta, **kw):
     return hip_panda_planner(SC.PANDA, T, P, S, ta, seed=0, **kw)
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_config2_shards_equal_unsharded_bitwise(golden, world):
+    """BASELINE config 2 (planar, 4 goals x 64 particles x 64 samples x 128 waypoints, fp32) through the lane-per-sample
+    launch: shards addressed by global particle index -- even (2, 8) and ragged with boundaries inside a goal (3) --
+    reproduce the unsharded run bit for bit, single calls and a multi-iteration call; the kernel choice is a function
+    of (S, T, n) alone, so a shard launches what the whole problem launches."""
+    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
+    om = planar_map(golden, F32)
+    mk = lambda **kw: hip_planar_planner(SC.PLANAR, 128, goals, 64, 64, om, F32, seed=3, **kw)   # noqa: E731
+    full = mk()
+    ref0 = full.particle_means.clone()
+    for _ in range(2):
+        full.optimize()
+    full.optimize(opt_iters=3)
+    assert full._engine.last_cost_kernel() == "fused_planar_seg_kernel"
+    shards = []
+    for r in range(world):
+        h = mk(rank=r, world_size=world)
+        assert torch.equal(h.particle_means, ref0[h.p0:h.p1])
+        for _ in range(2):
+            h.optimize()
+        h.optimize(opt_iters=3)
+        assert h._engine.last_cost_kernel() == "fused_planar_seg_kernel"
+        shards.append(h)
+    assert sum(h.num_particles_local for h in shards) == 256
+    assert torch.equal(torch.cat([h.particle_means for h in shards]), full.particle_means)
+    assert torch.equal(torch.cat([h._costs for h in shards]), full._costs)
+    assert torch.equal(torch.cat([h.state_samples for h in shards]), full.state_samples)
+
+
 def test_full_size_sharded_equals_unsharded_bitwise():
     """BASELINE config 3 shape (Panda, 1024 x 128 x 64, fp32): two half shards addressed by global
     particle index reproduce the single-GPU run bit for bit (means, costs) -- the property that
