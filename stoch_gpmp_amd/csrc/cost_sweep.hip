@@ -720,12 +720,12 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
     // (`done`, multi-GPU statistics: signalled by this kernel's own dispatch packet -- hipExtLaunchKernelGGL stop
     // event -- instead of a separate barrier packet behind it)
-    if (ft == SGPMP_FIELD_RBF)
-        hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_RBF>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs);
-    else if (ft == SGPMP_FIELD_SDF)
-        hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_SDF>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs);
-    else
-        hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_OCCUPANCY>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs);
+#define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, TAIL_>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
+    const bool with_tail = fs.tail.arrive != nullptr;
+    if (ft == SGPMP_FIELD_RBF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_RBF, true); else FUSED_LAUNCH(SGPMP_FIELD_RBF, false); }
+    else if (ft == SGPMP_FIELD_SDF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_SDF, true); else FUSED_LAUNCH(SGPMP_FIELD_SDF, false); }
+    else { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, true); else FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, false); }
+#undef FUSED_LAUNCH
     if (picked) *picked = "fused_step_kernel";
     if (tail_ran) *tail_ran = fs.tail.arrive != nullptr;
     *launched = true;
