@@ -82,6 +82,34 @@ def test_prior_blocks_and_factor_match_oracle(n, T, dt, ss, sg, sgoal):
     close(y_scan, y_ref, 1e-7, atol=1e-9 * float(y_ref.abs().max()))
 
 
+@pytest.mark.parametrize("n,T,dt,ss,sg,sgoal", PRIOR_CASES)
+def test_isotropic_prior_factor_equals_the_general_factorisation(n, T, dt, ss, sg, sgoal, monkeypatch):
+    """prior_factor_iso_kernel (a scalar sigma_gp: the reverse block-Cholesky as a recursion on 2 x 2 scalars, one lane)
+    against prior_factor_kernel (general d x d blocks on the fp64 matrix cores; SGPMP_K1_GENERAL, and what an explicit
+    Q_c^-1 = I / sigma_gp^2 runs): precision blocks, factor blocks and scan tables to rounding."""
+    from stoch_gpmp_amd import _lib as L
+    a, b, c = engine(n, T, 1, 1), engine(n, T, 1, 1), engine(n, T, 1, 1)
+    a.set_prior(L.PRIOR_SAMPLE, dt, ss, sg, sgoal)
+    monkeypatch.setenv("SGPMP_K1_GENERAL", "1")
+    b.set_prior(L.PRIOR_SAMPLE, dt, ss, sg, sgoal)
+    monkeypatch.delenv("SGPMP_K1_GENERAL")
+    c.set_prior(L.PRIOR_SAMPLE, dt, ss, None, sgoal, Q_c_inv=torch.eye(n, dtype=torch.float64) / sg ** 2)
+    for ref in (b, c):
+        # (precision blocks: closed forms, 1e-13; factor blocks: T dependent steps whose rounding compounds -- two valid
+        # fp64 evaluation orders of the same recursion agree to 1e-9 here, 3e-12 observed)
+        for x, y, tol in zip(a.get_prior(L.PRIOR_SAMPLE), ref.get_prior(L.PRIOR_SAMPLE), (1e-13, 1e-9, 1e-9)):
+            scale = float(y.abs().max())
+            assert float((x - y).abs().max()) <= tol * scale, float((x - y).abs().max()) / scale
+
+
+def test_isotropic_prior_not_positive_definite_raises_value_error():
+    """The 2 x 2 recursion reports a non-positive pivot like the general factorisation does (here: a NaN sigma)."""
+    from stoch_gpmp_amd import _lib as L
+    eng = engine(2, 8, 1, 1)
+    with pytest.raises(ValueError):
+        eng.set_prior(L.PRIOR_SAMPLE, 0.1, 1.0, float("nan"), 1.0)
+
+
 def test_prior_not_positive_definite_raises_value_error():
     from stoch_gpmp_amd import _lib as L
     eng = engine(2, 8, 1, 1)
