@@ -456,11 +456,44 @@ def gen_field_surface():
     np.savez_compressed(os.path.join(OUT, "g8_field_surface.npz"), **out)
 
 
+def gen_panda_urdf():
+    """The kinematic chain of the reference's OWN robot description, assets/franka_description/robots/
+    panda_arm_no_gripper.urdf (a data file of the reference; what examples/panda_environment.py:47 hands to torch_robotics):
+    every joint from panda_link0 to ee_link in chain order -- type, origin xyz / rpy, axis, limits -- parsed, not typed.
+    The forward-kinematics CODE the reference calls lives in un-vendored torch_robotics; its INPUT data are pinned here."""
+    import xml.etree.ElementTree as ET
+    root = ET.parse(os.path.join("/root/reference", "assets", "franka_description", "robots", "panda_arm_no_gripper.urdf")).getroot()
+    by_parent = {}
+    for j in root.findall("joint"):
+        by_parent.setdefault(j.find("parent").get("link"), []).append(j)
+    names, kinds, xyz, rpy, axis, lower, upper, links = [], [], [], [], [], [], [], ["panda_link0"]
+    link = "panda_link0"
+    while link != "ee_link":
+        cands = by_parent[link]
+        j = cands[0] if len(cands) == 1 else [c for c in cands if c.find("child").get("link") in
+                                                ("panda_hand", "ee_link") or c.find("child").get("link").startswith("panda_link")][0]
+        o = j.find("origin")
+        names.append(j.get("name")); kinds.append(j.get("type"))
+        xyz.append([float(v) for v in (o.get("xyz") if o is not None and o.get("xyz") else "0 0 0").split()])
+        rpy.append([float(v) for v in (o.get("rpy") if o is not None and o.get("rpy") else "0 0 0").split()])
+        ax = j.find("axis")
+        axis.append([float(v) for v in ax.get("xyz").split()] if ax is not None else [0., 0., 0.])
+        lim = j.find("limit")
+        lower.append(float(lim.get("lower")) if lim is not None and lim.get("lower") else np.nan)
+        upper.append(float(lim.get("upper")) if lim is not None and lim.get("upper") else np.nan)
+        link = j.find("child").get("link")
+        links.append(link)
+    np.savez(os.path.join(OUT, "g9_panda_urdf_chain.npz"), joint_names=np.array(names), joint_types=np.array(kinds),
+             xyz=np.array(xyz), rpy=np.array(rpy), axis=np.array(axis), lower=np.array(lower), upper=np.array(upper),
+             link_names=np.array(links))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
     gens = {"g1": gen_prior, "g2": gen_planar_e2e, "g3": gen_cost_terms, "g4": gen_panda_fields,
-            "g5": gen_update_and_is, "g6": gen_scene_tooling, "g7": gen_gpmp, "g8": gen_field_surface}
+            "g5": gen_update_and_is, "g6": gen_scene_tooling, "g7": gen_gpmp, "g8": gen_field_surface,
+            "g9": gen_panda_urdf}
     for key in (sys.argv[1:] or sorted(gens)):          # `python oracle/gen_golden.py g6` regenerates one
         gens[key]()
     for f in sorted(os.listdir(OUT)):
