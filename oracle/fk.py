@@ -14,7 +14,8 @@ import math
 
 import torch
 
-# (name, type, rpy, xyz) in chain order; constants typed from the URDF lines cited above.
+# (name, type, rpy, xyz) in chain order; constants typed from the URDF lines cited above and held to the URDF itself
+# by tests/test_oracle_golden.py::test_panda_chain_tables_equal_the_reference_urdf (fixture g9: the file, parsed).
 PANDA_CHAIN = [
     ("panda_joint1", "revolute", (0.0, 0.0, 0.0), (0.0, 0.0, 0.333)),
     ("panda_joint2", "revolute", (-1.57079632679, 0.0, 0.0), (0.0, 0.0, 0.0)),
