@@ -29,9 +29,10 @@
 extern "C" {
 #endif
 
-/* 2: sgpmp_step gained `flags`, sgpmp_set_priors / pipeline_* / comm_* appeared (round 2); 3: round 3 (see git log).
+/* 2: sgpmp_step gained `flags`, sgpmp_set_priors / pipeline_* / comm_* appeared (round 2); 3: round 3 (see git log);
+ * 4: sgpmp_comm_library, sgpmp_set_fk_codegen / sgpmp_fk_codegen_info, sgpmp_step's dense-weight partials (round 4).
  * The Python binding refuses any other value at load time. */
-#define SGPMP_ABI_VERSION 3
+#define SGPMP_ABI_VERSION 4
 
 enum { SGPMP_F32 = 0, SGPMP_F64 = 1 };
 enum { SGPMP_PRIOR_INIT = 0, SGPMP_PRIOR_SAMPLE = 1 };
@@ -126,8 +127,9 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * on a live context.  Names: force_generic_fk, no_flat_program, no_chain_codegen, no_dual_sweep,
  * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, comm_packet_event,
  * no_planar_seg (planar one-launch step through the LDS tile, fused_planar_kernel, even where the lane-per-sample launch applies),
- * tail_update, small_step (0/1; the last two: whole-iteration-in-one-launch variants that measured slower),
- * planar_slabs (0, 2, 4), pipe_split (1..15) and k3_blocks (count).
+ * pipe_split (1..15) and k3_blocks (count); and, ONLY in a library built with `make EXPERIMENTS=1` (launches that
+ * measured slower and are kept for the record; the default library answers SGPMP_EINVAL "unknown option"):
+ * tail_update, small_step (0/1: whole-iteration-in-one-launch variants), planar_slabs (0, 2, 4).
  * No reference counterpart. */
 int sgpmp_set_option(sgpmp_ctx* ctx, const char* name, long long value);
 /* Name of the cost-sweep kernel the dispatcher chose at the last sgpmp_cost_eval / sgpmp_step
@@ -273,6 +275,11 @@ int sgpmp_comm_destroy(sgpmp_ctx* ctx);
  * multi-GPU bench line can prove that RCCL saw N ranks: *world = 0 when no communicator is attached.
  * rccl_version: NCCL_VERSION_CODE of the loaded librccl (e.g. 22205), 0 if unavailable.  Any pointer may be NULL. */
 int sgpmp_comm_info(sgpmp_ctx* ctx, int* world, int* rank, int* rccl_version);
+/* Name of the collective library this process bound at its first sgpmp_comm_unique_id / sgpmp_comm_init ("" before):
+ * "librccl.so.1" (or one of its fallback names) in the product library, always.  *test_hooks (may be NULL) = 1 only in
+ * tests/fake_rccl/libsgpmp_testhooks.so, the build of comm.hip that honours SGPMP_RCCL_LIB (a stand-in that lets several
+ * ranks share one GPU in the tests); the product library never reads that variable.  Static string. */
+const char* sgpmp_comm_library(int* test_hooks);
 /* Sum stats (DEVICE double[SGPMP_STAT_SHARDS][4], produced on `stream`) over all ranks, in place, on
  * the context's side stream: returns at once and never makes `stream` wait. (planner.py:668-672's
  * statistic over all particles of all GPUs.) */
@@ -284,7 +291,8 @@ int sgpmp_stats_wait(sgpmp_ctx* ctx, double* stats, void* stream);
  * distribution's modes (a mode = the particles of one goal, p = g * nppg + k, planner.py:215); what a covariance
  * adaptation through MultiMPPrior.set_Sigma_invs (mp_priors_multi.py:125-128) or a mode summary consumes.
  * out DEVICE double[G][T*d + 1][2]:  [g][m] = (sum, sum of squares) of mu_p[m] over THIS context's particles of goal g,
- * [g][T*d] = (their number, 0).  sgpmp_mode_stats zeroes `out` and accumulates on `stream`.
+ * [g][T*d] = (their number, 0).  sgpmp_mode_stats zeroes `out` and accumulates on `stream` (no atomics: bitwise
+ * reproducible run to run for a given sharding; across shardings the additions are ordered differently -- equal to rounding).
  * sgpmp_allreduce_f64: sum any buffer of doubles over all ranks, in place, on the context's side stream (like
  * sgpmp_allreduce_stats; honour sgpmp_stats_wait(buf) before reading).
  * sgpmp_set_step_mode_stats(buf): from now on EVERY sgpmp_step produces them by itself, once per iteration: its update

@@ -19,7 +19,7 @@ MAX_TERMS, MAX_JOINTS, MAX_DOF, MAX_INTERP = 8, 16, 8, 8
 STAT_SHARDS = 64
 OK, EINVAL, ENOTPD, EHIP, ESTATE = 0, -1, -2, -3, -4
 STEP_MEANS_KEPT = 1
-ABI_VERSION = 3                      # include/sgpmp.h SGPMP_ABI_VERSION
+ABI_VERSION = 4                      # include/sgpmp.h SGPMP_ABI_VERSION
 
 
 class Dims(C.Structure):
@@ -57,6 +57,7 @@ SIGNATURES = {
     "sgpmp_comm_init": (_I, [_P, C.c_char_p, _I, _I]),
     "sgpmp_comm_destroy": (_I, [_P]),
     "sgpmp_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "sgpmp_comm_library": (C.c_char_p, [C.POINTER(_I)]),
     "sgpmp_allreduce_stats": (_I, [_P, _P, _P]),
     "sgpmp_stats_wait": (_I, [_P, _P, _P]),
     "sgpmp_allgather_means": (_I, [_P, _P, _P, _P]),

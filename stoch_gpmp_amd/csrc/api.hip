@@ -120,6 +120,9 @@ static void toggles_from_env(SgpmpToggles& tg) {
     if (const char* e = getenv("SGPMP_PIPE_SPLIT")) tg.pipe_split = atoll(e);
     if (const char* e = getenv("SGPMP_TAIL_DEBUG")) tg.tail_debug = atoll(e);
     if (const char* e = getenv("SGPMP_PLANAR_SLABS")) tg.planar_slabs = atoll(e);
+#if !SGPMP_EXPERIMENTS
+    tg.planar_slabs = 0; tg.tail_update = 0; tg.small_step = 0;
+#endif
 }
 
 extern "C" int sgpmp_abi_version(void) { return SGPMP_ABI_VERSION; }
@@ -200,6 +203,12 @@ extern "C" int sgpmp_set_option(sgpmp_ctx* c, const char* name, long long value)
     if (!c || !name) return fail(SGPMP_EINVAL, "sgpmp_set_option: null argument");
     if (std::strcmp(name, "k3_blocks") == 0) { c->tg.k3_blocks = value; return SGPMP_OK; }
     if (std::strcmp(name, "pipe_split") == 0) { c->tg.pipe_split = value; return SGPMP_OK; }
+#if !SGPMP_EXPERIMENTS
+    // launches that were measured slower live in `make EXPERIMENTS=1` builds only (csrc/Makefile): unknown here
+    for (const char* x : {"planar_slabs", "tail_update", "small_step"})
+        if (std::strcmp(name, x) == 0)
+            return fail(SGPMP_EINVAL, std::string("sgpmp_set_option: unknown option ") + name + " (an EXPERIMENTS=1 build has it)");
+#endif
     if (std::strcmp(name, "planar_slabs") == 0) { c->tg.planar_slabs = value; return SGPMP_OK; }
     for (const auto& t : kToggleNames)
         if (std::strcmp(name, t.name) == 0) { c->tg.*(t.flag) = value != 0; return SGPMP_OK; }
@@ -244,6 +253,11 @@ extern "C" int sgpmp_comm_info(sgpmp_ctx* c, int* world, int* rank, int* rccl_ve
     if (!c->comm) return SGPMP_OK;
     COMMCHK(comm_info(c->comm, world, rank, rccl_version));
     return SGPMP_OK;
+}
+
+extern "C" const char* sgpmp_comm_library(int* test_hooks) {
+    if (test_hooks) *test_hooks = comm_test_hooks();
+    return comm_library_name();
 }
 
 // ---- per-goal statistics of the particle means (the all-reduce's north_star content) -----------------------------

@@ -35,19 +35,34 @@ struct RcclApi {
 };
 
 static RcclApi g_rccl = {};
+static std::string g_rccl_name;                              // what load_rccl bound (sgpmp_comm_library)
+#ifndef SGPMP_TEST_HOOKS
+#define SGPMP_TEST_HOOKS 0
+#endif
+
+// Name of the collective library this process bound ("" before the first communicator); "librccl.so.1" etc. in the
+// product library -- a test-hooks build may report the stand-in it was told to load.
+const char* comm_library_name() { return g_rccl_name.c_str(); }
+int comm_test_hooks() { return SGPMP_TEST_HOOKS; }
 
 static const char* load_rccl() {
     if (g_rccl.handle) return nullptr;
     void* h = nullptr;
     // SGPMP_RCCL_LIB: a library with RCCL's entry points to bind instead (tests/fake_rccl: the shared-memory test double
     // that lets several ranks share ONE GPU, which real RCCL refuses -- the only way the N > 1 protocol runs on a 1-GPU box)
+    // -- compiled ONLY into tests/fake_rccl/libsgpmp_testhooks.so (-DSGPMP_TEST_HOOKS, csrc/Makefile `testhooks`): the
+    // product library ignores the variable, so a leaked environment cannot route its collectives anywhere but RCCL.
+#if SGPMP_TEST_HOOKS
     if (const char* over = getenv("SGPMP_RCCL_LIB")) {
         h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
         if (!h) return "SGPMP_RCCL_LIB is set but cannot be loaded";
+        g_rccl_name = over;
     }
+#endif
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         if (h) break;
         h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) g_rccl_name = name;
     }
     if (!h) return "librccl.so.1 not found (dlopen)";
 #define SYM(field, name)                                            \

@@ -497,9 +497,11 @@ static bool make_flat(const CostProgram& p, FlatProg<real>& f) {
 #include "cost_sweep_dual.inc"
 #include "fused_step.inc"
 #include "fused_planar.inc"
-#include "fused_planar_slab.inc"
 #include "fused_planar_seg.inc"
+#if SGPMP_EXPERIMENTS            // measured slower, kept for the record (make EXPERIMENTS=1)
+#include "fused_planar_slab.inc"
 #include "small_step.inc"
+#endif
 
 // Does a step qualify for a fused launch?  1: chain-code program (fused_step.inc), 2: program without forward
 // kinematics (fused_planar.inc), 0: no.
@@ -556,6 +558,9 @@ bool planar_seg_step(int dtype, int n, int T, const PriorDev& prior, const CostP
 bool fused_tail_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                          const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
                          const SgpmpToggles& tg) {
+#if !SGPMP_EXPERIMENTS
+    return false;                                        // (fused_tail.inc is compiled under make EXPERIMENTS=1 only)
+#endif
     if (!tg.tail_update || h_prog.n_ee > 0) return false;
     const int kind = fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
     if (kind != 1) return false;
@@ -575,6 +580,9 @@ static size_t small_step_lds(int n, int T, int S, size_t esz) {
 
 bool small_step_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, int P, int S,
                          const SgpmpToggles& tg) {
+#if !SGPMP_EXPERIMENTS
+    return false;                                        // (small_step.inc is compiled under make EXPERIMENTS=1 only)
+#endif
     if (!tg.small_step || !prior.isotropic || h_prog.needs_fk || h_prog.n_ee > 0 || (n != 2 && n != 3) || P < 1) return false;
     if (dtype == SGPMP_F32) { FlatProg<float> F; if (!make_flat<float>(h_prog, F) || (F.has_gp && (float)prior.dt != F.gp.dt)) return false; }
     else { FlatProg<double> F; if (!make_flat<double>(h_prog, F) || (F.has_gp && prior.dt != F.gp.dt)) return false; }
@@ -583,6 +591,7 @@ bool small_step_eligible(int dtype, int n, int T, const PriorDev& prior, const C
     return small_step_lds(n, T, S, dtype == SGPMP_F64 ? 8 : 4) <= 64 * 1024 && P <= 1024;
 }
 
+#if SGPMP_EXPERIMENTS
 template <typename real>
 static hipError_t small_step_launch(int n, int T, const PriorDev& prior, const CostProgram& h_prog, uint64_t seed, uint64_t draw,
                                     void* means, int P, int mode_offset, int S, void* samples, const void* isw, void* costs,
@@ -612,15 +621,20 @@ static hipError_t small_step_launch(int n, int T, const PriorDev& prior, const C
     return hipGetLastError();
 }
 
+#endif
 hipError_t launch_small_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, uint64_t seed,
                              uint64_t draw, void* means, int P, int mode_offset, int S, void* samples, const void* isw,
                              void* costs, double* costs64, const FusedTailHost& th, void* isw_next, void* means_copy,
                              hipStream_t stream, hipEvent_t done) {
+#if !SGPMP_EXPERIMENTS
+    return hipErrorNotSupported;                          // (never reached: small_step_eligible is false in this build)
+#else
     if (dtype == SGPMP_F64)
         return small_step_launch<double>(n, T, prior, h_prog, seed, draw, means, P, mode_offset, S, samples, isw, costs, costs64,
                                          th, isw_next, means_copy, stream, done);
     return small_step_launch<float>(n, T, prior, h_prog, seed, draw, means, P, mode_offset, S, samples, isw, costs, costs64, th,
                                     isw_next, means_copy, stream, done);
+#endif
 }
 
 // K2 + K3 in one launch when the step qualifies; *launched says whether it did.
@@ -675,6 +689,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         // (fused_planar_slab.inc), when the slabs are whole 16-waypoint chunks of at most 64 waypoints and the items
         // fill the workgroups.  Same results; measured level with fused_planar_kernel at config 2 (23.2 vs 22.4 us:
         // 35 % more vector instructions and two rounds of workgroups eat what the shorter chains gain).
+#if SGPMP_EXPERIMENTS
         int W = 0;
         const long long force = tg.planar_slabs;
         auto fits = [&](int w) { return T % (SGPMP_FUSED_TC * w) == 0 && T / w <= 64 && nitems % (4 / w) == 0 && nitems * w / 4 <= cap; };
@@ -693,6 +708,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
             *launched = true;
             return hipGetLastError();
         }
+#endif
         // lane = sample, wave = time segment (fused_planar_seg.inc) where the shape allows; picked from (S, T, n) alone
         {
             const int L = planar_seg_len(n, T, S, tg), G = L ? T / L : 0;
@@ -721,7 +737,13 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     // (`done`, multi-GPU statistics: signalled by this kernel's own dispatch packet -- hipExtLaunchKernelGGL stop
     // event -- instead of a separate barrier packet behind it)
 #define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, TAIL_>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
+#if SGPMP_EXPERIMENTS
     const bool with_tail = fs.tail.arrive != nullptr;
+#else
+    constexpr bool with_tail = false;                     // (fused_tail_eligible is false in this build: fs.tail stays zero)
+#undef FUSED_LAUNCH
+#define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
+#endif
     if (ft == SGPMP_FIELD_RBF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_RBF, true); else FUSED_LAUNCH(SGPMP_FIELD_RBF, false); }
     else if (ft == SGPMP_FIELD_SDF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_SDF, true); else FUSED_LAUNCH(SGPMP_FIELD_SDF, false); }
     else { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, true); else FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, false); }

@@ -9,6 +9,9 @@
 #define SGPMP_MAX_LINKS (SGPMP_MAX_JOINTS + 1)
 #define SGPMP_MAX_POINTS 32                 // links + interpolated points per field term
 #define SGPMP_WAVE 64
+#ifndef SGPMP_EXPERIMENTS
+#define SGPMP_EXPERIMENTS 0                  // 1 (make EXPERIMENTS=1): also the launches that were measured slower (Makefile)
+#endif
 
 // ---------------------------------------------------------------------------------- prior factor
 // Device-resident result of K1 for one prior (INIT or SAMPLE).
@@ -128,6 +131,8 @@ const char* comm_create(const unsigned char* id128, int world, int rank, SgpmpCo
 void comm_destroy(SgpmpComm* c);
 int comm_rank(const SgpmpComm* c);
 int comm_world(const SgpmpComm* c);
+const char* comm_library_name();
+int comm_test_hooks();
 const char* comm_info(const SgpmpComm* c, int* world, int* rank, int* version);   // asked of RCCL itself
 const char* comm_allreduce_stats(SgpmpComm* c, double* stats, hipStream_t stream);
 const char* comm_allreduce_f64(SgpmpComm* c, double* buf, size_t count, hipStream_t stream);

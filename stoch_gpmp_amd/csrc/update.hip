@@ -64,45 +64,55 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
 // a mode's particles are what a covariance adaptation (MultiMPPrior.set_Sigma_invs, mp_priors_multi.py:125-128) or a
 // mode summary would consume.  out [G][M + 1][2] doubles is ACCUMULATED into (zero it first): [g][m] = (sum of
 // mu_p[m], sum of mu_p[m]^2) over this shard's particles of goal g, [g][M] = (their number, 0).
-// grid = (ceil(M / 256), particle slices); a slice adds its partial sums with one atomic per element and goal run.
+// grid = (ceil((M + 1) / 64), G), 1024 threads: lane = element, the 16 waves take the goal's particles of this shard
+// round-robin; the waves' partial sums meet in LDS and are added in wave order -- NO atomics, so the sums are bitwise
+// reproducible run to run for a given sharding (round 3's version added up to 32 slices with fp64 atomics in whatever
+// order they arrived).  Across different shardings the order of the additions differs: equal to rounding only.
+#define SGPMP_MS_WAVES 16
 template <typename real>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * SGPMP_MS_WAVES)
 mode_stats_kernel(int M, int P, long long p_offset, int nppg, int G, const real* __restrict__ means,
                   double* __restrict__ out) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    const int per = (P + gridDim.y - 1) / gridDim.y;
-    const int p0 = blockIdx.y * per, p1 = min(P, p0 + per);
-    if (p0 >= p1) return;
-    int g = (int)min((long long)(G - 1), (p_offset + p0) / nppg);
+    __shared__ double red[SGPMP_MS_WAVES][64][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + lane;
+    const int g = blockIdx.y;
+    // local particles of goal g: global [g nppg, (g + 1) nppg) -- the last goal also takes what lies beyond (as the
+    // clamp min(G - 1, p / nppg) of the cost kernels does) -- cut to this shard [p_offset, p_offset + P)
+    const long long lo = (long long)g * nppg, hi = g == G - 1 ? (long long)1 << 62 : lo + nppg;
+    const long long a = lo > p_offset ? lo - p_offset : 0;
+    const long long b = hi - p_offset < (long long)P ? hi - p_offset : (long long)P;
     double s1 = 0., s2 = 0.;
-    int cnt = 0;
-    auto flush = [&]() {
-        if (m < M) {
-            atomicAdd(&out[((size_t)g * (M + 1) + m) * 2], s1);
-            atomicAdd(&out[((size_t)g * (M + 1) + m) * 2 + 1], s2);
-        } else if (m == M) {
-            atomicAdd(&out[((size_t)g * (M + 1) + M) * 2], (double)cnt);
+    if (m < M) {
+        long long p = a + wave;
+        for (; p + 3 * SGPMP_MS_WAVES < b; p += 4 * SGPMP_MS_WAVES) {            // four independent loads in flight
+            const double v0 = (double)means[(size_t)p * M + m], v1 = (double)means[(size_t)(p + SGPMP_MS_WAVES) * M + m];
+            const double v2 = (double)means[(size_t)(p + 2 * SGPMP_MS_WAVES) * M + m];
+            const double v3 = (double)means[(size_t)(p + 3 * SGPMP_MS_WAVES) * M + m];
+            s1 += v0; s2 += v0 * v0; s1 += v1; s2 += v1 * v1; s1 += v2; s2 += v2 * v2; s1 += v3; s2 += v3 * v3;
         }
-        s1 = s2 = 0.; cnt = 0;
-    };
-    for (int p = p0; p < p1; ++p) {
-        const int gp = (int)min((long long)(G - 1), (p_offset + p) / nppg);
-        if (gp != g) { flush(); g = gp; }
-        if (m < M) {
+        for (; p < b; p += SGPMP_MS_WAVES) {
             const double v = (double)means[(size_t)p * M + m];
             s1 += v; s2 += v * v;
         }
-        ++cnt;
     }
-    flush();
+    red[wave][lane][0] = s1; red[wave][lane][1] = s2;
+    __syncthreads();
+    if (wave == 0) {
+        double t1 = red[0][lane][0], t2 = red[0][lane][1];
+#pragma unroll
+        for (int w = 1; w < SGPMP_MS_WAVES; ++w) { t1 += red[w][lane][0]; t2 += red[w][lane][1]; }
+        double* o = out + ((size_t)g * (M + 1) + m) * 2;
+        if (m < M) { o[0] += t1; o[1] += t2; }                                   // (ACCUMULATES, as documented: one writer per element)
+        else if (m == M) o[0] += (double)(b > a ? b - a : 0);
+    }
 }
 
 hipError_t launch_mode_stats(int dtype, int n, int T, int P, long long p_offset, int nppg, int G, const void* means,
                              double* out, hipStream_t stream) {
     if (P <= 0) return hipSuccess;
     const int M = T * 2 * n;
-    const int slices = P >= 32 ? 32 : P;
-    dim3 grid((unsigned)((M + 1 + 255) / 256), (unsigned)slices), block(256);
+    dim3 grid((unsigned)((M + 1 + 63) / 64), (unsigned)G), block(64 * SGPMP_MS_WAVES);
     if (dtype == SGPMP_F64)
         hipLaunchKernelGGL((mode_stats_kernel<double>), grid, block, 0, stream, M, P, p_offset, nppg, G, (const double*)means, out);
     else

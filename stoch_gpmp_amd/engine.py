@@ -86,6 +86,13 @@ class Engine:
         L.check(self.lib.sgpmp_comm_info(self._ctx, C.byref(w), C.byref(r), C.byref(v)))
         return w.value, r.value, v.value
 
+    def comm_library(self):
+        """(name of the collective library this process bound -- "" before the first communicator --, 1 when this is the
+        test-hooks build that honours SGPMP_RCCL_LIB); include/sgpmp.h: sgpmp_comm_library."""
+        h = C.c_int(0)
+        name = self.lib.sgpmp_comm_library(C.byref(h))
+        return (name or b"").decode(), h.value
+
     def allreduce_stats(self, stats):
         with torch.cuda.device(self.device):
             L.check(self.lib.sgpmp_allreduce_stats(self._ctx, L.ptr(stats), L.stream_ptr()))

@@ -26,6 +26,10 @@ Additions over the reference API (all optional keyword arguments):
                              of squares per goal, all-reduced over the ranks on the side stream -- the "weighted-mean /
                              covariance statistics" of the modes); global_mode_stats() reads them.  False: the same
                              numbers are computed (and all-reduced) when global_mode_stats() is called.
+  clone_outputs=True         optimize() returns CLONES of the pre-update means, as the reference does (planner.py:252-253);
+                             False hands out views of the persistent buffer (two tiny copy launches fewer per call).
+  state_dict() / load_state_dict()   checkpoint / resume: means, seed, draw counter (the noise is counter-based, so a
+                             resumed run -- also under another sharding -- continues bit for bit).
   pipeline_steps=True        optimize(opt_iters >= 2) lets the context run the iterations of the call as two
                              particle-half chains on streams of its own (one half's update kernel under the
                              other half's sampler + sweep launch); same results, bit for bit.
@@ -146,6 +150,7 @@ class StochGPMP:
         # optimize(opt_iters >= 2) runs its iterations as two particle-half chains (sgpmp_pipeline_begin)
         self.pipeline_steps = bool(kwargs.get('pipeline_steps', True))
         self.mode_stats_every_step = bool(kwargs.get('mode_stats', False))
+        self.clone_outputs = bool(kwargs.get('clone_outputs', True))
         self._mode_buf = None
 
         self.reset(start_state, multi_goal_states, initial_particle_means=initial_particle_means)
@@ -246,9 +251,9 @@ class StochGPMP:
         # flatten(0,1): p = g * nppg + k (planner.py:215); keep this rank's shard
         self.particle_means = pm.reshape(P, T, d)[self.p0:self.p1].contiguous().clone()
 
-        # persistent buffers of the iteration.  NOTE: optimize() hands out VIEWS of these (the
-        # reference returns views of its sample tensor too, planner.py:246-249, but clones of the
-        # means): results kept across calls must be cloned by the caller.
+        # persistent buffers of the iteration.  optimize() hands out VIEWS of the sample buffer (the reference
+        # returns views of its sample tensor too, planner.py:246-249) and, like the reference (planner.py:252-253),
+        # CLONES of the pre-update means unless clone_outputs=False.
         if fresh:
             self._samples_buf = torch.empty(Pl, S, T, d, **ta)      # iteration buffer (pointers are pre-bound)
             self._costs = torch.empty(Pl, S, **ta)
@@ -269,6 +274,7 @@ class StochGPMP:
         self._stats_slot = 0
         self._step_calls = {}
         self._pm_obj, self._pm_version = None, -1       # means tensor / version after our last fused step
+        self._mode_fresh = False                        # _mode_buf holds the statistics of the current means
         self._Sigma_inv = None
         self._obs_src = None        # strong reference to the caller's obstacle tensor (see _spheres)
         self._obs_ver = -1
@@ -399,7 +405,11 @@ class StochGPMP:
         eng = self._engine
         torch_dist = (self.world_size > 1 or self._force_reduce) and not self._comm_attached \
             and self._collective == 'torch' and torch.distributed.is_initialized()
-        if self.mode_stats_every_step and self._native_cost:     # (a foreign cost object steps through sgpmp_update)
+        # the per-step buffer describes the means the LAST step wrote: before the first step, after reset() or after an
+        # edit of particle_means (torch's version counter moved) it is stale, and the on-demand path below answers
+        pm = self.particle_means
+        fresh = self._mode_fresh and pm is self._pm_obj and pm._version == self._pm_version
+        if self.mode_stats_every_step and self._native_cost and fresh:     # (a foreign cost object steps through sgpmp_update)
             eng.mode_stats_wait()
             buf = self._mode_buf.clone() if torch_dist else self._mode_buf
         else:
@@ -444,12 +454,16 @@ class StochGPMP:
                 kept = pm is self._pm_obj and pm._version == self._pm_version
                 call(self._draw, L.STEP_MEANS_KEPT if kept else 0)
                 self._pm_obj, self._pm_version = pm, pm._version
+                self._mode_fresh = self.mode_stats_every_step
             else:
                 self._engine.step(self.seed, self._draw, self.particle_means, self.state_samples,
                                   self.temperature, self.step_size, costs=self._costs,
                                   weights=self._weights_buf, grad=self._grad, means_prev=self._means_prev,
                                   spheres=self._spheres(observation), eps=self._draw_eps(),
                                   eps_mode_offset=self.p0, stats=self._stats[slot])
+                pm = self.particle_means
+                self._pm_obj, self._pm_version = pm, pm._version
+                self._mode_fresh = self.mode_stats_every_step
         elif self._comm_attached:
             # an empty shard (more ranks than particles) still joins the step's statistics all-reduce: it is a
             # collective, and the other ranks' side streams would wait for this rank for ever
@@ -546,6 +560,8 @@ class StochGPMP:
             if piped:
                 self._engine.pipeline_end()
         state_particles, control_particles, state_trajectories, control_samples = self._views
+        if self.clone_outputs:                           # planner.py:252-253: the reference hands out clones of the means
+            state_particles, control_particles = state_particles.clone(), control_particles.clone()
         self._recent_control_samples = control_samples
         self._recent_control_particles = control_particles
         self._recent_state_trajectories = state_trajectories
@@ -580,6 +596,55 @@ class StochGPMP:
         self._draw += 1
         self.state_samples = fresh                       # as the reference does (planner.py:341)
         return fresh[..., :self.n_dof], fresh[..., -self.n_dof:]
+
+    # ------------------------------------------------------------------------------- checkpoint / resume
+    def state_dict(self):
+        """Everything a run needs to continue where it stands (the reference keeps the same state in
+        `particle_means` and torch's global generator, planner.py:215,243,270): this rank's particle means with their
+        global particle range, the noise key (seed) and the draw counter.  The in-kernel noise is a pure function of
+        (seed, draw, GLOBAL particle, sample, element), so `load_state_dict` into a planner with the same problem
+        continues bit for bit -- also under another sharding (a state saved at world_size 1 feeds every shard).
+        noise='torch' planners also carry torch's CPU generator state."""
+        self._engine.stats_wait(None)
+        sd = {
+            'version': 1,
+            'particle_means': self.particle_means.detach().clone(),
+            'particle_range': (self.p0, self.p1), 'num_particles': self.num_particles,
+            'shape': (self.num_goals, self.num_particles_per_goal, self.num_samples, self.traj_len, self.n_dof),
+            'seed': self.seed, 'draw': self._draw, 'stats_slot': self._stats_slot,
+            'stats': self._stats.detach().clone(),
+            'temperature': self.temperature, 'step_size': self.step_size, 'noise': self.noise,
+            'cost_version': self.cost.version() if self._native_cost else None,
+        }
+        if self.noise == 'torch':
+            sd['torch_rng_state'] = torch.get_rng_state()
+        return sd
+
+    def load_state_dict(self, sd):
+        """Continue the run `sd` was taken from (see state_dict).  The saved particle range must cover this planner's
+        shard; problem shape and noise mode must match (ValueError otherwise)."""
+        if sd.get('version') != 1:
+            raise ValueError("load_state_dict: unknown state version")
+        shape = (self.num_goals, self.num_particles_per_goal, self.num_samples, self.traj_len, self.n_dof)
+        if tuple(sd['shape']) != shape or sd['num_particles'] != self.num_particles or sd['noise'] != self.noise:
+            raise ValueError(f"load_state_dict: state of problem {tuple(sd['shape'])} / noise {sd['noise']!r}, "
+                             f"planner is {shape} / {self.noise!r}")
+        q0, q1 = sd['particle_range']
+        if q0 > self.p0 or q1 < self.p1:
+            raise ValueError(f"load_state_dict: state holds particles [{q0}, {q1}), this shard needs [{self.p0}, {self.p1})")
+        self._engine.stats_wait(None)
+        pm = sd['particle_means'][self.p0 - q0:self.p1 - q0].to(**self.tensor_args)
+        self.particle_means.copy_(pm)                    # (in place: bumps the version counter -> no prepared IS weights)
+        self.seed, self._draw = int(sd['seed']), int(sd['draw'])
+        self._step_calls = {}                            # (the seed is pre-bound in the prepared calls)
+        self._pm_obj, self._pm_version = None, -1
+        self._mode_fresh = False
+        self._stats_slot = int(sd['stats_slot'])
+        if (q0, q1) == (self.p0, self.p1) and sd['stats'].shape == self._stats.shape:
+            self._stats.copy_(sd['stats'])               # (the last iteration's statistics: global_stats() answers as before)
+        self.temperature, self.step_size = sd['temperature'], sd['step_size']
+        if self.noise == 'torch' and 'torch_rng_state' in sd:
+            torch.set_rng_state(sd['torch_rng_state'])
 
     def gather_particle_means(self):
         """All ranks' particle means [P,T,d] (RCCL all-gather over xGMI); identity on one GPU."""

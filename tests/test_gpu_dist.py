@@ -185,16 +185,47 @@ def test_torch_collective_fallback_matches(one_rank_group):
     assert a.global_stats() == b.global_stats()
 
 
+def _test_double():
+    """(libfakerccl.so, libsgpmp_testhooks.so): the stand-in for librccl and the ONLY build of the library that will bind
+    it -- comm.hip compiled with -DSGPMP_TEST_HOOKS (csrc/Makefile `testhooks`); the product library ignores
+    SGPMP_RCCL_LIB."""
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
+    hooks = os.path.join(ROOT, "tests", "fake_rccl", "libsgpmp_testhooks.so")
+    if not os.path.exists(fake):
+        subprocess.run(["make", "-C", os.path.dirname(fake)], check=True, capture_output=True)
+    if not os.path.exists(hooks):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "stoch_gpmp_amd", "csrc"), "testhooks"], check=True, capture_output=True)
+    return fake, hooks
+
+
+def test_product_library_ignores_the_rccl_override():
+    """SGPMP_RCCL_LIB is a TEST hook: only libsgpmp_testhooks.so honours it.  The product library, with the variable
+    set to the stand-in, still binds librccl and says so (sgpmp_comm_library)."""
+    fake, hooks = _test_double()
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from stoch_gpmp_amd import _lib; lib = _lib.load(); "
+            "buf = C.create_string_buffer(128); rc = lib.sgpmp_comm_unique_id(buf); h = C.c_int(-1); "
+            "print('BOUND', rc, lib.sgpmp_comm_library(C.byref(h)).decode(), h.value)" % ROOT)
+    env = dict(os.environ, SGPMP_RCCL_LIB=fake)
+    env.pop("SGPMP_LIB_PATH", None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rc, name, hooked = p.stdout.strip().splitlines()[-1].split()[1:]
+    assert rc == "0" and "librccl" in name and "fake" not in name and hooked == "0", p.stdout
+    p = subprocess.run([sys.executable, "-c", code], env=dict(env, SGPMP_LIB_PATH=hooks), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rc, name, hooked = p.stdout.strip().splitlines()[-1].split()[1:]
+    assert rc == "0" and name == fake and hooked == "1", p.stdout
+
+
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_ranks_sharing_one_gpu_through_the_rccl_test_double(world):
     """The library's N > 1 protocol on a 1-GPU box: `world` processes on cuda:0, libsgpmp.so bound to
-    tests/fake_rccl/libfakerccl.so (stream-ordered shared-memory all-reduce / all-gather) through SGPMP_RCCL_LIB.  The
+    tests/fake_rccl/libfakerccl.so (stream-ordered shared-memory all-reduce / all-gather) through SGPMP_RCCL_LIB, which
+    only the test-hooks build of the library (SGPMP_LIB_PATH=tests/fake_rccl/libsgpmp_testhooks.so) honours.  The
     worker checks shards against the unsharded run bit for bit, all-reduced cost and per-goal mean statistics, ring-slot
     reuse, two-chain steps, the all-gather and a rank with an empty shard (world = 3: ragged shards too)."""
-    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
-    if not os.path.exists(fake):
-        subprocess.run(["make", "-C", os.path.dirname(fake)], check=True, capture_output=True)
-    env = dict(os.environ, SGPMP_RCCL_LIB=fake)
+    fake, hooks = _test_double()
+    env = dict(os.environ, SGPMP_RCCL_LIB=fake, SGPMP_LIB_PATH=hooks)
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
@@ -233,11 +264,9 @@ def test_bench_multi_rank_code_on_one_gpu_through_the_test_double(gpus):
     """bench.py's N > 1 code (own launcher, barriers, max over ranks, per-rank rates, the communicator's own rank
     count, the whole-job value) with `gpus` ranks sharing cuda:0 through tests/fake_rccl: exactly what the driver runs
     as `bench.py --gpus N`, minus RCCL and the other GPUs.  Not a measurement -- the line says so."""
-    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
-    if not os.path.exists(fake):
-        subprocess.run(["make", "-C", os.path.dirname(fake)], check=True, capture_output=True)
+    fake, hooks = _test_double()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update(SGPMP_BENCH_SHARED_GPU="1", SGPMP_RCCL_LIB=fake)
+    env.update(SGPMP_BENCH_SHARED_GPU="1", SGPMP_RCCL_LIB=fake, SGPMP_LIB_PATH=hooks)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20",
                         "--warmup", "5", "--particles", "128"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-6000:]
