@@ -471,6 +471,11 @@ class StochGPMP:
                 self._draw_eps()                         # (keep the global generator aligned with the other ranks)
             self._engine.step(self.seed, self._draw, self.particle_means, self.state_samples, self.temperature,
                               self.step_size, stats=self._stats[slot])
+            # (the step issued the per-goal statistics all-reduce too: this rank must read the per-step buffer like the
+            # others do, not start an on-demand collective of its own)
+            pm = self.particle_means
+            self._pm_obj, self._pm_version = pm, pm._version
+            self._mode_fresh = self.mode_stats_every_step
         self._draw += 1
         self._reduce_stats(slot)
         self._stats_slot ^= 1
