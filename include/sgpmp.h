@@ -23,7 +23,9 @@
 #ifndef SGPMP_H
 #define SGPMP_H
 
+#ifndef __HIPCC_RTC__          /* (the run-time compiler of the chain kernels has the fixed-width types built in) */
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {

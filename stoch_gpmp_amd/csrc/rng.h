@@ -7,8 +7,10 @@
 // particles are sharded over GPUs and nothing has to be stored to revisit a sample.
 // Parity with the reference is checked in the separate external-eps mode of the kernels.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 struct Philox4 { uint32_t x, y, z, w; };
 

@@ -1,7 +1,9 @@
 // Internal declarations shared by the HIP translation units of libsgpmp.so (gfx950 only).
 #pragma once
+#ifndef __HIPCC_RTC__                        // (hiprtc brings the runtime header and the fixed-width types itself)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 #include "../../include/sgpmp.h"
 
 #define SGPMP_TILE 16                       // state blocks padded to one 16x16 MFMA tile
@@ -123,6 +125,7 @@ struct SgpmpToggles {
     long long k3_blocks;      // SGPMP_K3_BLOCKS            workgroup cap of the dual sweep (0: default)
 };
 
+#ifndef __HIPCC_RTC__     // host-side declarations: not part of the run-time (hiprtc) translation unit of chain_rtc.hip
 // ---------------------------------------------------------------------------------- collectives (comm.hip)
 // RCCL communicator of one context; every function returns NULL on success or a static error string.
 struct SgpmpComm;
@@ -260,3 +263,4 @@ hipError_t launch_grid_lookup(int dtype, const CostTerm& term, const void* xy, l
 hipError_t launch_field_eval(int dtype, const CostTerm& term, const void* frames, long long batch,
                              int n_links, const void* spheres, int n_spheres, void* out,
                              hipStream_t stream);
+#endif  // !__HIPCC_RTC__

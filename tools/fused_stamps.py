@@ -27,10 +27,12 @@ start = c[:, 5]
 rel = torch.zeros_like(start)                          # (per XCD: the cycle counters of different XCDs need not agree)
 for x in c[:, 7].unique():
     m = c[:, 7] == x
-    # 24-bit stamps may wrap: take the start that leaves the smallest spread as the origin
+    # 24-bit stamps may wrap inside the launch: the origin is the start that follows the largest circular gap
     cand = start[m]
-    best = min(((cand - o) % (1 << 24) for o in cand[:: max(1, len(cand) // 64)]), key=lambda r: float(r.max()))
-    rel[m] = best
+    srt, _ = torch.sort(cand)
+    gaps_c = torch.cat([srt[1:] - srt[:-1], (srt[:1] + (1 << 24)) - srt[-1:]])
+    o = srt[(int(gaps_c.argmax()) + 1) % len(srt)]
+    rel[m] = (cand - o) % (1 << 24)
 print(f"wave starts after the first: median {rel.median():.0f}, 90 % {rel.quantile(0.9):.0f}, max {rel.max():.0f} cycles")
 
 # ---- occupancy timeline per SIMD: (xcd, se, sh, cu, simd) from HW_ID / XCC_ID
