@@ -128,6 +128,7 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * environment variable SGPMP_<NAME> that is read ONCE, in sgpmp_create; this call changes a switch
  * on a live context.  Names: force_generic_fk, no_flat_program, no_chain_codegen, no_dual_sweep,
  * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, comm_packet_event,
+ * no_wave_groups (fused launch / chunked sweep as 256-thread workgroups instead of one wave per workgroup),
  * no_planar_seg (planar one-launch step through the LDS tile, fused_planar_kernel, even where the lane-per-sample launch applies),
  * pipe_split (1..15) and k3_blocks (count); and, ONLY in a library built with `make EXPERIMENTS=1` (launches that
  * measured slower and are kept for the record; the default library answers SGPMP_EINVAL "unknown option"):
@@ -182,6 +183,23 @@ int sgpmp_get_prior(sgpmp_ctx* ctx, int which, double* blocks, double* G, double
 /* CostComposite(cost_list, FK) compiled to a device cost program (cost_functions.py:34-58). */
 int sgpmp_set_costs(sgpmp_ctx* ctx, const sgpmp_cost_desc* descs, int n_desc);
 int sgpmp_set_fk(sgpmp_ctx* ctx, const sgpmp_joint* chain, int n_joints);
+/* Any serial chain on the fast launches (the reference takes any FK callable, cost_functions.py:39,51-52).  The fused
+ * sampler + sweep launch and the chunked sweep need the chain as straight-line, constant-folded code; the library is built
+ * with that code for the Panda only.  For another chain the host generates `struct ChainCode_rt { ... };` with
+ * stoch_gpmp_amd/csrc/gen/chain_codegen.py (gen_chain("rt", chain): the same generator that wrote the built-in code) and
+ * hands the text over AFTER sgpmp_set_fk; the library compiles the same kernel sources around it with hiprtc for gfx950
+ * (dlopen; lazily per sphere-field type; cached in memory and under $SGPMP_RTC_CACHE | ~/.cache/sgpmp), verifies the code
+ * against the chain of sgpmp_set_fk (forward kinematics at random joint vectors, link and pair tables) and dispatches the chain
+ * like the built-in one.  fp32 contexts, n_dof <= 7, revolute joints first.  On failure -- SGPMP_ESTATE: hiprtc or the
+ * kernel sources (csrc/ next to the library, or $SGPMP_CSRC_DIR) unavailable; SGPMP_EINVAL: the code is not this chain's --
+ * the chain keeps the slower run-time-constant kernels; nothing else changes.  sgpmp_set_fk resets it. */
+int sgpmp_set_fk_codegen(sgpmp_ctx* ctx, const char* chain_struct_source);
+/* *codegen_id: 0 run-time constants, 1 built-in code (Panda), 2 compiled at run time; seconds spent in hiprtc and the code
+ * objects compiled / found in the disk cache for the current chain.  Any pointer may be NULL. */
+int sgpmp_fk_codegen_info(sgpmp_ctx* ctx, int* codegen_id, double* compile_s, int* compiled, int* from_cache);
+/* Compile-only check of chain code (hiprtc; no device, no context, nothing cached or loaded): SGPMP_OK and the size of the
+ * gfx950 code object, or SGPMP_ESTATE with the compiler's log in sgpmp_last_error(). */
+int sgpmp_fk_codegen_compile(const char* chain_struct_source, int field_type, int64_t* code_bytes);
 
 /* ---- kernels ---------------------------------------------------------------------------------- */
 /* K2. MultiMPPrior.sample (mp_priors_multi.py:204-207): out[m,s,:] = means[m,:] + scale_tril @ eps.

@@ -105,7 +105,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
     {"tail_update", &SgpmpToggles::tail_update}, {"small_step", &SgpmpToggles::small_step}, {"comm_packet_event", &SgpmpToggles::comm_packet_event},
-    {"no_planar_seg", &SgpmpToggles::no_planar_seg},
+    {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"no_wave_groups", &SgpmpToggles::no_wave_groups},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {
@@ -760,6 +760,56 @@ extern "C" int sgpmp_set_fk(sgpmp_ctx* c, const sgpmp_joint* chain, int n_joints
     HIPCHK(hipMemcpy(c->d_chain, &ch, sizeof(ch), hipMemcpyHostToDevice));
     c->have_chain = true;
     c->prog_dirty = true;
+    return SGPMP_OK;
+}
+
+// Straight-line code for the chain of the last sgpmp_set_fk, compiled at run time (chain_rtc.hip): `struct_src` is the text of
+// `struct ChainCode_rt { ... };` as csrc/gen/chain_codegen.py emits it for that chain (gen_chain("rt", chain)).  The library
+// compiles its fused sampler + sweep launch and its chunked sweep around it with hiprtc (lazily, per sphere-field type; code
+// objects are cached in memory and on disk), CHECKS the code against the chain -- link positions at pseudo-random joint
+// vectors against the host's fp64 forward kinematics, link / pair tables against the host analysis -- and from then on
+// dispatches this chain like the built-in one.  On any failure (no libhiprtc, kernel sources not found, code that does not
+// match the chain) the chain keeps the FkPlan register / generic sweep and the call says why.
+extern "C" int sgpmp_set_fk_codegen(sgpmp_ctx* c, const char* struct_src) {
+    if (!c || !struct_src) return fail(SGPMP_EINVAL, "sgpmp_set_fk_codegen: null argument");
+    if (!c->have_chain) return fail(SGPMP_ESTATE, "sgpmp_set_fk_codegen: no chain (sgpmp_set_fk first)");
+    if (c->h_chain.plan.codegen_id == 1) return SGPMP_OK;        // (the built-in chain needs none)
+    if (c->dims.dtype != SGPMP_F32 || c->dims.n_dof > 7 || !c->h_chain.plan.fast)
+        return fail(SGPMP_EINVAL, "sgpmp_set_fk_codegen: chain kernels are fp32, n_dof <= 7, revolute joints first");
+    RtcChain* rc = nullptr;
+    if (const char* e = rtc_chain_get(struct_src, c->dims.n_dof, &rc)) return fail(SGPMP_EINVAL, std::string("sgpmp_set_fk_codegen: ") + e);
+    int ft = SGPMP_FIELD_RBF;
+    for (int i = 0; i < c->h_prog.n_terms; ++i)
+        if (c->h_prog.terms[i].kind == SGPMP_COST_SPHERES) ft = c->h_prog.terms[i].flags & 15;
+    if (const char* e = rtc_verify(rc, c->h_chain, ft)) {
+        const std::string msg = e;
+        const bool mismatch = msg.find("does not") != std::string::npos || msg.find("outside the chain") != std::string::npos;
+        return fail(mismatch ? SGPMP_EINVAL : SGPMP_ESTATE, "sgpmp_set_fk_codegen: " + msg);
+    }
+    c->h_chain.plan.codegen_id = 2;
+    c->h_chain.rtc = rc;
+    HIPCHK(hipMemcpy(c->d_chain, &c->h_chain, sizeof(c->h_chain), hipMemcpyHostToDevice));
+    return SGPMP_OK;
+}
+
+// Compile-only check (needs hiprtc, no device): does this chain code build into the chain kernels for sphere-field type
+// `field_type`?  *code_bytes (may be NULL): size of the gfx950 code object.  Nothing is loaded or cached.
+extern "C" int sgpmp_fk_codegen_compile(const char* struct_src, int field_type, int64_t* code_bytes) {
+    if (!struct_src || field_type < 0 || field_type > 2) return fail(SGPMP_EINVAL, "sgpmp_fk_codegen_compile: bad argument");
+    std::vector<char> err(4200);
+    const long long r = rtc_compile_check_c(struct_src, field_type, err.data(), err.size());
+    if (code_bytes) *code_bytes = r > 0 ? r : 0;
+    if (r < 0) return fail(SGPMP_ESTATE, std::string("sgpmp_fk_codegen_compile: ") + err.data());
+    return SGPMP_OK;
+}
+
+// codegen_id: 0 the chain runs on run-time constants (FkPlan register path / generic path), 1 the code built with the library
+// (Panda), 2 code compiled at run time; compile_s / compiled / from_cache: seconds spent in hiprtc and code objects compiled /
+// taken from the disk cache for this chain so far.  Any pointer may be NULL.
+extern "C" int sgpmp_fk_codegen_info(sgpmp_ctx* c, int* codegen_id, double* compile_s, int* compiled, int* from_cache) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_fk_codegen_info: null context");
+    if (codegen_id) *codegen_id = c->have_chain ? c->h_chain.plan.codegen_id : 0;
+    rtc_stats(c->have_chain && c->h_chain.plan.codegen_id == 2 ? (const RtcChain*)c->h_chain.rtc : nullptr, compile_s, compiled, from_cache);
     return SGPMP_OK;
 }
 

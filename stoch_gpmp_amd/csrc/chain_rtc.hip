@@ -166,6 +166,53 @@ static std::string translation_unit(const RtcChain& c) {
     return tu.str();
 }
 
+// hiprtc: translation unit -> gfx950 code object.  Needs no device.
+static bool compile_tu(const std::string& tu, const std::string& dir, int ft, std::vector<char>& code, std::string& err, double* secs) {
+    if (const char* e = load_hiprtc()) { err = e; return false; }
+    hiprtcProgram prog;
+    if (g_rtc.CreateProgram(&prog, tu.c_str(), "sgpmp_chain_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        err = "hiprtcCreateProgram failed";
+        return false;
+    }
+    const std::string inc = "-I" + dir, ftd = "-DSGPMP_RTC_FT=" + std::to_string(ft),
+                      rounds = "-DSGPMP_PHILOX_ROUNDS=" + std::to_string(SGPMP_PHILOX_ROUNDS),
+                      exper = "-DSGPMP_EXPERIMENTS=" + std::to_string(SGPMP_EXPERIMENTS);
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str(), ftd.c_str(), rounds.c_str(), exper.c_str()};
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    const hiprtcResult r = g_rtc.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (secs) *secs += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    if (r != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        g_rtc.GetProgramLogSize(prog, &ls);
+        std::string log(ls + 1, '\0');
+        if (ls) g_rtc.GetProgramLog(prog, &log[0]);
+        err = "hiprtc: compilation of the chain kernels failed:\n" + log.substr(0, 4000);
+        g_rtc.DestroyProgram(&prog);
+        return false;
+    }
+    size_t cs = 0;
+    g_rtc.GetCodeSize(prog, &cs);
+    code.resize(cs);
+    g_rtc.GetCode(prog, code.data());
+    g_rtc.DestroyProgram(&prog);
+    return true;
+}
+
+// Compile-only check of chain code (no device, no cache): does `struct_src` build into the chain kernels?  -> bytes of code
+// object, or -1 with the reason in `err`.
+long long rtc_compile_check(const char* struct_src, int ft, std::string& err) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const std::string dir = csrc_dir();
+    if (dir.empty() || !file_exists(dir + "/fused_step.inc")) { err = "kernel sources not found (csrc/ next to libsgpmp.so; SGPMP_CSRC_DIR)"; return -1; }
+    RtcChain tmp;
+    tmp.struct_src = struct_src;
+    std::vector<char> code;
+    if (!compile_tu(translation_unit(tmp), dir, ft, code, err, nullptr)) return -1;
+    return (long long)code.size();
+}
+
 // Compile (or fetch from the disk cache) the code object of chain `c` for sphere-field type `ft`; load it as a module.
 static bool build_module(RtcChain& c, int ft) {
     if (c.mod[ft]) return true;
@@ -197,35 +244,7 @@ static bool build_module(RtcChain& c, int ft) {
         if (f) { code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>()); if (!code.empty()) c.from_cache += 1; }
     }
     if (code.empty()) {
-        if (const char* e = load_hiprtc()) { c.err = e; return false; }
-        hiprtcProgram prog;
-        if (g_rtc.CreateProgram(&prog, tu.c_str(), "sgpmp_chain_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
-            c.err = "hiprtcCreateProgram failed";
-            return false;
-        }
-        const std::string inc = "-I" + dir, ftd = "-DSGPMP_RTC_FT=" + std::to_string(ft),
-                          rounds = "-DSGPMP_PHILOX_ROUNDS=" + std::to_string(SGPMP_PHILOX_ROUNDS),
-                          exper = "-DSGPMP_EXPERIMENTS=" + std::to_string(SGPMP_EXPERIMENTS);
-        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str(), ftd.c_str(), rounds.c_str(), exper.c_str()};
-        timespec t0, t1;
-        clock_gettime(CLOCK_MONOTONIC, &t0);
-        const hiprtcResult r = g_rtc.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        c.compile_s += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-        if (r != HIPRTC_SUCCESS) {
-            size_t ls = 0;
-            g_rtc.GetProgramLogSize(prog, &ls);
-            std::string log(ls + 1, '\0');
-            if (ls) g_rtc.GetProgramLog(prog, &log[0]);
-            c.err = "hiprtc: compilation of the chain kernels failed:\n" + log.substr(0, 4000);
-            g_rtc.DestroyProgram(&prog);
-            return false;
-        }
-        size_t cs = 0;
-        g_rtc.GetCodeSize(prog, &cs);
-        code.resize(cs);
-        g_rtc.GetCode(prog, code.data());
-        g_rtc.DestroyProgram(&prog);
+        if (!compile_tu(tu, dir, ft, code, c.err, &c.compile_s)) return false;
         c.compiled += 1;
         if (!cpath.empty()) {                     // write-then-rename: concurrent processes never see half a file
             const std::string tmp = cpath + "." + std::to_string((long)getpid());
@@ -348,4 +367,11 @@ const char* rtc_verify(RtcChain* c, const ChainDev& ch, int ft_hint) {
         }
     }
     return nullptr;
+}
+
+long long rtc_compile_check_c(const char* struct_src, int field_type, char* err, size_t err_len) {
+    std::string e;
+    const long long r = rtc_compile_check(struct_src, field_type, e);
+    if (err && err_len) { std::strncpy(err, e.c_str(), err_len - 1); err[err_len - 1] = 0; }
+    return r;
 }

@@ -114,10 +114,14 @@ static int fused_step_kind(int dtype, int n, int T, const PriorDev& prior, const
         return 2;
     }
     if (tg.no_dual_sweep || tg.no_chain_codegen || tg.force_generic_fk) return 0;
-    if (n != CCp::N || !h_chain.plan.fast || h_chain.plan.codegen_id != 1 || F.has_grid) return 0;
+    if (!h_chain.plan.fast || F.has_grid) return 0;
+    if (h_chain.plan.codegen_id == 1) { if (n != CCp::N) return 0; }         // the chain built with the library
+    else if (h_chain.plan.codegen_id != 2 || !h_chain.rtc || n > 7) return 0;   // ... or compiled at run time (sgpmp_set_fk_codegen)
     if (n_spheres > SGPMP_FUSED_SPH) return 0;
     for (int i = 0; i < h_prog.n_terms; ++i)
         if (h_prog.terms[i].n_interp > 0) return 0;
+    if (h_chain.plan.codegen_id == 2 &&
+        !rtc_kernel((RtcChain*)h_chain.rtc, F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF, false)) return 0;   // (compiled on first use)
     return 1;
 }
 
@@ -325,6 +329,16 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     }
     if (!fs.tail.arrive) done = nullptr;          // (the statistics are complete after update_kernel, which then carries the event)
     const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
+    if (h_chain.plan.codegen_id == 2) {           // this chain's kernels were compiled at run time (chain_rtc.hip)
+        hipFunction_t f = rtc_kernel((RtcChain*)h_chain.rtc, ft, false);
+        if (!f) return hipSuccess;                // (not launched: the caller takes the two-launch path)
+        std::memset(&fs.tail, 0, sizeof(fs.tail));
+        void* args[] = {&a, &F, &fs};
+        const hipError_t e = rtc_launch(f, (unsigned)blocks, stream, args, nullptr);
+        if (picked) *picked = "fused_step_kernel (run-time chain code)";
+        *launched = e == hipSuccess;
+        return e;
+    }
     // (`done`, multi-GPU statistics: signalled by this kernel's own dispatch packet -- hipExtLaunchKernelGGL stop
     // event -- instead of a separate barrier packet behind it)
 #define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, TAIL_>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
@@ -335,6 +349,20 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
 #undef FUSED_LAUNCH
 #define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
 #endif
+    // One wave per workgroup (round 4) when sixteen of them fit the LDS of a CU: a SIMD's slot is then refilled when its own
+    // wave ends, not when the slowest of four does.  The grid-stride loop stays for capped grids (k3_blocks).
+    const size_t dyn = fused_wave_dyn_lds(n_spheres, F.has_goal ? F.goal.dim0 : 0);
+    const bool wave_groups = !with_tail && !tg.no_wave_groups && fused_wave_static_lds<CCp::N>() + dyn <= 10240;
+    if (wave_groups) {
+        long long wblocks = nitems;
+        if (tg.k3_blocks > 0 && wblocks > 4 * tg.k3_blocks) wblocks = 4 * tg.k3_blocks;
+        if (wblocks > (1LL << 20)) wblocks = 1LL << 20;
+#define FUSED_LAUNCH_W(FT_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false, 1>), dim3((unsigned)wblocks), dim3(64), (unsigned)dyn, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
+        if (ft == SGPMP_FIELD_RBF) FUSED_LAUNCH_W(SGPMP_FIELD_RBF);
+        else if (ft == SGPMP_FIELD_SDF) FUSED_LAUNCH_W(SGPMP_FIELD_SDF);
+        else FUSED_LAUNCH_W(SGPMP_FIELD_OCCUPANCY);
+#undef FUSED_LAUNCH_W
+    } else
     if (ft == SGPMP_FIELD_RBF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_RBF, true); else FUSED_LAUNCH(SGPMP_FIELD_RBF, false); }
     else if (ft == SGPMP_FIELD_SDF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_SDF, true); else FUSED_LAUNCH(SGPMP_FIELD_SDF, false); }
     else { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, true); else FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, false); }
@@ -387,7 +415,9 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
     auto log2_exact = [](long long v) { int s = 0; while ((1LL << s) < v && s < 62) ++s; return (1LL << s) == v ? s : -1; };
     a.rpp_shift = log2_exact(a.rows_per_particle);
     a.rpg_shift = (flat && F.has_goal) ? log2_exact(F.goal.rows_per_goal) : -1;
-    if (reg && h_chain.plan.codegen_id == 1 && n == ChainCode_panda::N && !tg.no_chain_codegen) {
+    const bool cg_static = h_chain.plan.codegen_id == 1 && n == ChainCode_panda::N;
+    const bool cg_rtc = h_chain.plan.codegen_id == 2 && h_chain.rtc && sizeof(real) == 4 && n <= 7;
+    if (reg && (cg_static || cg_rtc) && !tg.no_chain_codegen) {
         if constexpr (sizeof(real) == 4) {
             // two trajectories per wave on packed fp32 math (cost_sweep_dual.inc) when rows pair up
             const bool pairs_ok = (batch_offset % 2 == 0) && (!isw || a.rows_per_particle % 2 == 0) &&
@@ -411,6 +441,14 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
                 if (tg.k3_blocks > 0) ccap = tg.k3_blocks;
                 if (cblocks > ccap) cblocks = ccap;
                 const int cft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
+                hipFunction_t rf = cg_rtc ? rtc_kernel((RtcChain*)h_chain.rtc, cft, true) : nullptr;
+                if (cg_rtc && rf) {                       // the chain's own kernels, compiled at run time (chain_rtc.hip)
+                    void* args[] = {&a, &F, &fs};
+                    const hipError_t e = rtc_launch(rf, (unsigned)cblocks, stream, args, nullptr);
+                    *picked = "cost_sweep_chunked_kernel (run-time chain code)";
+                    return e;
+                }
+                if (!cg_rtc) {                            // (cg_rtc without a kernel: FkPlan register path below)
                 if (cft == SGPMP_FIELD_RBF)
                     hipLaunchKernelGGL((cost_sweep_chunked_kernel<ChainCode_panda::N, ChainCode_panda, SGPMP_FIELD_RBF>),
                                        dim3((unsigned)cblocks), dim3(256), 0, stream, a, F, fs);
@@ -422,8 +460,9 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
                                        dim3((unsigned)cblocks), dim3(256), 0, stream, a, F, fs);
                 *picked = "cost_sweep_chunked_kernel";
                 return hipGetLastError();
+                }
             }
-            if (flat && !F.has_grid && pairs_ok && sph_ok && !tg.no_dual_sweep) {
+            if (cg_static && flat && !F.has_grid && pairs_ok && sph_ok && !tg.no_dual_sweep) {
                 long long pblocks = ((batch + 1) / 2 + 3) / 4;
                 long long pcap = 256LL * 20;          // 20 workgroups per CU (4 resident): measured optimum (tools/k3_grid_sweep.sh)
                 if (tg.k3_blocks > 0) pcap = tg.k3_blocks;
@@ -454,6 +493,7 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
                 return hipGetLastError();
             }
         }
+        if (cg_static) {
         *picked = f64 ? "cost_sweep_kernel<f64, generated chain>" : "cost_sweep_kernel<f32, generated chain>";
         if (flat)
             hipLaunchKernelGGL((cost_sweep_kernel<real, ChainCode_panda::N, 1000, true>), dim3((unsigned)blocks),
@@ -462,6 +502,7 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
             hipLaunchKernelGGL((cost_sweep_kernel<real, ChainCode_panda::N, 1000, false>), dim3((unsigned)blocks),
                                dim3(256), 0, stream, a, P, F);
         return hipGetLastError();
+        }
     }
 #define COST_REG(NN, NJJ)                                                                          \
     if (reg && n == NN && nj == NJJ) {                                                             \

@@ -81,7 +81,7 @@ struct JointDev {
 // fields.py:79,86,124 that the register-resident FK path of the cost sweep exploits.
 struct FkPlan {
     int fast;                                   // chain is revolute-first: register path usable
-    int codegen_id;                             // 0 none; 1 = ChainCode_panda (chain_code_generated.h)
+    int codegen_id;                             // 0 none; 1 = ChainCode_panda (chain_code_generated.h); 2 = compiled at run time (ChainDev::rtc)
     int n_rep;                                  // distinct link positions
     float mult[SGPMP_MAX_LINKS];                // multiplicity of link l if representative, else 0
     float wpair[SGPMP_MAX_LINKS * SGPMP_MAX_LINKS];   // [i*ML+j], i>j: 2 m_i m_j if q-dependent, else 0
@@ -98,6 +98,7 @@ struct ChainDev {
     float Rf[SGPMP_MAX_JOINTS][9];              // fp32 copies of the joint constants
     float tf[SGPMP_MAX_JOINTS][3];
     FkPlan plan;
+    void* rtc;                                  // HOST: RtcChain* of this chain's run-time compiled kernels (chain_rtc.hip), or null
 };
 
 // ---------------------------------------------------------------------------------- debug toggles
@@ -115,6 +116,7 @@ struct SgpmpToggles {
     int no_fused_step;        // SGPMP_NO_FUSED_STEP        K2 and K3 as separate kernels inside sgpmp_step
     int no_chunked_sweep;     // SGPMP_NO_CHUNKED_SWEEP     64-lane-pass two-trajectory sweeps instead of the chunked one
     int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
+    int no_wave_groups;       // SGPMP_NO_WAVE_GROUPS       fused launch / chunked sweep as 256-thread workgroups (round 2-3) instead of one wave each
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
     long long planar_slabs;   // SGPMP_PLANAR_SLABS         time slabs of the planar one-launch step: 0 none (fused_planar_kernel, default), 2, 4 (fused_planar_slab.inc, where the shape allows)
     int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
@@ -147,6 +149,16 @@ const char* comm_step_begin2(SgpmpComm* c, hipStream_t s0, hipStream_t s1, doubl
 const char* comm_step_end(SgpmpComm* c, double* stats, bool two_halves);
 const char* comm_stats_wait(SgpmpComm* c, double* stats, hipStream_t stream);
 const char* comm_allgather(SgpmpComm* c, const void* send, void* recv, size_t bytes, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------- run-time chain kernels (chain_rtc.hip)
+struct RtcChain;
+const char* rtc_chain_get(const char* struct_src, int n_dof, RtcChain** out);       // null on success, else the reason
+hipFunction_t rtc_kernel(RtcChain* c, int field_type, bool sweep);                   // compiled on first use; null: unavailable
+hipError_t rtc_launch(hipFunction_t f, unsigned blocks, hipStream_t stream, void** args, hipEvent_t done);
+const char* rtc_verify(RtcChain* c, const ChainDev& chain, int field_type_hint);     // generated code == this chain?
+const char* rtc_error(const RtcChain* c);
+void rtc_stats(const RtcChain* c, double* compile_s, int* compiled, int* from_cache);
+long long rtc_compile_check_c(const char* struct_src, int field_type, char* err, size_t err_len);   // compile only: bytes, or -1
 
 // ---------------------------------------------------------------------------------- launchers
 // (defined in the .hip files; all asynchronous on `stream`)

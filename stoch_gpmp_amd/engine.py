@@ -2,10 +2,29 @@
 tensors to raw device pointers and Python descriptors to the C structs; no arithmetic happens here.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib as L
+
+
+_CODEGEN = None
+
+
+def _chain_struct_source(chain):
+    """`struct ChainCode_rt { ... };` for `chain` from the generator that wrote the library's built-in chain code
+    (csrc/gen/chain_codegen.py: FK as straight-line code with folded joint constants, merged link frames, q-dependent pairs)."""
+    global _CODEGEN
+    if _CODEGEN is None:
+        import importlib.util
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "gen", "chain_codegen.py")
+        spec = importlib.util.spec_from_file_location("sgpmp_chain_codegen", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _CODEGEN = mod
+    norm = [(str(nm), str(kind), tuple(float(v) for v in rpy), tuple(float(v) for v in xyz)) for nm, kind, rpy, xyz in chain]
+    return "\n".join(_CODEGEN.gen_chain("rt", norm)) + "\n"
 
 
 class Engine:
@@ -241,8 +260,11 @@ class Engine:
         with torch.cuda.device(self.device):
             L.check(self.lib.sgpmp_set_costs(self._ctx, arr, len(descs)))
 
-    def set_fk(self, chain):
-        """chain: list of (name, 'revolute'|'fixed', rpy, xyz)."""
+    def set_fk(self, chain, codegen=True):
+        """chain: list of (name, 'revolute'|'fixed', rpy, xyz).  codegen: for a chain the library was not built with, also
+        generate its straight-line code (csrc/gen/chain_codegen.py) and have the library compile its fast launches at run
+        time (sgpmp_set_fk_codegen); where that is impossible the chain keeps the slower run-time-constant kernels and
+        `fk_codegen_error` says why."""
         arr = (L.Joint * len(chain))()
         for i, (_, kind, rpy, xyz) in enumerate(chain):
             arr[i].rpy = (C.c_double * 3)(*[float(v) for v in rpy])
@@ -251,6 +273,24 @@ class Engine:
         with torch.cuda.device(self.device):
             L.check(self.lib.sgpmp_set_fk(self._ctx, arr, len(chain)))
         self.n_links = len(chain) + 1
+        self.fk_codegen_error = None
+        if codegen and self.fk_codegen_info()[0] == 0 and self.dtype == torch.float32 and self.n <= 7 \
+                and not os.environ.get("SGPMP_NO_RTC"):
+            try:
+                src = _chain_struct_source(chain)
+                with torch.cuda.device(self.device):
+                    L.check(self.lib.sgpmp_set_fk_codegen(self._ctx, src.encode()))
+            except (ValueError, RuntimeError, L.SgpmpError) as e:        # the chain stays on the slower kernels
+                self.fk_codegen_error = str(e)
+                import warnings
+                warnings.warn(f"stoch_gpmp_amd: no run-time chain code for this robot ({e}); using the generic cost sweep")
+
+    def fk_codegen_info(self):
+        """(codegen_id, seconds in hiprtc, code objects compiled, taken from the disk cache); codegen_id: 0 run-time
+        constants, 1 the code built with the library (Panda), 2 compiled at run time (include/sgpmp.h)."""
+        cid, cs, nc, nf = C.c_int(), C.c_double(), C.c_int(), C.c_int()
+        L.check(self.lib.sgpmp_fk_codegen_info(self._ctx, C.byref(cid), C.byref(cs), C.byref(nc), C.byref(nf)))
+        return cid.value, cs.value, nc.value, nf.value
 
     # ------------------------------------------------------------------ kernels
     def _chk(self, t, name):

@@ -36,7 +36,7 @@ class URDFChain:
         key = (dtype, str(device))
         if key not in self._engines:
             eng = Engine(self._n_dofs, 2, 0, 1, tensor_args={"device": device, "dtype": dtype})
-            eng.set_fk(self.chain)
+            eng.set_fk(self.chain, codegen=False)           # (frames only: no sweep kernels to compile)
             self._engines[key] = eng
         return self._engines[key]
 

@@ -8,7 +8,7 @@ from stoch_gpmp_amd.costs.cost_functions import (CostCollision, CostComposite, C
                                                  CostGoalPrior)
 from stoch_gpmp_amd.costs.fields import LinkDistanceField, LinkSelfDistanceField
 from stoch_gpmp_amd.planner import StochGPMP
-from stoch_gpmp_amd.robots.panda import DifferentiableFrankaPanda
+from stoch_gpmp_amd.robots.panda import DifferentiableFrankaPanda, URDFChain
 
 
 PLANAR = dict(n_dof=2, dt=0.02, start=[-9., -9., 0., 0.],
@@ -65,12 +65,13 @@ def hip_planar_planner(c, T, goals, nppg, S, obst_map, ta, initial_particle_mean
 
 
 def hip_panda_cost(c, T, nppg, S, ta, field_type='rbf', goals=None, with_self=True,
-                   with_spheres=True, clamp_sdf=False):
+                   with_spheres=True, clamp_sdf=False, chain=None):
     n = c["n_dof"]
     start = torch.tensor(c["start_q"] + [0.] * n, **ta)
     goals_t = torch.tensor([c["goal_q"] + [0.] * n], **ta) if goals is None \
         else torch.as_tensor(goals).to(**ta)
-    fk = DifferentiableFrankaPanda(gripper=False, device=ta["device"])
+    fk = DifferentiableFrankaPanda(gripper=False, device=ta["device"]) if chain is None \
+        else URDFChain(chain, device=ta["device"])             # (any serial chain: c["n_dof"] revolute joints)
     terms = [
         CostGP(n, T, start, c["dt"], dict(sigma_start=c["cost_sigma_start"],
                                           sigma_gp=c["cost_sigma_gp"]), ta),
@@ -89,11 +90,11 @@ def hip_panda_cost(c, T, nppg, S, ta, field_type='rbf', goals=None, with_self=Tr
 
 
 def hip_panda_planner(c, T, nppg, S, ta, field_type='rbf', seed=None, noise='philox', goals=None,
-                      initial_particle_means=None, **kw):
+                      initial_particle_means=None, chain=None, **kw):
     n = c["n_dof"]
     goals_t = torch.tensor([c["goal_q"] + [0.] * n], **ta) if goals is None \
         else torch.as_tensor(goals).to(**ta)
-    cost = hip_panda_cost(c, T, nppg, S, ta, field_type=field_type, goals=goals_t)
+    cost = hip_panda_cost(c, T, nppg, S, ta, field_type=field_type, goals=goals_t, chain=chain)
     return StochGPMP(
         num_particles_per_goal=nppg, num_samples=S, traj_len=T, opt_iters=1, dt=c["dt"], n_dof=n,
         step_size=c["step_size"], temperature=c["temperature"],

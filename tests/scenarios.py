@@ -41,8 +41,11 @@ def oracle_planar_planner(c, T, goals, nppg, S, grid, cell_size, c_offset, dtype
 
 
 def oracle_panda_cost(c, T, nppg, S, dtype, field_type='rbf', goals=None, with_self=True,
-                      with_spheres=True):
+                      with_spheres=True, chain=None):
     from oracle.fk import fk_all_links
+    if chain is not None:                                # any serial chain (same URDF semantics, oracle/fk.py)
+        import functools
+        fk_all_links = functools.partial(fk_all_links, chain=chain)
     n = c["n_dof"]
     start = torch.tensor(c["start_q"] + [0.] * n, dtype=dtype)
     goals_t = torch.tensor([c["goal_q"] + [0.] * n], dtype=dtype) if goals is None \
@@ -63,11 +66,11 @@ def oracle_panda_cost(c, T, nppg, S, dtype, field_type='rbf', goals=None, with_s
 
 
 def oracle_panda_planner(c, T, nppg, S, dtype=torch.float64, field_type='rbf', seed=None,
-                         eps_init=None, goals=None):
+                         eps_init=None, goals=None, chain=None):
     n = c["n_dof"]
     goals_t = torch.tensor([c["goal_q"] + [0.] * n], dtype=dtype) if goals is None \
         else torch.as_tensor(goals, dtype=dtype)
-    cost = oracle_panda_cost(c, T, nppg, S, dtype, field_type=field_type, goals=goals_t)
+    cost = oracle_panda_cost(c, T, nppg, S, dtype, field_type=field_type, goals=goals_t, chain=chain)
     return R.OraclePlanner(
         nppg, S, T, c["dt"], n, torch.tensor(c["start_q"] + [0.] * n, dtype=dtype), goals_t,
         cost, c["step_size"], c["temperature"],

@@ -295,6 +295,34 @@ def test_hand_placed_loads_are_not_touched_before_their_wait():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    # 8 = fused_step_kernel x 3 field types + cost_sweep_chunked_kernel x 3 + fused_planar_kernel x 2 (n = 2, 3)
-    # (an EXPERIMENTS=1 build adds the three fused_step_kernel instantiations with the in-launch update: 11)
-    assert re.search(r"\b8 kernels audited, \d+ hand-placed loads, 0 offending", r.stdout), r.stdout
+    # 11 = fused_step_kernel x 3 field types x {one wave per workgroup, four} + cost_sweep_chunked_kernel x 3
+    # + fused_planar_kernel x 2 (n = 2, 3)   (an EXPERIMENTS=1 build adds three more with the in-launch update)
+    assert re.search(r"\b11 kernels audited, \d+ hand-placed loads, 0 offending", r.stdout), r.stdout
+
+
+def test_run_time_chain_code_compiles_for_gfx950_without_a_device():
+    """csrc/chain_rtc.hip: the chain kernels of a robot the library was not built for -- the host generates
+    `struct ChainCode_rt` (csrc/gen/chain_codegen.py) and the library compiles cost_device.h + fused_step.inc around it with
+    hiprtc.  Compilation needs no GPU, so the build container can hold the kernel sources to "still includable by the
+    run-time translation unit" (no host library headers, no host declarations under __HIPCC_RTC__): a 6-DoF and a 7-DoF
+    chain, all three sphere-field types; and broken chain code comes back as SGPMP_ESTATE with the compiler's log."""
+    import ctypes as C
+    from stoch_gpmp_amd import _lib
+    from stoch_gpmp_amd.engine import _chain_struct_source
+    from stoch_gpmp_amd.robots.panda_chain import PANDA_CHAIN
+    lib = _lib.load()
+    h = 1.57079632679
+    arm6 = [("j1", "revolute", (0, 0, 0), (0, 0, 0.1625)), ("j2", "revolute", (h, 0, 0), (0, 0, 0)),
+            ("j3", "revolute", (0, 0, 0), (-0.425, 0, 0)), ("j4", "revolute", (0, 0, 0), (-0.3922, 0, 0.1333)),
+            ("j5", "revolute", (h, 0, 0), (0, -0.0997, 0)), ("j6", "revolute", (-h, 0, 0), (0, 0.0996, 0)),
+            ("tool", "fixed", (0, 0, 0), (0, 0, 0.12))]
+    arm7 = [(nm, kind, rpy, (xyz[0] + (0.01 if i == 3 else 0.0), xyz[1], xyz[2])) for i, (nm, kind, rpy, xyz) in enumerate(PANDA_CHAIN)]
+    for chain, fts in ((arm6, (0, 1, 2)), (arm7, (0,))):
+        src = _chain_struct_source(chain)
+        assert "struct ChainCode_rt" in src and f"N = {sum(1 for j in chain if j[1] == 'revolute')};" in src
+        for ft in fts:
+            n = C.c_int64(0)
+            rc = lib.sgpmp_fk_codegen_compile(src.encode(), ft, C.byref(n))
+            assert rc == _lib.OK and n.value > 10000, (rc, _lib.last_error()[:2000])
+    rc = lib.sgpmp_fk_codegen_compile(b"struct ChainCode_rt { static constexpr int N = 7; };", 0, None)
+    assert rc == _lib.ESTATE and "hiprtc" in _lib.last_error()
