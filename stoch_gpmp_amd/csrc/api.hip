@@ -92,6 +92,9 @@ struct sgpmp_ctx {
     hipStream_t ms_side = nullptr;   // the side stream when no communicator is attached
     bool ms_used[2] = {false, false};
     unsigned long long ms_step = 0;
+    // dense-weight regime of the update: softmax partials of the fused launch + per-particle row counts (FusedArgs::part)
+    float* d_part = nullptr;         // [P][S / 8][4 + M], allocated by the first step that can use it
+    unsigned* d_nnz = nullptr;       // [P]
     int last_step_launches = 0;      // kernels the last sgpmp_step enqueued for its particle range (1: everything in one launch)
     hipStream_t k1_side = nullptr;   // sgpmp_set_priors: the second factorisation's stream
     hipEvent_t k1_fork = nullptr;
@@ -106,6 +109,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
     {"tail_update", &SgpmpToggles::tail_update}, {"small_step", &SgpmpToggles::small_step}, {"comm_packet_event", &SgpmpToggles::comm_packet_event},
     {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"no_wave_groups", &SgpmpToggles::no_wave_groups},
+    {"no_dense_partials", &SgpmpToggles::no_dense_partials},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {
@@ -349,6 +353,7 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     free_prior(c->prior[1]);
     hipFree(c->d_qc); hipFree(c->d_prog); hipFree(c->d_chain); hipFree(c->d_isw);
     hipFree(c->d_costs64); hipFree(c->d_arrive); hipFree(c->d_done); hipFree(c->d_tail_acc);
+    hipFree(c->d_part); hipFree(c->d_nnz);
     if (c->ms_side) { hipStreamSynchronize(c->ms_side); hipStreamDestroy(c->ms_side); }
     for (int i = 0; i < 2; ++i) { hipFree(c->ms_snap[i]); if (c->ms_read[i]) hipEventDestroy(c->ms_read[i]); }
     if (c->ms_ready) hipEventDestroy(c->ms_ready);
@@ -903,6 +908,38 @@ extern "C" int sgpmp_update(sgpmp_ctx* c, const void* costs, int costs_dtype, co
     return SGPMP_OK;
 }
 
+// Buffers of the dense-weight regime (allocated once, by the first step that may leave partials: fp32, S a multiple of 8).
+// Particles whose previous update spread its weight over more than S / 4 rows get partials (a fused wave pays ~6 % for them,
+// the update reads S / 8 rows instead of nnz).
+static int dense_buffers(sgpmp_ctx* c, FusedDenseHost* d, double temperature) {
+    const sgpmp_dims& D = c->dims;
+    d->part = nullptr; d->nnz = nullptr; d->threshold = (unsigned)(D.num_samples / 4); d->temperature = temperature;
+    if (D.dtype != SGPMP_F32 || D.num_samples % 8 != 0 || c->tg.no_dense_partials || D.num_particles < 1) return SGPMP_OK;
+    if (!c->d_part) {
+        const size_t P = (size_t)D.num_particles;
+        HIPCHK(hipMalloc(&c->d_part, P * (size_t)(D.num_samples / 8) * (size_t)(c->M + 4) * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_nnz, P * sizeof(unsigned)));
+        HIPCHK(hipMemset(c->d_nnz, 0, P * sizeof(unsigned)));
+    }
+    d->part = c->d_part; d->nnz = c->d_nnz;
+    return SGPMP_OK;
+}
+
+// Diagnostic (synchronous): how many particles' last update spread its weight over more than S / 4 samples -- the
+// particles for which the NEXT fused launch leaves softmax partials (dense-weight regime).  -1 before the buffers exist.
+extern "C" int sgpmp_dense_particles(sgpmp_ctx* c, int64_t* count) {
+    if (!c || !count) return fail(SGPMP_EINVAL, "sgpmp_dense_particles: null argument");
+    *count = -1;
+    if (!c->d_nnz) return SGPMP_OK;
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<unsigned> nnz((size_t)c->dims.num_particles);
+    HIPCHK(hipMemcpy(nnz.data(), c->d_nnz, nnz.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    int64_t k = 0;
+    for (unsigned v : nnz) k += v > (unsigned)(c->dims.num_samples / 4) ? 1 : 0;
+    *count = k;
+    return SGPMP_OK;
+}
+
 // ---- two-chain steps (StepPipe) ----------------------------------------------------------------------------
 static int pipe_first_half(const sgpmp_ctx* c) {
     const long long s = (c->tg.pipe_split >= 1 && c->tg.pipe_split <= 15) ? c->tg.pipe_split : 8;
@@ -998,9 +1035,13 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
         // the update inside the launch when the half qualifies (its last particle writes the statistics into `slot`)
         FusedTailHost th = {c->d_arrive + off, c->d_done + h, c->d_tail_acc + (size_t)h * SGPMP_STAT_SHARDS * 4, slot, wh, gh, mph,
                             temperature, step_size};
+        FusedDenseHost dh;
+        if ((rc = dense_buffers(c, &dh, temperature)) != SGPMP_OK) return rc;
+        if (dh.part) { dh.part += off * (size_t)(S / 8) * (size_t)(c->M + 4); dh.nnz += off; }
+        bool armed = false;
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, mu, Ph,
                                  D.particle_offset + (int)off, S, X, spheres, n_spheres, isw, slot, cs, c64, sh, c->tg,
-                                 &c->last_cost_kernel, &launched, &th, k4_done[h], &tail[h]));
+                                 &c->last_cost_kernel, &launched, &th, k4_done[h], &tail[h], &dh, &armed));
         if (!launched) return fail(SGPMP_ESTATE, "sgpmp_step: a half of a pipelined step did not qualify for the fused launch");
         c->last_step_launches = 1;
         if (tail[h]) continue;
@@ -1011,7 +1052,8 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
                 c->last_step_launches += 1;
             }
         HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, Ph, S, c64, SGPMP_F64, X, mu, temperature, step_size, wh, gh, mph,
-                             slot, sh, c->tg.comm_packet_event ? k4_done[h] : nullptr, &pr, isw, &tail[h]));
+                             slot, sh, c->tg.comm_packet_event ? k4_done[h] : nullptr, &pr, isw, &tail[h], nullptr,
+                             armed ? dh.part : nullptr, dh.nnz, dh.threshold));
         if (!c->tg.comm_packet_event && k4_done[h]) HIPCHK(hipEventRecord(k4_done[h], sh));
         c->last_step_launches += 1;
     }
@@ -1140,14 +1182,17 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         return SGPMP_OK;
     }
     bool tail_ran = false;                                       // the update ran inside the fused launch
+    FusedDenseHost dense = {nullptr, nullptr, 0u, temperature};   // softmax partials for the dense-weight regime of the update
+    bool partials = false;
     if (fused) {
         if (se) { HIPCHK(hipEventRecord(se->ev[2], st)); se->has[1] = false; }   // (fused: the whole launch is booked on the sweep)
         // ... and the update too when the step qualifies (fused_tail.inc): ONE launch per iteration
         FusedTailHost th = {c->d_arrive, c->d_done, c->d_tail_acc, acc_stats, weights, grad, means_prev, temperature, step_size};
+        if ((rc = dense_buffers(c, &dense, temperature)) != SGPMP_OK) return rc;
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, means, P,
                                  D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, acc_stats, costs,
                                  c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, c->ms_buf ? nullptr : &th, k4_done,
-                                 &tail_ran));
+                                 &tail_ran, &dense, &partials));
         if (fused) c->last_step_launches += 1;
         for (int i = 0; fused && i < c->h_prog.n_terms; ++i)
             if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) {
@@ -1179,7 +1224,8 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
                              temperature, step_size, weights, grad, means_prev, acc_stats, st,
                              c->tg.comm_packet_event ? k4_done : nullptr, &pr, c->d_isw,
-                             &isw_written, c->ms_buf ? c->ms_snap[slot] : nullptr));
+                             &isw_written, c->ms_buf ? c->ms_snap[slot] : nullptr,
+                             (fused && partials) ? dense.part : nullptr, dense.nnz, dense.threshold));
         if (!c->tg.comm_packet_event && k4_done) HIPCHK(hipEventRecord(k4_done, st));
         c->last_step_launches += 1;
         if (c->ms_buf) {

@@ -238,9 +238,11 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                              int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
                              const void* isw, double* zero_stats, void* costs, double* costs64,
                              hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched,
-                             const FusedTailHost* tail, hipEvent_t done, bool* tail_ran) {
+                             const FusedTailHost* tail, hipEvent_t done, bool* tail_ran, const FusedDenseHost* dense,
+                             bool* partials_armed) {
     *launched = false;
     if (tail_ran) *tail_ran = false;
+    if (partials_armed) *partials_armed = false;
     using CCp = ChainCode_panda;
     const int kind = (!samples || !isw) ? 0 : fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
     if (kind == 0) return hipSuccess;
@@ -260,6 +262,13 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     fs.seed = seed; fs.draw = draw; fs.mode_offset = mode_offset; fs.S = S;
     fs.gpp = S / SGPMP_FUSED_SPW; fs.gpp_shift = log2_exact(fs.gpp);
     fs.zero_stats = zero_stats;
+    fs.part = nullptr; fs.nnz_prev = nullptr; fs.nnz_threshold = 0u; fs.inv_temperature = 0.f;
+    // softmax partials for the dense-weight regime of the update: chain-code launch whose costs are complete inside it
+    if (kind == 1 && dense && dense->part && dense->nnz && h_prog.n_ee == 0 && !tg.no_dense_partials && (T * 2 * n) % 4 == 0) {
+        fs.part = dense->part; fs.nnz_prev = dense->nnz; fs.nnz_threshold = dense->threshold;
+        fs.inv_temperature = (float)(1. / dense->temperature);
+        if (partials_armed) *partials_armed = true;
+    }
     std::memset(&fs.tail, 0, sizeof(fs.tail));
     if (tail && fused_tail_eligible(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg)) {
         TailArgs& t = fs.tail;
@@ -270,6 +279,8 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         t.temperature = tail->temperature; t.step_size = tail->step_size; t.isotropic = prior.isotropic; t.P = P;
         t.debug = (int)tg.tail_debug;
         fs.zero_stats = nullptr;                              // (the launch's last particle writes the statistics)
+        fs.part = nullptr;                                    // (the in-launch update gathers its rows itself)
+        if (partials_armed) *partials_armed = false;
     }
     const long long nitems = batch / SGPMP_FUSED_SPW;
     long long blocks = (nitems + 3) / 4;

@@ -116,6 +116,7 @@ struct SgpmpToggles {
     int no_fused_step;        // SGPMP_NO_FUSED_STEP        K2 and K3 as separate kernels inside sgpmp_step
     int no_chunked_sweep;     // SGPMP_NO_CHUNKED_SWEEP     64-lane-pass two-trajectory sweeps instead of the chunked one
     int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
+    int no_dense_partials;    // SGPMP_NO_DENSE_PARTIALS    update_kernel re-reads all rows with weight even when the weights are spread (round 3)
     int no_wave_groups;       // SGPMP_NO_WAVE_GROUPS       fused launch / chunked sweep as 256-thread workgroups (round 2-3) instead of one wave each
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
     long long planar_slabs;   // SGPMP_PLANAR_SLABS         time slabs of the planar one-launch step: 0 none (fused_planar_kernel, default), 2, 4 (fused_planar_slab.inc, where the shape allows)
@@ -182,6 +183,13 @@ hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const
                        double* costs64, hipStream_t stream, const SgpmpToggles& tg, const char** picked);
 
 // K4 inside the fused launch (fused_tail.inc): what the host hands over; null = update_kernel follows the launch
+// Dense-weight regime of the update (FusedArgs::part): buffers the fused launch may leave softmax partials in
+struct FusedDenseHost {
+    float* part;                  // [P][S / 8][4 + T d]
+    unsigned* nnz;                // [P] rows with weight in each particle's previous update
+    unsigned threshold;           // partials for particles with nnz above it
+    double temperature;
+};
 struct FusedTailHost {
     unsigned* arrive;             // [P] arrival counters of the launch's particles (zero between launches)
     unsigned* done;               // finished-particle counter (zero between launches)
@@ -206,7 +214,8 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                              int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
                              const void* isw, double* zero_stats, void* costs, double* costs64,
                              hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched,
-                             const FusedTailHost* tail = nullptr, hipEvent_t done = nullptr, bool* tail_ran = nullptr);
+                             const FusedTailHost* tail = nullptr, hipEvent_t done = nullptr, bool* tail_ran = nullptr,
+                             const FusedDenseHost* dense = nullptr, bool* partials_armed = nullptr);
 bool planar_seg_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
                      int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg);
 // does the step qualify for the fused launch? (same conditions, no launch)
@@ -222,7 +231,8 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
                          hipStream_t stream, hipEvent_t done = nullptr, const PriorDev* isw_prior = nullptr,
-                         void* isw_next = nullptr, bool* isw_written = nullptr, void* means_copy = nullptr);
+                         void* isw_next = nullptr, bool* isw_written = nullptr, void* means_copy = nullptr,
+                         const float* part = nullptr, unsigned* nnz = nullptr, unsigned nnz_threshold = 0);
 
 hipError_t launch_stats_add(double* dst, const double* src, hipStream_t stream);
 hipError_t launch_mode_stats(int dtype, int n, int T, int P, long long p_offset, int nppg, int G, const void* means,

@@ -107,7 +107,8 @@ __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_
                                                 real* __restrict__ means, double temperature, double step_size,
                                                 real* __restrict__ weights, real* __restrict__ grad, real* __restrict__ means_prev,
                                                 double* __restrict__ stats, const IswNext<real>& nx, real* __restrict__ means_copy,
-                                                unsigned char* lds_raw, const real* mu_rd = nullptr) {
+                                                unsigned char* lds_raw, const real* mu_rd = nullptr,
+                                                const float* __restrict__ partials = nullptr, int gpp = 0, unsigned* __restrict__ nnz_out = nullptr) {
     typedef real vec __attribute__((ext_vector_type(VW)));
     double* w = reinterpret_cast<double*>(lds_raw);                  // [S] weights
     int* idx = reinterpret_cast<int*>(lds_raw + (size_t)S * 8);      // [S] samples with weight != 0
@@ -204,6 +205,16 @@ __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_
     }
     __syncthreads();
     const int nnz = nnz_s;
+    if (nnz_out && threadIdx.x == 0) *nnz_out = (unsigned)nnz;        // (the next step's fused launch decides on it: FusedArgs::nnz_prev)
+    // Dense-weight regime: the fused launch left softmax partials of the particle's gpp = S / 8 row groups (FusedArgs::part):
+    // sum_s w_s (x_s - mu) = sum_j [exp(-cmin_j / temperature - zmax) / Z] acc_j -- gpp rows instead of nnz
+    const bool use_part = sizeof(real) == 4 && VW == 4 && partials != nullptr && nnz > gpp;
+    double* coef = reinterpret_cast<double*>(idx);                  // [gpp] (the compacted indices are not needed on this path)
+    if (use_part) {
+        for (int j = tid; j < gpp; j += nthr)
+            coef[j] = exp(-(double)partials[(size_t)j * (M + 4)] / temperature - zmax) * invZ;
+        __syncthreads();
+    }
 
     real* mu = means + (size_t)p * M;
     for (int m = tid < nthr ? tid * VW : M; m < M; m += nthr * VW) {
@@ -212,6 +223,26 @@ __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_
 #pragma unroll
         for (int i = 0; i < VW; ++i) acc[i] = 0.;
         int k = 0;
+        if (use_part) {
+            if constexpr (sizeof(real) == 4 && VW == 4) {
+                for (int j = 0; j < gpp; j += 4) {           // (gpp is a multiple of ... any count: the tail below)
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    f4 v[4];
+                    double cj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int jj = j + u < gpp ? j + u : gpp - 1;
+                        cj[u] = j + u < gpp ? coef[jj] : 0.;
+                        v[u] = *reinterpret_cast<const f4*>(partials + (size_t)jj * (M + 4) + 4 + m);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int i = 0; i < VW; ++i) acc[i] = fma(cj[u], (double)v[u][i], acc[i]);
+                }
+            }
+            k = nnz;                                     // (skip the row gather)
+        }
         for (; k + 4 <= nnz; k += 4) {                   // four rows in flight per thread
             vec v[4];
             double ws[4];
@@ -264,10 +295,16 @@ __global__ void __launch_bounds__(256)
 update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __restrict__ samples,
               real* __restrict__ means, double temperature, double step_size,
               real* __restrict__ weights, real* __restrict__ grad, real* __restrict__ means_prev,
-              double* __restrict__ stats, IswNext<real> nx, real* __restrict__ means_copy) {
+              double* __restrict__ stats, IswNext<real> nx, real* __restrict__ means_copy,
+              const float* __restrict__ part, int gpp, unsigned* __restrict__ nnz, unsigned nnz_threshold) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int p = blockIdx.x;
+    // partials of this particle exist iff the fused launch of THIS step saw nnz[p] above the threshold: the same word,
+    // read here before this particle's new count replaces it
+    const float* part_p = nullptr;
+    if (part && nnz && nnz[p] > nnz_threshold) part_p = part + (size_t)p * gpp * (M + 4);
     update_particle<real, cost_t, VW>(p, M, S, costs + (size_t)p * S, samples + (size_t)p * S * M, (size_t)M, means, temperature,
-                                      step_size, weights, grad, means_prev, stats, nx, means_copy, lds_raw);
+                                      step_size, weights, grad, means_prev, stats, nx, means_copy, lds_raw, nullptr, part_p, gpp,
+                                      nnz ? nnz + p : nullptr);
 }
 

@@ -81,6 +81,12 @@ class Engine:
         """Kernels the last step enqueued for its particle range (1: the whole iteration in one launch)."""
         return int(self.lib.sgpmp_last_step_launches(self._ctx))
 
+    def dense_particles(self):
+        """Particles whose last in-step update spread its weight over more than S / 4 samples (include/sgpmp.h)."""
+        k = C.c_int64()
+        L.check(self.lib.sgpmp_dense_particles(self._ctx, C.byref(k)))
+        return k.value
+
     def last_cost_kernel(self):
         """Name of the cost-sweep kernel the dispatcher picked at the last launch."""
         return self.lib.sgpmp_last_cost_kernel(self._ctx).decode()

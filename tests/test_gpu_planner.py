@@ -618,6 +618,55 @@ def test_config2_free_running_ten_iterations_against_the_dense_oracle(golden):
     assert rec["tracking_fraction_per_iteration"][0] == 1.0
 
 
+# --------------------------------------------------------------------------- dense-weight regime of the update
+def test_dense_weight_update_adds_partials_of_the_fused_launch_instead_of_rereading_the_rows():
+    """planner.py:263-275 is a softmax.  With the reference's hyper-parameters it is one-hot and update_kernel reads one row;
+    at a temperature where many samples carry weight, round 3's update re-read every such row.  Now the fused launch leaves a
+    softmax partial per 8 rows for the particles whose PREVIOUS update was spread (device-side count, no host round trip) and
+    the update adds S / 8 partials: same means / gradient / weights as the row-reading update (`no_dense_partials`) to 1e-6,
+    and both follow the fp64 oracle at that temperature."""
+    from oracle.native_noise import native_eps
+    n, T, nppg, S, seed = 7, 32, 24, 64, 23
+    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=seed))
+    found = None
+    for temp in (1e7, 1e9, 1e11, 1e13):
+        c = dict(SC.PANDA, temperature=temp)
+        a = hip_panda_planner(c, T, nppg, S, F32, seed=seed)
+        for _ in range(2):
+            a.optimize(opt_iters=1, obstacle_spheres=sph.to(**F32))
+        k = a._engine.dense_particles()
+        print(f"\n[dense-weight regime] temperature {temp:g}: {k} of {nppg} particles spread their weight over more than S / 4 samples")
+        if k >= nppg // 2:
+            found = (temp, c)
+            break
+    assert found is not None, "no temperature of the scan spreads the weights: the test needs another scenario"
+    temp, c = found
+    a = hip_panda_planner(c, T, nppg, S, F32, seed=seed)
+    b = hip_panda_planner(c, T, nppg, S, F32, seed=seed)
+    b._engine.set_option("no_dense_partials", 1)
+    eps0 = torch.from_numpy(native_eps(seed, 0, range(1), nppg, T, n, "float32")).double()
+    ora = SC.oracle_panda_planner(c, T, nppg, S, seed=seed, eps_init=eps0)
+    scale = float(a.particle_means.abs().max())
+    used = 0
+    for it in range(5):
+        b.particle_means.copy_(a.particle_means)
+        ora.particle_means.copy_(a.particle_means.cpu().double())
+        ora.prior.set_mean(ora.particle_means.view(nppg, -1))
+        eps = torch.from_numpy(native_eps(seed, 2 + it, range(nppg), S, T, n, "float32")).double()
+        costs_o, grad_o = ora.step(eps=eps, obstacle_spheres=sph)
+        _, _, _, _, ca, ga = a.optimize(opt_iters=1, obstacle_spheres=sph.to(**F32))
+        _, _, _, _, cb, gb = b.optimize(opt_iters=1, obstacle_spheres=sph.to(**F32))
+        assert a._engine.last_cost_kernel() == "fused_step_kernel" and torch.equal(ca, cb)
+        assert float((a.particle_means - b.particle_means).abs().max()) <= 1e-6 * scale, it
+        assert float((ga - gb).abs().max()) <= 1e-6 * max(float(gb.abs().max()), 1e-30) + 1e-7 * scale, it
+        assert torch.allclose(a._weights, b._weights, rtol=0, atol=1e-7)
+        # the oracle at this temperature: soft weights make the means a smooth function of the costs
+        assert rel_err(ca, costs_o) < 5e-3
+        assert float((a.particle_means.cpu().double() - ora.particle_means).abs().max()) < 1e-3 * scale, it
+        used = max(used, a._engine.dense_particles())
+    assert used >= nppg // 2 and b._engine.dense_particles() == -1
+
+
 # --------------------------------------------------------------------------- any serial chain on the fast launches
 # The reference takes any FK callable (cost_functions.py:39,51-52).  The library is built with straight-line chain code for
 # the Panda only; another chain's code is generated by the host (csrc/gen/chain_codegen.py) and compiled by the library at

@@ -19,14 +19,16 @@ c = pl._costs.reshape(-1, 8).double().cpu()          # [item = wave][slot]
 names = ["phase A (noise + recurrence)", "wait + phase B (x = mu + y, stores)", "phase C loads + quadratic forms",
          "kinematics + fields", "whole item"]
 tot = c[:, 4]
+xcc_all = (c[:, 6].long() >> 16).double()
 print(f"{c.shape[0]} waves, {T // 16} chunks each; whole item: median {tot.median():.0f}, mean {tot.mean():.0f}, max {tot.max():.0f} cycles")
 for i, n in enumerate(names[:4]):
     print(f"  {n:38s} median {c[:, i].median():8.0f}  mean {c[:, i].mean():8.0f}  ({100 * c[:, i].mean() / tot.mean():5.1f} % of the item)  per chunk {c[:, i].mean() / (T // 16):7.0f}")
-print(f"  {'outside the stamped phases':38s} mean {(tot - c[:, :4].sum(1)).mean():8.0f}")
+print(f"  {'prologue (kernel entry -> first chunk)':38s} median {c[:, 7].median():8.0f}  mean {c[:, 7].mean():8.0f}  ({100 * c[:, 7].mean() / tot.mean():5.1f} % of the wave)")
+print(f"  {'epilogue / unstamped':38s} mean {(tot - c[:, :4].sum(1) - c[:, 7]).mean():8.0f}")
 start = c[:, 5]
 rel = torch.zeros_like(start)                          # (per XCD: the cycle counters of different XCDs need not agree)
-for x in c[:, 7].unique():
-    m = c[:, 7] == x
+for x in xcc_all.unique():
+    m = xcc_all == x
     # 24-bit stamps may wrap inside the launch: the origin is the start that follows the largest circular gap
     cand = start[m]
     srt, _ = torch.sort(cand)
@@ -36,8 +38,8 @@ for x in c[:, 7].unique():
 print(f"wave starts after the first: median {rel.median():.0f}, 90 % {rel.quantile(0.9):.0f}, max {rel.max():.0f} cycles")
 
 # ---- occupancy timeline per SIMD: (xcd, se, sh, cu, simd) from HW_ID / XCC_ID
-hw = c[:, 6].long()
-xcc = c[:, 7].long()
+hw = c[:, 6].long() & 0xffff
+xcc = c[:, 6].long() >> 16
 simd_key = (xcc << 16) | (hw & 0xfff0)                # everything but the wave slot
 slot = hw & 0xf
 import collections
@@ -61,6 +63,6 @@ occ = torch.tensor(occ); gaps = torch.tensor(gaps) if gaps else torch.zeros(1); 
 print(f"launch span (first wave start .. last wave end) {span:.0f} cycles = {span / 2.3e3:.1f} us at 2.3 GHz")
 print(f"waves resident per SIMD, time-averaged over the span: mean {occ.mean():.2f}, min {occ.min():.2f}, max {occ.max():.2f}")
 print(f"first wave of a SIMD starts: median {first.median():.0f}, max {first.max():.0f}; last wave of a SIMD ends: median {last.median():.0f}, min {last.min():.0f} (span {span:.0f})")
-print(f"gap between a wave's end and the next wave's start in the same slot: median {gaps.median():.0f}, mean {gaps.mean():.0f}, 90 % {gaps.quantile(0.9):.0f}, max {gaps.max():.0f} cycles ({len(gaps)} gaps)")
+print(f"gap between a wave's last stamp and the ENTRY of the next wave in the same slot (store drain at s_endpgm + dispatch): median {gaps.median():.0f}, mean {gaps.mean():.0f}, 90 % {gaps.quantile(0.9):.0f}, max {gaps.max():.0f} cycles ({len(gaps)} gaps)")
 slots_used = sorted(set(int(x) for x in slot))
 print("wave slots used:", slots_used)
