@@ -629,13 +629,18 @@ def test_dense_weight_update_adds_partials_of_the_fused_launch_instead_of_reread
     n, T, nppg, S, seed = 7, 32, 24, 64, 23
     sph = torch.as_tensor(SC.panda_spheres(num=5, seed=seed))
     found = None
-    for temp in (1e7, 1e9, 1e11, 1e13):
-        c = dict(SC.PANDA, temperature=temp)
+    # (the importance-sampling term temperature * x^T Sigma^-1 mu grows with the temperature: with the reference's stiff
+    # sampling prior the softmax stays one-hot at ANY temperature -- the weights spread only under a weak sampling prior)
+    soft = dict(sigma_start_sample=1.0, sigma_goal_sample=1.0, sigma_gp_sample=30.0)
+    for temp, extra in ((1e9, {}), (1e13, {}), (1e11, soft), (1e14, soft), (1e17, soft)):
+        c = dict(SC.PANDA, temperature=temp, **extra)
         a = hip_panda_planner(c, T, nppg, S, F32, seed=seed)
         for _ in range(2):
             a.optimize(opt_iters=1, obstacle_spheres=sph.to(**F32))
         k = a._engine.dense_particles()
-        print(f"\n[dense-weight regime] temperature {temp:g}: {k} of {nppg} particles spread their weight over more than S / 4 samples")
+        nz = float((a._weights_buf != 0).sum()) / nppg
+        print(f"\n[dense-weight regime] temperature {temp:g} {extra}: {k} of {nppg} particles spread their weight over more than "
+              f"S / 4 samples ({nz:.1f} rows with weight per particle)")
         if k >= nppg // 2:
             found = (temp, c)
             break
