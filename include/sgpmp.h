@@ -128,7 +128,7 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * environment variable SGPMP_<NAME> that is read ONCE, in sgpmp_create; this call changes a switch
  * on a live context.  Names: force_generic_fk, no_flat_program, no_chain_codegen, no_dual_sweep,
  * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, comm_packet_event,
- * no_dense_partials (dense-weight regime: update_kernel re-reads every row with weight, as in round 3),
+ * gpmp_cholesky (GPMP solve by round 3's LDS block-Cholesky kernel), no_dense_partials (dense-weight regime: update_kernel re-reads every row with weight, as in round 3),
  * no_wave_groups (fused launch / chunked sweep as 256-thread workgroups instead of one wave per workgroup),
  * no_planar_seg (planar one-launch step through the LDS tile, fused_planar_kernel, even where the lane-per-sample launch applies),
  * pipe_split (1..15) and k3_blocks (count); and, ONLY in a library built with `make EXPERIMENTS=1` (launches that

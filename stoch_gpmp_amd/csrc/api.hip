@@ -109,7 +109,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
     {"tail_update", &SgpmpToggles::tail_update}, {"small_step", &SgpmpToggles::small_step}, {"comm_packet_event", &SgpmpToggles::comm_packet_event},
     {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"no_wave_groups", &SgpmpToggles::no_wave_groups},
-    {"no_dense_partials", &SgpmpToggles::no_dense_partials},
+    {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {
@@ -1417,7 +1417,7 @@ extern "C" int sgpmp_gpmp_solve(sgpmp_ctx* c, void* means, const double* diag_su
     a.status = c->d_gstatus;
     a.inv_particles = 1.0 / (double)(c->dims.num_particles_global > 0 ? c->dims.num_particles_global : a.P);
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(launch_gpmp_solve(c->dims.dtype, a, means, d_theta, costs, st));
+    HIPCHK(launch_gpmp_solve(c->dims.dtype, a, means, d_theta, costs, st, c->tg.gpmp_cholesky != 0));
     int status = 0;                                   // synchronous, like sgpmp_set_prior: GPMP is not the hot path
     HIPCHK(hipMemcpyAsync(&status, c->d_gstatus, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -282,6 +282,224 @@ gpmp_solve_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_the
     }
 }
 
+// Block-Thomas form of the Gauss-Newton solve, the matrices in REGISTERS (round 4).
+//
+// The normal matrix is block-tridiagonal with diagonal blocks D_t (constant GP / unary part (x) I_n, + one rank-1 term per
+// link field on the position block, + damping) and the CONSTANT sub-diagonal block E = -Q^-1 Phi = E2 (x) I_n.  Forward:
+//     S_0 = D_0,  S_t = D_t - E M_{t-1} E^T,  r_t = g_t - E M_{t-1} r_{t-1},   M_t = S_t^-1
+// backward:  x_{T-1} = M_{T-1} r_{T-1},  x_t = M_t (r_t - E^T x_{t+1}).
+// One wave per particle, lane r < d holds ROW r of the current d x d matrix in registers:
+//   * E M E^T and E M r need no matrix product: E2 (x) I_n mixes row (pos, i) with row (vel, i) -- one exchange with the partner
+//     lane r +- n -- and column (pos, j) with column (vel, j) -- in-lane;
+//   * M_t = S_t^-1 by Gauss-Jordan elimination without pivoting (S_t is symmetric positive definite), the pivot row broadcast by
+//     v_readlane with literal lane numbers: no LDS, no barrier inside the elimination (round 3's column-by-column Cholesky
+//     through LDS paid two barriers and an fp64 sqrt + division per column, 14 us per waypoint; this is ~1.5 us);
+//   * M_t rows are parked for the backward sweep (d x d doubles per waypoint instead of two 16 x 16 tiles).
+template <typename real, int N>
+__global__ void __launch_bounds__(64)
+gpmp_thomas_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_theta, real* __restrict__ costs) {
+    constexpr int D = 2 * N;
+    extern __shared__ __align__(16) unsigned char gp_lds_raw[];
+    __shared__ double csum[64];
+    const int l = threadIdx.x, p = blockIdx.x;
+    const int T = a.T;
+    double* mu = reinterpret_cast<double*>(gp_lds_raw);   // [T][TS] means
+    double* y = mu + (size_t)T * TS;                      // [T][TS] r_t, then the solution
+    double* fv = y + (size_t)T * TS;                      // [F][T]    (index t-1)
+    double* fg = fv + (size_t)a.n_fields * T;             // [F][T][8]
+    real* mp = means + (size_t)p * T * D;
+    double* scr = a.scratch + (size_t)p * T * D * D;      // [T][D][D] M_t
+    for (int e = l; e < T * TS; e += 64) {
+        const int t = e / TS, i = e % TS;
+        mu[e] = i < D ? (double)mp[t * D + i] : 0.;
+    }
+    for (int f = 0; f < a.n_fields; ++f) {
+        for (int e = l; e < T - 1; e += 64) fv[f * T + e] = ld<real>(a.f[f].val, (size_t)p * (T - 1) + e);
+        for (int e = l; e < (T - 1) * N; e += 64) {
+            const int t1 = e / N, j = e - t1 * N;
+            fg[((size_t)f * T + t1) * 8 + j] = ld<real>(a.f[f].grad, ((size_t)p * (T - 1) + t1) * N + j);
+        }
+    }
+    __syncthreads();
+    const long long gi = a.Kg > 0. ? (a.p_offset + p) / a.rows_per_goal : 0;
+    const int r = l < D ? l : 0;                          // this lane's row (lanes >= D idle along)
+    const int k = r % N;
+    const bool pos = r < N;
+    const int partner = pos ? r + N : r - N;
+    // E2 = -K [[c11, c11 dt + c12], [c12, c12 dt + c22]]  (rows: pos, vel of the LATER waypoint; columns: of the earlier one)
+    const double e00 = -a.Kgp * a.c11, e01 = -a.Kgp * (a.c11 * a.dt + a.c12), e10 = -a.Kgp * a.c12, e11 = -a.Kgp * (a.c12 * a.dt + a.c22);
+    const double er0 = pos ? e00 : e10, er1 = pos ? e01 : e11;      // this lane's row of E2
+    // constant part of D_t, element (r, c): nonzero for c = k (pos column) and c = N + k (vel column) only
+    const double q_p = a.Kgp * (pos ? a.c11 : a.c12), q_v = a.Kgp * (pos ? a.c12 : a.c22);         // Q^-1 row
+    const double mm = a.c11 * a.dt + a.c12;
+    const double pq_p = a.Kgp * (pos ? a.c11 : mm), pq_v = a.Kgp * (pos ? mm : a.c11 * a.dt * a.dt + 2. * a.c12 * a.dt + a.c22);   // Phi^T Q^-1 Phi row
+    double M[D], EM[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) { M[c] = 0.; EM[c] = 0.; }
+    double rprev = 0., cost = 0.;
+    bool bad = false;
+
+    for (int t = 0; t < T; ++t) {
+        // ---- right-hand side g_t and the cost terms at waypoint t (as gpmp_solve_kernel)
+        double g = 0.;
+        {
+            if (t == 0 && a.Ks > 0.) {
+                const double e0 = ld<real>(a.start, r) - mu[r];
+                g += a.Ks * e0;
+                cost += a.Ks * e0 * e0;
+            }
+            if (t == T - 1 && a.Kg > 0.) {
+                const double eg = ld<real>(a.goals, (size_t)gi * D + r) - mu[t * TS + r];
+                g += a.Kg * eg;
+                cost += a.Kg * eg * eg;
+            }
+            if (t <= T - 2) {
+                const double ep = mu[(t + 1) * TS + k] - (mu[t * TS + k] + a.dt * mu[t * TS + N + k]);
+                const double ev = mu[(t + 1) * TS + N + k] - mu[t * TS + N + k];
+                const double qp = a.Kgp * (a.c11 * ep + a.c12 * ev), qv = a.Kgp * (a.c12 * ep + a.c22 * ev);
+                g += pos ? qp : a.dt * qp + qv;
+                cost += pos ? ep * qp : ev * qv;
+            }
+            if (t >= 1) {
+                const double ep = mu[t * TS + k] - (mu[(t - 1) * TS + k] + a.dt * mu[(t - 1) * TS + N + k]);
+                const double ev = mu[t * TS + N + k] - mu[(t - 1) * TS + N + k];
+                g -= a.Kgp * (pos ? a.c11 * ep + a.c12 * ev : a.c12 * ep + a.c22 * ev);
+                if (pos)
+                    for (int f = 0; f < a.n_fields; ++f) {
+                        const double fval = fv[f * T + t - 1];
+                        g += a.f[f].K * (-fg[((size_t)f * T + t - 1) * 8 + r]) * fval;
+                        if (r == 0) cost += a.f[f].K * fval * fval;
+                    }
+            }
+        }
+        // ---- EM = (E M_{t-1}) row r: e2[row][0] * M[(pos, k)][:] + e2[row][1] * M[(vel, k)][:]
+        double S[D];
+        if (t >= 1) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                const double other = __shfl(M[c], partner, 64);
+                const double mp_ = pos ? M[c] : other, mv_ = pos ? other : M[c];
+                EM[c] = er0 * mp_ + er1 * mv_;
+            }
+            // r_t = g_t - (E M_{t-1}) r_{t-1}
+            double acc = g;
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                const double rc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rprev), c),
+                                                   __builtin_amdgcn_readlane(__double2loint(rprev), c));
+                acc -= EM[c] * rc;
+            }
+            g = acc;
+            // S = - (E M E^T) row r:  column (beta, j) = e2[beta][0] EM[(pos, j)] + e2[beta][1] EM[(vel, j)]
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                S[j] = -(e00 * EM[j] + e01 * EM[N + j]);
+                S[N + j] = -(e10 * EM[j] + e11 * EM[N + j]);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < D; ++c) S[c] = 0.;
+        }
+        // ---- + D_t: constant part, link-field rank-1 terms on the position block, damping
+        {
+            double dk = 0., dnk = 0.;                     // elements (r, k) and (r, N + k) of the constant part
+            if (t >= 1) { dk += q_p; dnk += q_v; }
+            if (t <= T - 2) { dk += pq_p; dnk += pq_v; }
+            double diag_c = pos ? dk : dnk;               // element (r, r) of the constant part without the unary factors
+            if (t == 0) diag_c += a.Ks;
+            if (t == T - 1) diag_c += a.Kg;
+            const double damp = a.diag_sum ? a.delta * (diag_c + a.diag_sum[t * D + r] * a.inv_particles) : a.delta;
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double v = 0.;
+                if (c == k) v += dk;
+                if (c == N + k) v += dnk;
+                if (c == r) v += damp + (t == 0 ? a.Ks : 0.) + (t == T - 1 ? a.Kg : 0.);
+                S[c] += v;
+            }
+            if (t >= 1)
+                for (int f = 0; f < a.n_fields; ++f) {
+                    const double* h = fg + ((size_t)f * T + t - 1) * 8;
+                    const double hr = pos ? a.f[f].K * h[r] : 0.;
+#pragma unroll
+                    for (int c = 0; c < N; ++c) S[c] += hr * h[c];
+                }
+        }
+        // ---- M_t = S^-1: Gauss-Jordan without pivoting, pivot row by readlane (literal lanes).  Step kk, with row kk of
+        // the current matrix in SGPRs (rowk) and ip = 1 / pivot:   pivot lane: new[c] = rowk[c] ip (c != kk), new[kk] = ip;
+        // other lanes, f = their element of column kk:  new[c] = old[c] - (f ip) rowk[c] (c != kk), new[kk] = -f ip.
+        // One form for both: new[c] = A old[c] - fe rowk'[c] with rowk'[kk] = 1 and (A, fe) = (0, -ip) in the pivot lane,
+        // (1, f ip) elsewhere (old[kk] is dropped by A' = 0 in that column): a multiply and an FMA per element, no selects.
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) {
+            double rowk[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c)
+                rowk[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(S[c]), kk),
+                                           __builtin_amdgcn_readlane(__double2loint(S[c]), kk));
+            const double piv = rowk[kk];
+            bad = bad || !(piv > 0.) || !(piv < 1e300);
+            double ip = __builtin_amdgcn_rcp(piv);        // v_rcp_f64 + two Newton steps: full double precision for normal pivots
+            ip = fma(fma(-piv, ip, 1.), ip, ip);
+            ip = fma(fma(-piv, ip, 1.), ip, ip);
+            const bool pl = l == kk;
+            const double A = pl ? 0. : 1.;
+            const double fe = pl ? -ip : S[kk] * ip;
+#pragma unroll
+            for (int c = 0; c < D; ++c) S[c] = c == kk ? -fe : fma(-fe, rowk[c], A * S[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < D; ++c) M[c] = S[c];
+        rprev = g;
+        if (l < D) {
+            y[t * TS + l] = g;
+#pragma unroll
+            for (int c = 0; c < D; ++c) scr[((size_t)t * D + l) * D + c] = M[c];
+        }
+    }
+    if (bad && l == 0) *a.status = 1;
+    csum[l] = l < D ? cost : 0.;
+    __syncthreads();
+    if (l == 0) {
+        double c = 0.;
+        for (int i = 0; i < D; ++i) c += csum[i];
+        if (costs) costs[p] = (real)c;
+    }
+    // ---- backward: x_t = M_t (r_t - E^T x_{t+1});  (E^T x)[(gamma, i)] = e2[0][gamma] x[(pos, i)] + e2[1][gamma] x[(vel, i)]
+    double xn = 0.;                                       // x_{t+1}[r]
+    for (int t = T - 1; t >= 0; --t) {
+        double Mt[D];
+        if (t == T - 1) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) Mt[c] = M[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < D; ++c) Mt[c] = scr[((size_t)t * D + r) * D + c];
+        }
+        double v = y[t * TS + r];
+        if (t < T - 1) {
+            const double xo = __shfl(xn, partner, 64);
+            const double xp = pos ? xn : xo, xv = pos ? xo : xn;
+            v -= pos ? e00 * xp + e10 * xv : e01 * xp + e11 * xv;
+        }
+        double acc = 0.;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const double vc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), c), __builtin_amdgcn_readlane(__double2loint(v), c));
+            acc += Mt[c] * vc;
+        }
+        xn = acc;
+        if (l < D) y[t * TS + l] = acc;
+    }
+    __syncthreads();
+    for (int e = l; e < T * D; e += 64) {
+        const int t = e / D, i = e % D;
+        const double x = y[t * TS + i];
+        if (d_theta) d_theta[(size_t)p * T * D + e] = (real)x;
+        mp[e] = (real)(mu[t * TS + i] + a.step_size * x);
+    }
+}
+
 hipError_t launch_gpmp_diag(int dtype, const GpmpArgs& a, double* diag_sum, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(diag_sum, 0, (size_t)a.T * 2 * a.n * sizeof(double), stream);
     if (e != hipSuccess || a.P <= 0 || a.n_fields == 0) return e;
@@ -292,9 +510,22 @@ hipError_t launch_gpmp_diag(int dtype, const GpmpArgs& a, double* diag_sum, hipS
 }
 
 hipError_t launch_gpmp_solve(int dtype, const GpmpArgs& a, void* means, void* d_theta, void* costs,
-                             hipStream_t stream) {
+                             hipStream_t stream, bool cholesky) {
     if (a.P <= 0) return hipSuccess;
     const size_t lds = ((size_t)2 * a.T * TS + (size_t)a.n_fields * a.T * 9) * sizeof(double);
+    // register-resident block-Thomas solve (round 4) for the instantiated joint counts; `cholesky`: round 3's kernel
+#define THOMAS(NN)                                                                                                  \
+    if (!cholesky && a.n == NN) {                                                                                   \
+        if (dtype == SGPMP_F64)                                                                                     \
+            hipLaunchKernelGGL((gpmp_thomas_kernel<double, NN>), dim3(a.P), dim3(64), lds, stream, a, (double*)means, \
+                               (double*)d_theta, (double*)costs);                                                   \
+        else                                                                                                        \
+            hipLaunchKernelGGL((gpmp_thomas_kernel<float, NN>), dim3(a.P), dim3(64), lds, stream, a, (float*)means,  \
+                               (float*)d_theta, (float*)costs);                                                     \
+        return hipGetLastError();                                                                                   \
+    }
+    THOMAS(2) THOMAS(3) THOMAS(6) THOMAS(7)
+#undef THOMAS
     if (dtype == SGPMP_F64)
         hipLaunchKernelGGL((gpmp_solve_kernel<double>), dim3(a.P), dim3(64), lds, stream, a, (double*)means,
                            (double*)d_theta, (double*)costs);

@@ -116,6 +116,7 @@ struct SgpmpToggles {
     int no_fused_step;        // SGPMP_NO_FUSED_STEP        K2 and K3 as separate kernels inside sgpmp_step
     int no_chunked_sweep;     // SGPMP_NO_CHUNKED_SWEEP     64-lane-pass two-trajectory sweeps instead of the chunked one
     int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
+    int gpmp_cholesky;        // SGPMP_GPMP_CHOLESKY        GPMP solve by round 3's block Cholesky through LDS instead of the register-resident block-Thomas kernel
     int no_dense_partials;    // SGPMP_NO_DENSE_PARTIALS    update_kernel re-reads all rows with weight even when the weights are spread (round 3)
     int no_wave_groups;       // SGPMP_NO_WAVE_GROUPS       fused launch / chunked sweep as 256-thread workgroups (round 2-3) instead of one wave each
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
@@ -275,7 +276,7 @@ struct GpmpArgs {
 
 hipError_t launch_gpmp_diag(int dtype, const GpmpArgs& a, double* diag_sum, hipStream_t stream);
 hipError_t launch_gpmp_solve(int dtype, const GpmpArgs& a, void* means, void* d_theta, void* costs,
-                             hipStream_t stream);
+                             hipStream_t stream, bool cholesky = false);
 hipError_t launch_link_dist(int dtype, const void* frames, long long batch, int n_links, const void* spheres,
                             int n_other, int mode, double buffer, void* out, hipStream_t stream);
 hipError_t launch_fk(int dtype, int n, const ChainDev* d_chain, int n_links, const void* q,

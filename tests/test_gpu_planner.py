@@ -1751,6 +1751,24 @@ def test_gpmp_matches_reference_run_and_oracle(golden, tag, delta, trust):
             assert rel_err(costs, torch.from_numpy(g[f"lm/costs{it + 1}"])) < 1e-9
 
 
+@pytest.mark.parametrize("ta_name,tol", [("f64", 1e-9), ("f32", 2e-4)])
+def test_gpmp_register_kernel_equals_the_lds_cholesky_kernel(golden, ta_name, tol):
+    """Round 4's solve (block-Thomas recursion, the d x d matrices in registers, Gauss-Jordan by readlane) against round 3's
+    (block Cholesky through LDS tiles, `gpmp_cholesky`): same step, same costs, both damping modes."""
+    g = golden("g7_gpmp.npz")
+    sph = torch.from_numpy(g["spheres"])
+    ta = F64 if ta_name == "f64" else F32
+    for tag, delta, trust in (("lm", 5.0, False), ("tr", 1e-2, True)):
+        a, b = _hip_gpmp(g, tag, ta, delta, trust), _hip_gpmp(g, tag, ta, delta, trust)
+        b._engine.set_option("gpmp_cholesky", 1)
+        for it in range(3):
+            b.particle_means.copy_(a.particle_means)
+            _, _, ca = a.optimize(obstacle_spheres=sph.to(**ta))
+            _, _, cb = b.optimize(obstacle_spheres=sph.to(**ta))
+            assert rel_err(a._d_theta, b._d_theta) < tol, (tag, it)
+            assert rel_err(ca, cb) < (1e-12 if ta_name == "f64" else 1e-5)
+
+
 def test_gpmp_with_end_effector_goal_matches_oracle(golden):
     """GPMP with CostGoal (EESE3DistanceField) in the cost list: its one row on the last waypoint enters the
     block-tridiagonal normal equations like a collision row; d_theta, costs and means against the dense oracle

@@ -16,8 +16,10 @@ for dtype in (torch.float32, torch.float64):
                   sigma_gp_init=c["sigma_gp_init"], sigma_gp_sample=c["sigma_gp_sample"], seed=0,
                   solver_params=dict(delta=1e-2, trust_region=True, method='cholesky'), tensor_args=ta)
         sph = torch.as_tensor(W.panda_spheres()).to(**ta)
-        for _ in range(3): pl.optimize(obstacle_spheres=sph)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(10): _, _, costs = pl.optimize(obstacle_spheres=sph)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-        print(f"{str(dtype):14s} P={P:5d} T={T}: {dt*1e3:7.3f} ms per Gauss-Newton step (N = {T*14} unknowns per particle), mean cost {float(costs.mean()):.4g}")
+        for kernel in ("registers (block Thomas)", "LDS block Cholesky (round 3)"):
+            pl._engine.set_option("gpmp_cholesky", 0 if kernel.startswith("reg") else 1)
+            for _ in range(3): pl.optimize(obstacle_spheres=sph)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(10): _, _, costs = pl.optimize(obstacle_spheres=sph)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+            print(f"{str(dtype):14s} P={P:5d} T={T} {kernel:30s}: {dt*1e3:7.3f} ms per Gauss-Newton step (N = {T*14} unknowns per particle), mean cost {float(costs.mean()):.4g}")
