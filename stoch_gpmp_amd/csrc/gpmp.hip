@@ -308,7 +308,7 @@ gpmp_thomas_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_th
     double* fv = y + (size_t)T * TS;                      // [F][T]    (index t-1)
     double* fg = fv + (size_t)a.n_fields * T;             // [F][T][8]
     real* mp = means + (size_t)p * T * D;
-    double* scr = a.scratch + (size_t)p * T * D * D;      // [T][D][D] M_t
+    double* scr = a.scratch + (size_t)p * T * D * D;      // [T][D][D] M_t, element (row, column) at [t][column][row]
     for (int e = l; e < T * TS; e += 64) {
         const int t = e / TS, i = e % TS;
         mu[e] = i < D ? (double)mp[t * D + i] : 0.;
@@ -454,7 +454,7 @@ gpmp_thomas_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_th
         if (l < D) {
             y[t * TS + l] = g;
 #pragma unroll
-            for (int c = 0; c < D; ++c) scr[((size_t)t * D + l) * D + c] = M[c];
+            for (int c = 0; c < D; ++c) scr[((size_t)t * D + c) * D + l] = M[c];   // [t][column][row]: one contiguous 8 d-byte run per store
         }
     }
     if (bad && l == 0) *a.status = 1;
@@ -467,14 +467,13 @@ gpmp_thomas_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_th
     }
     // ---- backward: x_t = M_t (r_t - E^T x_{t+1});  (E^T x)[(gamma, i)] = e2[0][gamma] x[(pos, i)] + e2[1][gamma] x[(vel, i)]
     double xn = 0.;                                       // x_{t+1}[r]
+    double Mt[D], Mn[D];                                  // M_t, and M_{t-1} on its way in while step t computes
+#pragma unroll
+    for (int c = 0; c < D; ++c) { Mt[c] = M[c]; Mn[c] = 0.; }
     for (int t = T - 1; t >= 0; --t) {
-        double Mt[D];
-        if (t == T - 1) {
+        if (t >= 1) {
 #pragma unroll
-            for (int c = 0; c < D; ++c) Mt[c] = M[c];
-        } else {
-#pragma unroll
-            for (int c = 0; c < D; ++c) Mt[c] = scr[((size_t)t * D + r) * D + c];
+            for (int c = 0; c < D; ++c) Mn[c] = scr[((size_t)(t - 1) * D + c) * D + r];
         }
         double v = y[t * TS + r];
         if (t < T - 1) {
@@ -490,6 +489,8 @@ gpmp_thomas_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_th
         }
         xn = acc;
         if (l < D) y[t * TS + l] = acc;
+#pragma unroll
+        for (int c = 0; c < D; ++c) Mt[c] = Mn[c];
     }
     __syncthreads();
     for (int e = l; e < T * D; e += 64) {

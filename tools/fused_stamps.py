@@ -16,12 +16,17 @@ for _ in range(30):
 torch.cuda.synchronize()
 assert pl._engine.last_cost_kernel() == "fused_step_kernel"
 c = pl._costs.reshape(-1, 8).double().cpu()          # [item = wave][slot]
+PRO = os.environ.get("FUSED_STAMPS_PROLOGUE") == "1"          # library built with -DFUSED_STAMPS=2: slots 0..2 = cycles from kernel entry
 names = ["phase A (noise + recurrence)", "wait + phase B (x = mu + y, stores)", "phase C loads + quadratic forms",
          "kinematics + fields", "whole item"]
 tot = c[:, 4]
 xcc_all = (c[:, 6].long() >> 16).double()
 print(f"{c.shape[0]} waves, {T // 16} chunks each; whole item: median {tot.median():.0f}, mean {tot.mean():.0f}, max {tot.max():.0f} cycles")
-for i, n in enumerate(names[:4]):
+if PRO:
+    for i, n in enumerate(["sphere / state tables staged", "barrier passed", "static sphere sum done"]):
+        print(f"  from kernel entry to: {n:32s} median {c[:, i].median():8.0f}  mean {c[:, i].mean():8.0f} cycles")
+    print(f"  from kernel entry to: first chunk                      median {c[:, 7].median():8.0f}  mean {c[:, 7].mean():8.0f} cycles")
+for i, n in enumerate([] if PRO else names[:4]):
     print(f"  {n:38s} median {c[:, i].median():8.0f}  mean {c[:, i].mean():8.0f}  ({100 * c[:, i].mean() / tot.mean():5.1f} % of the item)  per chunk {c[:, i].mean() / (T // 16):7.0f}")
 print(f"  {'prologue (kernel entry -> first chunk)':38s} median {c[:, 7].median():8.0f}  mean {c[:, 7].mean():8.0f}  ({100 * c[:, 7].mean() / tot.mean():5.1f} % of the wave)")
 print(f"  {'epilogue / unstamped':38s} mean {(tot - c[:, :4].sum(1) - c[:, 7]).mean():8.0f}")
