@@ -326,3 +326,32 @@ def test_run_time_chain_code_compiles_for_gfx950_without_a_device():
             assert rc == _lib.OK and n.value > 10000, (rc, _lib.last_error()[:2000])
     rc = lib.sgpmp_fk_codegen_compile(b"struct ChainCode_rt { static constexpr int N = 7; };", 0, None)
     assert rc == _lib.ESTATE and "hiprtc" in _lib.last_error()
+
+
+def test_host_bookkeeping_under_address_and_ub_sanitizers(tmp_path):
+    """tests/host_asan: api.hip and comm.hip compiled host-only with -fsanitize=address,undefined over a stub HIP runtime
+    (malloc-backed device memory, streams that execute at enqueue), stub launchers that touch the kernels' byte ranges and
+    the shared-memory stand-in for librccl -- contexts, priors, cost programs, chains, the step as one chain / two
+    particle-half chains / with profiling events / per-step mode statistics / an empty shard, the statistics ring beyond its
+    eight slots, the reduced-event table beyond its eight entries, communicator re-attach, destroy (no stream, event or
+    buffer may outlive its context).  Also run with the fused launch eligible and with lagging events (the fall-back stream
+    waits), and once with a buffer deliberately one element short: that run must FAIL with an AddressSanitizer report."""
+    import shutil
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc") or not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("no ROCm clang")
+    d = os.path.join(ROOT, "tests", "host_asan")
+    b = str(tmp_path / "build")
+    r = subprocess.run(["make", "-C", d, f"B={b}", "-j4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    exe, fake = os.path.join(b, "host_asan"), os.path.join(b, "libfakerccl_stub.so")
+    base = {k: v for k, v in os.environ.items() if not k.startswith(("SGPMP_", "STUB_", "HOST_ASAN"))}
+    base["ASAN_OPTIONS"] = "detect_leaks=1:abort_on_error=0"
+    for extra in ({}, {"SGPMP_RCCL_LIB": fake}, {"SGPMP_RCCL_LIB": fake, "STUB_FUSED": "1", "STUB_EVENT_LAG": "1"},
+                  {"STUB_FUSED": "1", "SGPMP_NO_STEP_PIPELINE": "1"}):
+        p = subprocess.run([exe], env=dict(base, **extra), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "HOST_ASAN_OK" in p.stdout, (extra, p.stdout[-1000:], p.stderr[-4000:])
+        assert "Sanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
+    p = subprocess.run([exe], env=dict(base, HOST_ASAN_INJECT="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "AddressSanitizer" in p.stderr, "the harness did not notice a short buffer"
+    shutil.rmtree(b, ignore_errors=True)
