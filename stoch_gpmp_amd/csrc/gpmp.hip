@@ -295,37 +295,84 @@ gpmp_solve_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_the
 //     v_readlane with literal lane numbers: no LDS, no barrier inside the elimination (round 3's column-by-column Cholesky
 //     through LDS paid two barriers and an fp64 sqrt + division per column, 14 us per waypoint; this is ~1.5 us);
 //   * M_t rows are parked for the backward sweep (d x d doubles per waypoint instead of two 16 x 16 tiles).
-template <typename real, int N>
+// PPW particles per wave, one per row of 16 lanes (a single wave is ISSUE-bound on this recursion -- ~2500 instructions per
+// waypoint at one per 4 cycles -- and a lane-row layout leaves 50 of 64 lanes idle: four particles share every instruction).
+// The pivot-row broadcast is then per 16-lane row: DPP row_newbcast instead of v_readlane.
+template <int PPW, int K>
+__device__ __forceinline__ double row_bcast(double v) {
+    if constexpr (PPW == 1) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), K), __builtin_amdgcn_readlane(__double2loint(v), K));
+    } else {
+        // (every lane of a row has a source lane: the `old` operand is never kept -- handing the source itself spares a move)
+        const int hi = __double2hiint(v), lo = __double2loint(v);
+        return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x150 + K, 0xf, 0xf, true),
+                                __builtin_amdgcn_update_dpp(lo, lo, 0x150 + K, 0xf, 0xf, true));
+    }
+}
+// dst[c] = lane c's value of v, for every c (lane numbers must be literals: recursion over the index)
+template <int PPW, int D, int C = 0>
+__device__ __forceinline__ void bcast_each(double v, double (&dst)[D]) {
+    if constexpr (C < D) {
+        dst[C] = row_bcast<PPW, C>(v);
+        bcast_each<PPW, D, C + 1>(v, dst);
+    }
+}
+// dst[c] = lane kk's src[c] for every c; kk is a loop constant after unrolling -- a switch keeps it a literal for the DPP control
+template <int PPW, int D, int KK = 0>
+__device__ __forceinline__ void bcast_row(const double (&src)[D], double (&dst)[D], int kk) {
+    if constexpr (KK < D) {
+        if (kk == KK) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) dst[c] = row_bcast<PPW, KK>(src[c]);
+        } else {
+            bcast_row<PPW, D, KK + 1>(src, dst, kk);
+        }
+    }
+}
+
+template <typename real, int N, int PPW>
 __global__ void __launch_bounds__(64)
 gpmp_thomas_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_theta, real* __restrict__ costs) {
     constexpr int D = 2 * N;
     extern __shared__ __align__(16) unsigned char gp_lds_raw[];
     __shared__ double csum[64];
-    const int l = threadIdx.x, p = blockIdx.x;
+    const int l = threadIdx.x;
+    const int sub = PPW == 1 ? 0 : l >> 4, l16 = PPW == 1 ? l : l & 15;       // particle of the wave, lane within its row
+    const int p_raw = blockIdx.x * PPW + sub;
+    const bool valid = p_raw < a.P;
+    const int p = valid ? p_raw : a.P - 1;                // (lanes of a missing particle compute on the last one, write nothing)
     const int T = a.T;
-    double* mu = reinterpret_cast<double*>(gp_lds_raw);   // [T][TS] means
+    const size_t per = (size_t)2 * T * TS + (size_t)a.n_fields * T * 9;       // doubles of LDS per particle
+    double* mu = reinterpret_cast<double*>(gp_lds_raw) + (size_t)sub * per;   // [T][TS] means
     double* y = mu + (size_t)T * TS;                      // [T][TS] r_t, then the solution
     double* fv = y + (size_t)T * TS;                      // [F][T]    (index t-1)
     double* fg = fv + (size_t)a.n_fields * T;             // [F][T][8]
     real* mp = means + (size_t)p * T * D;
     double* scr = a.scratch + (size_t)p * T * D * D;      // [T][D][D] M_t, element (row, column) at [t][column][row]
-    for (int e = l; e < T * TS; e += 64) {
-        const int t = e / TS, i = e % TS;
-        mu[e] = i < D ? (double)mp[t * D + i] : 0.;
-    }
-    for (int f = 0; f < a.n_fields; ++f) {
-        for (int e = l; e < T - 1; e += 64) fv[f * T + e] = ld<real>(a.f[f].val, (size_t)p * (T - 1) + e);
-        for (int e = l; e < (T - 1) * N; e += 64) {
-            const int t1 = e / N, j = e - t1 * N;
-            fg[((size_t)f * T + t1) * 8 + j] = ld<real>(a.f[f].grad, ((size_t)p * (T - 1) + t1) * N + j);
+    for (int q = 0; q < PPW; ++q) {                       // all 64 lanes stage each particle of the wave
+        const int pq = min(blockIdx.x * PPW + q, a.P - 1);
+        double* muq = reinterpret_cast<double*>(gp_lds_raw) + (size_t)q * per;
+        double* fvq = muq + (size_t)2 * T * TS;
+        double* fgq = fvq + (size_t)a.n_fields * T;
+        const real* mq = means + (size_t)pq * T * D;
+        for (int e = l; e < T * TS; e += 64) {
+            const int t = e / TS, i = e % TS;
+            muq[e] = i < D ? (double)mq[t * D + i] : 0.;
+        }
+        for (int f = 0; f < a.n_fields; ++f) {
+            for (int e = l; e < T - 1; e += 64) fvq[f * T + e] = ld<real>(a.f[f].val, (size_t)pq * (T - 1) + e);
+            for (int e = l; e < (T - 1) * N; e += 64) {
+                const int t1 = e / N, j = e - t1 * N;
+                fgq[((size_t)f * T + t1) * 8 + j] = ld<real>(a.f[f].grad, ((size_t)pq * (T - 1) + t1) * N + j);
+            }
         }
     }
     __syncthreads();
     const long long gi = a.Kg > 0. ? (a.p_offset + p) / a.rows_per_goal : 0;
-    const int r = l < D ? l : 0;                          // this lane's row (lanes >= D idle along)
+    const int r = l16 < D ? l16 : 0;                      // this lane's row (lanes >= D of a row idle along)
     const int k = r % N;
     const bool pos = r < N;
-    const int partner = pos ? r + N : r - N;
+    const int partner = (PPW == 1 ? 0 : (l & 48)) + (pos ? r + N : r - N);
     // E2 = -K [[c11, c11 dt + c12], [c12, c12 dt + c22]]  (rows: pos, vel of the LATER waypoint; columns: of the earlier one)
     const double e00 = -a.Kgp * a.c11, e01 = -a.Kgp * (a.c11 * a.dt + a.c12), e10 = -a.Kgp * a.c12, e11 = -a.Kgp * (a.c12 * a.dt + a.c22);
     const double er0 = pos ? e00 : e10, er1 = pos ? e01 : e11;      // this lane's row of E2
@@ -383,11 +430,11 @@ gpmp_thomas_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_th
             }
             // r_t = g_t - (E M_{t-1}) r_{t-1}
             double acc = g;
+            {
+                double rb[D];
+                bcast_each<PPW, D>(rprev, rb);            // r_{t-1} of every row to every lane of the particle
 #pragma unroll
-            for (int c = 0; c < D; ++c) {
-                const double rc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rprev), c),
-                                                   __builtin_amdgcn_readlane(__double2loint(rprev), c));
-                acc -= EM[c] * rc;
+                for (int c = 0; c < D; ++c) acc -= EM[c] * rb[c];
             }
             g = acc;
             // S = - (E M E^T) row r:  column (beta, j) = e2[beta][0] EM[(pos, j)] + e2[beta][1] EM[(vel, j)]
@@ -433,16 +480,13 @@ gpmp_thomas_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_th
 #pragma unroll
         for (int kk = 0; kk < D; ++kk) {
             double rowk[D];
-#pragma unroll
-            for (int c = 0; c < D; ++c)
-                rowk[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(S[c]), kk),
-                                           __builtin_amdgcn_readlane(__double2loint(S[c]), kk));
+            bcast_row<PPW, D>(S, rowk, kk);               // row kk of the particle's matrix to all its lanes
             const double piv = rowk[kk];
             bad = bad || !(piv > 0.) || !(piv < 1e300);
             double ip = __builtin_amdgcn_rcp(piv);        // v_rcp_f64 + two Newton steps: full double precision for normal pivots
             ip = fma(fma(-piv, ip, 1.), ip, ip);
             ip = fma(fma(-piv, ip, 1.), ip, ip);
-            const bool pl = l == kk;
+            const bool pl = l16 == kk;
             const double A = pl ? 0. : 1.;
             const double fe = pl ? -ip : S[kk] * ip;
 #pragma unroll
@@ -451,18 +495,20 @@ gpmp_thomas_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_th
 #pragma unroll
         for (int c = 0; c < D; ++c) M[c] = S[c];
         rprev = g;
-        if (l < D) {
-            y[t * TS + l] = g;
+        if (l16 < D) {
+            y[t * TS + l16] = g;
+            if (valid) {
 #pragma unroll
-            for (int c = 0; c < D; ++c) scr[((size_t)t * D + c) * D + l] = M[c];   // [t][column][row]: one contiguous 8 d-byte run per store
+                for (int c = 0; c < D; ++c) scr[((size_t)t * D + c) * D + l16] = M[c];   // [t][column][row]: one contiguous 8 d-byte run per store
+            }
         }
     }
-    if (bad && l == 0) *a.status = 1;
-    csum[l] = l < D ? cost : 0.;
+    if (bad && valid && l16 == 0) *a.status = 1;
+    csum[l] = l16 < D ? cost : 0.;
     __syncthreads();
-    if (l == 0) {
+    if (l16 == 0 && valid) {
         double c = 0.;
-        for (int i = 0; i < D; ++i) c += csum[i];
+        for (int i = 0; i < D; ++i) c += csum[l + i];
         if (costs) costs[p] = (real)c;
     }
     // ---- backward: x_t = M_t (r_t - E^T x_{t+1});  (E^T x)[(gamma, i)] = e2[0][gamma] x[(pos, i)] + e2[1][gamma] x[(vel, i)]
@@ -482,22 +528,30 @@ gpmp_thomas_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_th
             v -= pos ? e00 * xp + e10 * xv : e01 * xp + e11 * xv;
         }
         double acc = 0.;
+        {
+            double vb[D];
+            bcast_each<PPW, D>(v, vb);
 #pragma unroll
-        for (int c = 0; c < D; ++c) {
-            const double vc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), c), __builtin_amdgcn_readlane(__double2loint(v), c));
-            acc += Mt[c] * vc;
+            for (int c = 0; c < D; ++c) acc += Mt[c] * vb[c];
         }
         xn = acc;
-        if (l < D) y[t * TS + l] = acc;
+        if (l16 < D) y[t * TS + l16] = acc;
 #pragma unroll
         for (int c = 0; c < D; ++c) Mt[c] = Mn[c];
     }
     __syncthreads();
-    for (int e = l; e < T * D; e += 64) {
-        const int t = e / D, i = e % D;
-        const double x = y[t * TS + i];
-        if (d_theta) d_theta[(size_t)p * T * D + e] = (real)x;
-        mp[e] = (real)(mu[t * TS + i] + a.step_size * x);
+    for (int q = 0; q < PPW; ++q) {
+        const int pq = blockIdx.x * PPW + q;
+        if (pq >= a.P) break;
+        const double* muq = reinterpret_cast<const double*>(gp_lds_raw) + (size_t)q * per;
+        const double* yq = muq + (size_t)T * TS;
+        real* mq = means + (size_t)pq * T * D;
+        for (int e = l; e < T * D; e += 64) {
+            const int t = e / D, i = e % D;
+            const double x = yq[t * TS + i];
+            if (d_theta) d_theta[(size_t)pq * T * D + e] = (real)x;
+            mq[e] = (real)(muq[t * TS + i] + a.step_size * x);
+        }
     }
 }
 
@@ -515,17 +569,26 @@ hipError_t launch_gpmp_solve(int dtype, const GpmpArgs& a, void* means, void* d_
     if (a.P <= 0) return hipSuccess;
     const size_t lds = ((size_t)2 * a.T * TS + (size_t)a.n_fields * a.T * 9) * sizeof(double);
     // register-resident block-Thomas solve (round 4) for the instantiated joint counts; `cholesky`: round 3's kernel
-#define THOMAS(NN)                                                                                                  \
-    if (!cholesky && a.n == NN) {                                                                                   \
+    // particles per wave: four (one per row of 16 lanes) while their staging fits the LDS, else two, else one
+    const size_t per_particle = lds;
+    const int ppw = 4 * per_particle <= 150 * 1024 ? 4 : 2 * per_particle <= 150 * 1024 ? 2 : 1;
+#define THOMAS_L(NN, PP)                                                                                            \
+    {                                                                                                               \
+        const unsigned grid = (unsigned)((a.P + PP - 1) / PP);                                                      \
         if (dtype == SGPMP_F64)                                                                                     \
-            hipLaunchKernelGGL((gpmp_thomas_kernel<double, NN>), dim3(a.P), dim3(64), lds, stream, a, (double*)means, \
-                               (double*)d_theta, (double*)costs);                                                   \
+            hipLaunchKernelGGL((gpmp_thomas_kernel<double, NN, PP>), dim3(grid), dim3(64), PP * per_particle, stream, a,        \
+                               (double*)means, (double*)d_theta, (double*)costs);                                   \
         else                                                                                                        \
-            hipLaunchKernelGGL((gpmp_thomas_kernel<float, NN>), dim3(a.P), dim3(64), lds, stream, a, (float*)means,  \
-                               (float*)d_theta, (float*)costs);                                                     \
+            hipLaunchKernelGGL((gpmp_thomas_kernel<float, NN, PP>), dim3(grid), dim3(64), PP * per_particle, stream, a,         \
+                               (float*)means, (float*)d_theta, (float*)costs);                                      \
         return hipGetLastError();                                                                                   \
     }
+#define THOMAS(NN)                                                                                                  \
+    if (!cholesky && a.n == NN) {                                                                                   \
+        if (ppw == 4) THOMAS_L(NN, 4) else if (ppw == 2) THOMAS_L(NN, 2) else THOMAS_L(NN, 1)                       \
+    }
     THOMAS(2) THOMAS(3) THOMAS(6) THOMAS(7)
+#undef THOMAS_L
 #undef THOMAS
     if (dtype == SGPMP_F64)
         hipLaunchKernelGGL((gpmp_solve_kernel<double>), dim3(a.P), dim3(64), lds, stream, a, (double*)means,

@@ -10,7 +10,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-other-configs"
+BENCH="python3 $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-other-configs --no-parity"
 
 # Per-kernel figures want whole-range launches: inside optimize(opt_iters=K) the context runs two half-range launch
 # sequences that overlap each other (csrc/api.hip StepPipe), which stretches each launch's duration in a trace.
