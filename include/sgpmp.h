@@ -129,7 +129,7 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * on a live context.  Names: force_generic_fk, no_flat_program, no_chain_codegen, no_dual_sweep,
  * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, comm_packet_event,
  * gpmp_cholesky (GPMP solve by round 3's LDS block-Cholesky kernel), no_dense_partials (dense-weight regime: update_kernel re-reads every row with weight, as in round 3),
- * no_wave_groups (fused launch / chunked sweep as 256-thread workgroups instead of one wave per workgroup),
+ * wave_groups (fused launch as one-wave workgroups; measured level, not the default),
  * no_planar_seg (planar one-launch step through the LDS tile, fused_planar_kernel, even where the lane-per-sample launch applies),
  * pipe_split (1..15) and k3_blocks (count); and, ONLY in a library built with `make EXPERIMENTS=1` (launches that
  * measured slower and are kept for the record; the default library answers SGPMP_EINVAL "unknown option"):
@@ -240,8 +240,10 @@ int sgpmp_update(sgpmp_ctx* ctx, const void* costs, int costs_dtype, const void*
 /* Diagnostic (synchronous): the number of particles whose last update (inside sgpmp_step) spread its weight over more than
  * S / 4 samples.  For those the next step's fused launch leaves softmax partials of every 8 rows and the update adds S / 8
  * partials instead of re-reading the rows (planner.py:263-275 is a softmax; with the reference's hyper-parameters it is
- * one-hot and the count is 0).  -1: the step has not run on that path yet. */
-int sgpmp_dense_particles(sgpmp_ctx* ctx, int64_t* count);
+ * one-hot and the count is 0).  -1: the step has not run on that path yet.  The partials are ARMED only while update kernels
+ * report such particles (a pinned host word the host reads without synchronising, so arming lags a step or two; it lapses 64
+ * steps after the last report): *armed_steps (may be NULL) counts the steps launched with partials so far. */
+int sgpmp_dense_particles(sgpmp_ctx* ctx, int64_t* count, int64_t* armed_steps);
 
 /* One body of the loop at planner.py:289-299 for the context's particle shard:
  * K5 -> K2 -> K3 -> K4 on `stream` (K2 + K3 as ONE launch when the configuration qualifies, see

@@ -84,7 +84,7 @@ SIGNATURES = {
     "sgpmp_cost_eval": (_I, [_P, _P, _I64, _I64, _P, _I, _P, _I, _P, _P, _P]),
     "sgpmp_is_weights": (_I, [_P, _P, _I, _D, _P, _P]),
     "sgpmp_update": (_I, [_P, _P, _I, _P, _P, _D, _D, _P, _P, _P, _P, _P]),
-    "sgpmp_dense_particles": (_I, [_P, C.POINTER(_I64)]),
+    "sgpmp_dense_particles": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "sgpmp_step": (_I, [_P, _U64, _U64, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _D, _D, _P, _I, _P]),
     "sgpmp_fk": (_I, [_P, _P, _I64, _P, _P]),
     "sgpmp_grid_lookup": (_I, [_P, _I, _P, _I64, _P, _P]),

@@ -95,6 +95,9 @@ struct sgpmp_ctx {
     // dense-weight regime of the update: softmax partials of the fused launch + per-particle row counts (FusedArgs::part)
     float* d_part = nullptr;         // [P][S / 8][4 + M], allocated by the first step that can use it
     unsigned* d_nnz = nullptr;       // [P]
+    unsigned* h_dense_flag = nullptr;   // pinned host word: an update kernel found a particle with spread weights
+    unsigned* d_dense_flag = nullptr;   // ... its device address
+    long long dense_step = 0, dense_armed_until = -1, dense_armed_steps = 0;
     int last_step_launches = 0;      // kernels the last sgpmp_step enqueued for its particle range (1: everything in one launch)
     hipStream_t k1_side = nullptr;   // sgpmp_set_priors: the second factorisation's stream
     hipEvent_t k1_fork = nullptr;
@@ -108,7 +111,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
     {"tail_update", &SgpmpToggles::tail_update}, {"small_step", &SgpmpToggles::small_step}, {"comm_packet_event", &SgpmpToggles::comm_packet_event},
-    {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"no_wave_groups", &SgpmpToggles::no_wave_groups},
+    {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"wave_groups", &SgpmpToggles::wave_groups},
     {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
 };
 
@@ -354,6 +357,7 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     hipFree(c->d_qc); hipFree(c->d_prog); hipFree(c->d_chain); hipFree(c->d_isw);
     hipFree(c->d_costs64); hipFree(c->d_arrive); hipFree(c->d_done); hipFree(c->d_tail_acc);
     hipFree(c->d_part); hipFree(c->d_nnz);
+    if (c->h_dense_flag) hipHostFree(c->h_dense_flag);
     if (c->ms_side) { hipStreamSynchronize(c->ms_side); hipStreamDestroy(c->ms_side); }
     for (int i = 0; i < 2; ++i) { hipFree(c->ms_snap[i]); if (c->ms_read[i]) hipEventDestroy(c->ms_read[i]); }
     if (c->ms_ready) hipEventDestroy(c->ms_ready);
@@ -913,23 +917,36 @@ extern "C" int sgpmp_update(sgpmp_ctx* c, const void* costs, int costs_dtype, co
 // the update reads S / 8 rows instead of nnz).
 static int dense_buffers(sgpmp_ctx* c, FusedDenseHost* d, double temperature) {
     const sgpmp_dims& D = c->dims;
-    d->part = nullptr; d->nnz = nullptr; d->threshold = (unsigned)(D.num_samples / 4); d->temperature = temperature;
+    d->part = nullptr; d->nnz = nullptr; d->flag = nullptr; d->threshold = (unsigned)(D.num_samples / 4); d->temperature = temperature;
     if (D.dtype != SGPMP_F32 || D.num_samples % 8 != 0 || c->tg.no_dense_partials || D.num_particles < 1) return SGPMP_OK;
-    if (!c->d_part) {
+    if (!c->d_nnz) {
         const size_t P = (size_t)D.num_particles;
-        HIPCHK(hipMalloc(&c->d_part, P * (size_t)(D.num_samples / 8) * (size_t)(c->M + 4) * sizeof(float)));
         HIPCHK(hipMalloc(&c->d_nnz, P * sizeof(unsigned)));
         HIPCHK(hipMemset(c->d_nnz, 0, P * sizeof(unsigned)));
+        HIPCHK(hipHostMalloc((void**)&c->h_dense_flag, sizeof(unsigned), hipHostMallocDefault));
+        *c->h_dense_flag = 0u;
+        HIPCHK(hipHostGetDevicePointer((void**)&c->d_dense_flag, c->h_dense_flag, 0));
     }
-    d->part = c->d_part; d->nnz = c->d_nnz;
+    // The partials are ARMED only while update kernels keep reporting spread weights (the pinned word, read without any
+    // synchronisation -- it may lag a step or two): with the reference's one-hot weights the fused launch stays exactly round 3's.
+    c->dense_step += 1;
+    if (*(volatile unsigned*)c->h_dense_flag) { c->dense_armed_until = c->dense_step + 64; *(volatile unsigned*)c->h_dense_flag = 0u; }
+    d->nnz = c->d_nnz; d->flag = c->d_dense_flag;
+    if (c->dense_step <= c->dense_armed_until) {
+        if (!c->d_part)
+            HIPCHK(hipMalloc(&c->d_part, (size_t)D.num_particles * (size_t)(D.num_samples / 8) * (size_t)(c->M + 4) * sizeof(float)));
+        d->part = c->d_part;
+        c->dense_armed_steps += 1;
+    }
     return SGPMP_OK;
 }
 
 // Diagnostic (synchronous): how many particles' last update spread its weight over more than S / 4 samples -- the
 // particles for which the NEXT fused launch leaves softmax partials (dense-weight regime).  -1 before the buffers exist.
-extern "C" int sgpmp_dense_particles(sgpmp_ctx* c, int64_t* count) {
+extern "C" int sgpmp_dense_particles(sgpmp_ctx* c, int64_t* count, int64_t* armed_steps) {
     if (!c || !count) return fail(SGPMP_EINVAL, "sgpmp_dense_particles: null argument");
     *count = -1;
+    if (armed_steps) *armed_steps = c->dense_armed_steps;
     if (!c->d_nnz) return SGPMP_OK;
     HIPCHK(hipDeviceSynchronize());
     std::vector<unsigned> nnz((size_t)c->dims.num_particles);
@@ -1053,7 +1070,7 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
             }
         HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, Ph, S, c64, SGPMP_F64, X, mu, temperature, step_size, wh, gh, mph,
                              slot, sh, c->tg.comm_packet_event ? k4_done[h] : nullptr, &pr, isw, &tail[h], nullptr,
-                             armed ? dh.part : nullptr, dh.nnz, dh.threshold));
+                             armed ? dh.part : nullptr, dh.nnz, dh.threshold, dh.flag));
         if (!c->tg.comm_packet_event && k4_done[h]) HIPCHK(hipEventRecord(k4_done[h], sh));
         c->last_step_launches += 1;
     }
@@ -1182,7 +1199,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         return SGPMP_OK;
     }
     bool tail_ran = false;                                       // the update ran inside the fused launch
-    FusedDenseHost dense = {nullptr, nullptr, 0u, temperature};   // softmax partials for the dense-weight regime of the update
+    FusedDenseHost dense = {nullptr, nullptr, 0u, temperature, nullptr};   // softmax partials for the dense-weight regime of the update
     bool partials = false;
     if (fused) {
         if (se) { HIPCHK(hipEventRecord(se->ev[2], st)); se->has[1] = false; }   // (fused: the whole launch is booked on the sweep)
@@ -1225,7 +1242,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
                              temperature, step_size, weights, grad, means_prev, acc_stats, st,
                              c->tg.comm_packet_event ? k4_done : nullptr, &pr, c->d_isw,
                              &isw_written, c->ms_buf ? c->ms_snap[slot] : nullptr,
-                             (fused && partials) ? dense.part : nullptr, dense.nnz, dense.threshold));
+                             (fused && partials) ? dense.part : nullptr, dense.nnz, dense.threshold, dense.flag));
         if (!c->tg.comm_packet_event && k4_done) HIPCHK(hipEventRecord(k4_done, st));
         c->last_step_launches += 1;
         if (c->ms_buf) {

@@ -360,10 +360,11 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
 #undef FUSED_LAUNCH
 #define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
 #endif
-    // One wave per workgroup (round 4) when sixteen of them fit the LDS of a CU: a SIMD's slot is then refilled when its own
-    // wave ends, not when the slowest of four does.  The grid-stride loop stays for capped grids (k3_blocks).
+    // Opt-in `wave_groups` (round 4): one wave per workgroup when sixteen of them fit the LDS of a CU -- a SIMD's slot is then
+    // refilled when its own wave ends, not when the slowest of four does.  Bit-identical; measured level in rate with 2.5 % more
+    // vector instructions (every wave stages the tables), 1-2 % slower as a single launch: not the default.
     const size_t dyn = fused_wave_dyn_lds(n_spheres, F.has_goal ? F.goal.dim0 : 0);
-    const bool wave_groups = !with_tail && !tg.no_wave_groups && fused_wave_static_lds<CCp::N>() + dyn <= 10240;
+    const bool wave_groups = !with_tail && tg.wave_groups && fused_wave_static_lds<CCp::N>() + dyn <= 10240;
     if (wave_groups) {
         long long wblocks = nitems;
         if (tg.k3_blocks > 0 && wblocks > 4 * tg.k3_blocks) wblocks = 4 * tg.k3_blocks;

@@ -118,7 +118,7 @@ struct SgpmpToggles {
     int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
     int gpmp_cholesky;        // SGPMP_GPMP_CHOLESKY        GPMP solve by round 3's block Cholesky through LDS instead of the register-resident block-Thomas kernel
     int no_dense_partials;    // SGPMP_NO_DENSE_PARTIALS    update_kernel re-reads all rows with weight even when the weights are spread (round 3)
-    int no_wave_groups;       // SGPMP_NO_WAVE_GROUPS       fused launch / chunked sweep as 256-thread workgroups (round 2-3) instead of one wave each
+    int wave_groups;          // SGPMP_WAVE_GROUPS          fused launch as one-wave workgroups with dynamic LDS tables (round 4: measured level, +2.5 % instructions) instead of 256-thread ones
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
     long long planar_slabs;   // SGPMP_PLANAR_SLABS         time slabs of the planar one-launch step: 0 none (fused_planar_kernel, default), 2, 4 (fused_planar_slab.inc, where the shape allows)
     int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
@@ -186,10 +186,11 @@ hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const
 // K4 inside the fused launch (fused_tail.inc): what the host hands over; null = update_kernel follows the launch
 // Dense-weight regime of the update (FusedArgs::part): buffers the fused launch may leave softmax partials in
 struct FusedDenseHost {
-    float* part;                  // [P][S / 8][4 + T d]
+    float* part;                  // [P][S / 8][4 + T d]; null while no update has reported spread weights (the launch is then round 3's)
     unsigned* nnz;                // [P] rows with weight in each particle's previous update
     unsigned threshold;           // partials for particles with nnz above it
     double temperature;
+    unsigned* flag;               // device view of the host-visible "some particle is dense" word update_kernel sets
 };
 struct FusedTailHost {
     unsigned* arrive;             // [P] arrival counters of the launch's particles (zero between launches)
@@ -233,7 +234,8 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                          void* weights, void* grad, void* means_prev, double* stats,
                          hipStream_t stream, hipEvent_t done = nullptr, const PriorDev* isw_prior = nullptr,
                          void* isw_next = nullptr, bool* isw_written = nullptr, void* means_copy = nullptr,
-                         const float* part = nullptr, unsigned* nnz = nullptr, unsigned nnz_threshold = 0);
+                         const float* part = nullptr, unsigned* nnz = nullptr, unsigned nnz_threshold = 0,
+                         unsigned* dense_flag = nullptr);
 
 hipError_t launch_stats_add(double* dst, const double* src, hipStream_t stream);
 hipError_t launch_mode_stats(int dtype, int n, int T, int P, long long p_offset, int nppg, int G, const void* means,

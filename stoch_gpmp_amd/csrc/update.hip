@@ -23,7 +23,8 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
                          hipStream_t stream, hipEvent_t done, const PriorDev* isw_prior, void* isw_next,
-                         bool* isw_written, void* means_copy, const float* part, unsigned* nnz, unsigned nnz_threshold) {
+                         bool* isw_written, void* means_copy, const float* part, unsigned* nnz, unsigned nnz_threshold,
+                         unsigned* dense_flag) {
     const int M = T * 2 * n;
     size_t lds = (size_t)S * (sizeof(double) + sizeof(int));
     if (isw_prior) {
@@ -46,7 +47,7 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                           IswNext<REAL>{isw_prior ? (REAL*)isw_next : nullptr, isw_prior ? isw_prior->Qinv : nullptr, \
                                         isw_prior ? isw_prior->ks : 0., isw_prior ? isw_prior->kg : -1., \
                                         isw_prior ? isw_prior->dt : 0., n, isw_prior ? isw_prior->isotropic : 1}, \
-                          (REAL*)means_copy, (dtype == SGPMP_F32 && M % 4 == 0) ? part : (const float*)nullptr, S / 8, nnz, nnz_threshold)
+                          (REAL*)means_copy, (dtype == SGPMP_F32 && M % 4 == 0) ? part : (const float*)nullptr, S / 8, nnz, nnz_threshold, dense_flag)
     if (dtype == SGPMP_F64) {
         if (M % 4 == 0) UPD(double, double, 4); else UPD(double, double, 2);
     } else if (costs_dtype == SGPMP_F64) {

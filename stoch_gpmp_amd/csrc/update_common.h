@@ -296,7 +296,8 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
               real* __restrict__ means, double temperature, double step_size,
               real* __restrict__ weights, real* __restrict__ grad, real* __restrict__ means_prev,
               double* __restrict__ stats, IswNext<real> nx, real* __restrict__ means_copy,
-              const float* __restrict__ part, int gpp, unsigned* __restrict__ nnz, unsigned nnz_threshold) {
+              const float* __restrict__ part, int gpp, unsigned* __restrict__ nnz, unsigned nnz_threshold,
+              unsigned* __restrict__ dense_flag) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int p = blockIdx.x;
     // partials of this particle exist iff the fused launch of THIS step saw nnz[p] above the threshold: the same word,
@@ -306,5 +307,8 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
     update_particle<real, cost_t, VW>(p, M, S, costs + (size_t)p * S, samples + (size_t)p * S * M, (size_t)M, means, temperature,
                                       step_size, weights, grad, means_prev, stats, nx, means_copy, lds_raw, nullptr, part_p, gpp,
                                       nnz ? nnz + p : nullptr);
+    // a word in host-visible memory tells the host (no synchronisation: it looks when it enqueues a later step) that some
+    // particle's weights are spread -- only then does it arm the fused launch's partials (api.hip dense_buffers)
+    if (dense_flag && nnz && threadIdx.x == 0 && nnz[p] > nnz_threshold) *dense_flag = 1u;
 }
 

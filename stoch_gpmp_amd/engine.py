@@ -84,8 +84,14 @@ class Engine:
     def dense_particles(self):
         """Particles whose last in-step update spread its weight over more than S / 4 samples (include/sgpmp.h)."""
         k = C.c_int64()
-        L.check(self.lib.sgpmp_dense_particles(self._ctx, C.byref(k)))
+        L.check(self.lib.sgpmp_dense_particles(self._ctx, C.byref(k), None))
         return k.value
+
+    def dense_armed_steps(self):
+        """Steps launched with the fused launch's softmax partials armed so far (include/sgpmp.h: sgpmp_dense_particles)."""
+        k, a = C.c_int64(), C.c_int64()
+        L.check(self.lib.sgpmp_dense_particles(self._ctx, C.byref(k), C.byref(a)))
+        return a.value
 
     def last_cost_kernel(self):
         """Name of the cost-sweep kernel the dispatcher picked at the last launch."""

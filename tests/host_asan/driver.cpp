@@ -138,8 +138,8 @@ static void run_planner(int n, int T, int P, int P_global, int offset, int S, in
         CHECK(sgpmp_cost_eval(c, samples.p, (int64_t)P * S, (int64_t)offset * S, n_sph ? sph.p : nullptr, n_sph, isw.p, S, costs.p, (double*)c64.p, nullptr));
         CHECK(sgpmp_update(c, c64.p, SGPMP_F64, samples.p, means.p, 1.0, 0.1, weights.p, grad.p, prev.p, (double*)stats_a.p, nullptr));
         EXPECT(sgpmp_update(c, c64.p, SGPMP_F64, samples.p, means.p, -1.0, 0.1, nullptr, nullptr, nullptr, nullptr, nullptr), SGPMP_EINVAL);
-        int64_t dense = 0;
-        CHECK(sgpmp_dense_particles(c, &dense));
+        int64_t dense = 0, armed = 0;
+        CHECK(sgpmp_dense_particles(c, &dense, &armed));
         // per-mode precisions and their quadratic forms
         std::vector<double> D((size_t)2 * T * d * d, 0.), E((size_t)2 * (T - 1) * d * d, 0.);
         for (int m = 0; m < 2; ++m) for (int t = 0; t < T; ++t) for (int i = 0; i < d; ++i) D[(((size_t)m * T + t) * d + i) * d + i] = 2.;
@@ -150,7 +150,7 @@ static void run_planner(int n, int T, int P, int P_global, int offset, int S, in
         CHECK(sgpmp_get_prior(c, SGPMP_PRIOR_INIT, nullptr, G_.data(), H_.data()));
     }
     EXPECT(sgpmp_set_option(c, "no_such_switch", 1), SGPMP_EINVAL);
-    for (const char* name : {"no_fused_step", "no_step_pipeline", "no_dense_partials", "no_wave_groups", "gpmp_cholesky", "comm_packet_event"}) {
+    for (const char* name : {"no_fused_step", "no_step_pipeline", "no_dense_partials", "wave_groups", "gpmp_cholesky", "comm_packet_event"}) {
         CHECK(sgpmp_set_option(c, name, 1));
         step(400, 0);
         CHECK(sgpmp_set_option(c, name, 0));

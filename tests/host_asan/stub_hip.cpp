@@ -43,6 +43,7 @@ hipError_t hipFree(void* p) {
 }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); g_live_dev.insert(*p); return hipSuccess; }
 hipError_t hipHostFree(void* p) { return hipFree(p); }
+hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) { check_stream(st); std::memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }

@@ -91,7 +91,7 @@ hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& p, const v
 }
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int cdt, const void* samples, void* means, double, double, void* weights,
                          void* grad, void* means_prev, double* stats, hipStream_t, hipEvent_t done, const PriorDev* ip, void* isw_next, bool* isw_written,
-                         void* means_copy, const float* part, unsigned* nnz, unsigned) {
+                         void* means_copy, const float* part, unsigned* nnz, unsigned, unsigned* dense_flag) {
     const size_t M = (size_t)T * 2 * n, w = esz(dtype);
     rd(costs, (size_t)P * S * esz(cdt)); rd(samples, (size_t)P * S * M * w);
     wr(means, (size_t)P * M * w); wr(weights, (size_t)P * S * w); wr(grad, (size_t)P * M * w); wr(means_prev, (size_t)P * M * w);
@@ -101,6 +101,7 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
     if (isw_written) *isw_written = ip != nullptr && P > 0;
     if (part) rd(part, (size_t)P * (S / 8) * (M + 4) * 4);
     if (nnz) { rd(nnz, (size_t)P * 4); wr(nnz, (size_t)P * 4, 1); }
+    if (dense_flag && env1("STUB_DENSE")) *dense_flag = 1u;          // (as if some particle's weights were spread)
     if (done) return hipEventRecord(done, nullptr);
     return hipSuccess;
 }

@@ -652,8 +652,8 @@ def test_dense_weight_update_adds_partials_of_the_fused_launch_instead_of_reread
     eps0 = torch.from_numpy(native_eps(seed, 0, range(1), nppg, T, n, "float32")).double()
     ora = SC.oracle_panda_planner(c, T, nppg, S, seed=seed, eps_init=eps0)
     scale = float(a.particle_means.abs().max())
-    used = 0
-    for it in range(5):
+    used = armed_before = 0
+    for it in range(8):
         b.particle_means.copy_(a.particle_means)
         ora.particle_means.copy_(a.particle_means.cpu().double())
         ora.prior.set_mean(ora.particle_means.view(nppg, -1))
@@ -669,7 +669,16 @@ def test_dense_weight_update_adds_partials_of_the_fused_launch_instead_of_reread
         assert rel_err(ca, costs_o) < 5e-3
         assert float((a.particle_means.cpu().double() - ora.particle_means).abs().max()) < 1e-3 * scale, it
         used = max(used, a._engine.dense_particles())
-    assert used >= nppg // 2 and b._engine.dense_particles() == -1
+    # the partials are armed by a host-visible word the update kernel sets (no synchronisation, so it lags a step or two):
+    # the first iterations ran round 3's row-reading update, the later ones the partials -- both inside the 1e-6 above
+    armed = a._engine.dense_armed_steps()
+    print(f"\n[dense-weight regime] {armed} of 8 iterations ran with the fused launch's partials armed")
+    assert used >= nppg // 2 and armed >= 4 and b._engine.dense_particles() == -1
+    # one-hot weights (the reference's hyper-parameters): never armed -- the launch stays round 3's
+    h = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=seed)
+    for _ in range(6):
+        h.optimize(opt_iters=1, obstacle_spheres=sph.to(**F32))
+    assert h._engine.dense_particles() == 0 and h._engine.dense_armed_steps() == 0
 
 
 # --------------------------------------------------------------------------- any serial chain on the fast launches

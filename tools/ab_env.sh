@@ -1,6 +1,7 @@
 #!/bin/bash
-# Same-box A/B of ENVIRONMENT switches of one library (e.g. grid sizes): bash tools/ab_env.sh "SGPMP_K3_BLOCKS=1024" "SGPMP_K3_BLOCKS=2048" ""
-for rep in 1 2; do
+# Same-box A/B of ENVIRONMENT switches of one library (e.g. grid sizes): bash tools/ab_env.sh "SGPMP_K3_BLOCKS=1024" "SGPMP_K3_BLOCKS=2048" "SGPMP_X=0"
+REPS=${REPS:-2}
+for rep in $(seq 1 $REPS); do
 for e in "$@"; do
   env $e python3 bench.py --steps 300 --warmup 20 --no-other-configs --no-cpu-baseline --no-parity 2>/dev/null | python3 -c "
 import json,sys
