@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* 2: sgpmp_step gained `flags`, sgpmp_set_priors / pipeline_* / comm_* appeared (round 2); 3: round 3 (see git log);
- * 4: sgpmp_comm_library, sgpmp_set_fk_codegen / sgpmp_fk_codegen_info, sgpmp_step's dense-weight partials (round 4).
+ * 4: sgpmp_comm_library, sgpmp_set_fk_codegen / _info / _compile, sgpmp_dense_particles (round 4).
  * The Python binding refuses any other value at load time. */
 #define SGPMP_ABI_VERSION 4
 

@@ -400,10 +400,12 @@ class Engine:
         seed = int(seed)
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
-        def call(draw, flags=0):
+        def call(draw, flags=0, means_prev=None):
+            """means_prev: another destination for this step's pre-update means (a raw pointer) than the pre-bound one."""
             if torch.cuda.current_device() != dev_index:
                 torch.cuda.set_device(dev_index)
-            L.check(fn(ctx, seed, draw, None, 0, 0, *fixed, flags, L.stream_ptr(dev_index)))
+            args = fixed if means_prev is None else fixed[:5] + (means_prev,) + fixed[6:]
+            L.check(fn(ctx, seed, draw, None, 0, 0, *args, flags, L.stream_ptr(dev_index)))
         return call
 
     def fk(self, q):

@@ -26,8 +26,9 @@ Additions over the reference API (all optional keyword arguments):
                              of squares per goal, all-reduced over the ranks on the side stream -- the "weighted-mean /
                              covariance statistics" of the modes); global_mode_stats() reads them.  False: the same
                              numbers are computed (and all-reduced) when global_mode_stats() is called.
-  clone_outputs=True         optimize() returns CLONES of the pre-update means, as the reference does (planner.py:252-253);
-                             False hands out views of the persistent buffer (two tiny copy launches fewer per call).
+  clone_outputs=True         optimize() returns the pre-update means in a tensor of the call's own, as the reference does with its
+                             clones (planner.py:252-253) -- the call's last step writes them there, so there is no copy;
+                             False hands out views of the persistent buffer.
   state_dict() / load_state_dict()   checkpoint / resume: means, seed, draw counter (the noise is counter-based, so a
                              resumed run -- also under another sharding -- continues bit for bit).
   pipeline_steps=True        optimize(opt_iters >= 2) lets the context run the iterations of the call as two
@@ -260,11 +261,12 @@ class StochGPMP:
             self._costs64 = torch.empty(Pl, S, device=ta['device'], dtype=torch.float64)
             self._weights_buf = torch.empty(Pl, S, **ta)
             self._grad = torch.empty(Pl, T, d, **ta)
-            self._means_prev = torch.empty(Pl, T, d, **ta)
+            self._means_prev_buf = torch.empty(Pl, T, d, **ta)     # pre-update means of a step (scratch of the iterations)
+            self._means_prev = self._means_prev_buf                # ... of the LAST step: the buffer, or the tensor optimize() handed out
             self._stats = torch.zeros(2, L.STAT_SHARDS, 4, device=ta['device'], dtype=torch.float64)
             # views handed back by optimize(): created once, the buffers are persistent
             self._weights = self._weights_buf.view(-1, S, 1, 1)
-            self._views = (self._means_prev[..., :n], self._means_prev[..., -n:],
+            self._views = (self._means_prev_buf[..., :n], self._means_prev_buf[..., -n:],
                            self._samples_buf[..., :n], self._samples_buf[..., -n:])
         else:
             self._engine.stats_wait(None)                # a side-stream all-reduce may still use _stats
@@ -422,9 +424,12 @@ class StochGPMP:
         return mode_moments(buf, self.traj_len, self.d_state_opt)
 
     # ------------------------------------------------------------------------------- the loop
-    def step(self, **observation):
-        """One body of the loop at planner.py:289-299 on this rank's particle shard."""
+    def step(self, _means_prev_out=None, **observation):
+        """One body of the loop at planner.py:289-299 on this rank's particle shard.  (_means_prev_out: where this step leaves
+        its pre-update means -- optimize() passes a fresh tensor for the step whose means it returns.)"""
         self.state_samples = self._samples_buf           # (sample_trajectories may have re-pointed it)
+        prev_out = self._means_prev_buf if _means_prev_out is None else _means_prev_out
+        self._means_prev = prev_out
         if not self._native_cost:
             return self._step_foreign_cost(**observation)
         slot = self._stats_slot
@@ -446,19 +451,19 @@ class StochGPMP:
                     call = self._engine.prepare_step(
                         self.seed, self.particle_means, self.state_samples, self.temperature,
                         self.step_size, costs=self._costs, weights=self._weights_buf, grad=self._grad,
-                        means_prev=self._means_prev, spheres=sph, stats=self._stats[slot])
+                        means_prev=self._means_prev_buf, spheres=sph, stats=self._stats[slot])
                     self._step_calls[key] = call
                 # torch bumps a tensor's version counter on every in-place edit; the kernels do not: if the
                 # means are the same tensor at the version recorded after our last step, only we wrote them
                 pm = self.particle_means
                 kept = pm is self._pm_obj and pm._version == self._pm_version
-                call(self._draw, L.STEP_MEANS_KEPT if kept else 0)
+                call(self._draw, L.STEP_MEANS_KEPT if kept else 0, None if _means_prev_out is None else L.ptr(prev_out))
                 self._pm_obj, self._pm_version = pm, pm._version
                 self._mode_fresh = self.mode_stats_every_step
             else:
                 self._engine.step(self.seed, self._draw, self.particle_means, self.state_samples,
                                   self.temperature, self.step_size, costs=self._costs,
-                                  weights=self._weights_buf, grad=self._grad, means_prev=self._means_prev,
+                                  weights=self._weights_buf, grad=self._grad, means_prev=prev_out,
                                   spheres=self._spheres(observation), eps=self._draw_eps(),
                                   eps_mode_offset=self.p0, stats=self._stats[slot])
                 pm = self.particle_means
@@ -542,7 +547,7 @@ class StochGPMP:
         if opt_iters is None:
             opt_iters = self.opt_iters
         start_time = time.time()
-        costs = approx_grad = None
+        costs = approx_grad = fresh_prev = None
         # Nobody looks at the buffers between the iterations of one call (the reference returns the last
         # iteration's tensors only), so the context may run them as two particle-half chains on streams of its
         # own -- one half's update kernel under the other half's sampler + sweep launch (include/sgpmp.h:
@@ -558,15 +563,18 @@ class StochGPMP:
         try:
             for opt_step in range(opt_iters):
                 start_time_iter = time.time()
-                costs, approx_grad = self.step(**observation)
+                if opt_step == opt_iters - 1 and self.clone_outputs and self.num_particles_local > 0:
+                    fresh_prev = torch.empty_like(self._means_prev_buf)      # (caching allocator: no launch)
+                costs, approx_grad = self.step(_means_prev_out=fresh_prev, **observation)
                 if debug and opt_step % 50 == 0:
                     print_info(opt_step, opt_iters, start_time_iter, start_time, costs)
         finally:
             if piped:
                 self._engine.pipeline_end()
         state_particles, control_particles, state_trajectories, control_samples = self._views
-        if self.clone_outputs:                           # planner.py:252-253: the reference hands out clones of the means
-            state_particles, control_particles = state_particles.clone(), control_particles.clone()
+        if fresh_prev is not None:                       # planner.py:252-253: the reference hands out clones of the means
+            n = self.n_dof                               # (here: a tensor of this call's own, written by its last step -- no copy)
+            state_particles, control_particles = fresh_prev[..., :n], fresh_prev[..., -n:]
         self._recent_control_samples = control_samples
         self._recent_control_particles = control_particles
         self._recent_state_trajectories = state_trajectories
