@@ -151,6 +151,32 @@ def test_mode_statistics_every_step_through_the_rccl_group(one_rank_group):
     assert a.global_mode_stats()[2].tolist() == [48., 48.]
 
 
+def test_mode_statistics_describe_the_current_means_not_the_last_step():
+    """mode_stats=True keeps the statistics the LAST step left.  Before the first step, after reset() and after the caller
+    edited particle_means they describe other means than the current ones (round-3 advisor finding): global_mode_stats()
+    must then answer from the current means, as the mode_stats=False path does."""
+    T, nppg, S, n = 32, 24, 16, 7
+    goals = [SC.PANDA["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n]
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
+    a = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=15, goals=goals, mode_stats=True)
+
+    def check():
+        m, v, c = a.global_mode_stats()
+        dm, dv = _direct_mode_moments(a.particle_means, 2)
+        assert c.tolist() == [float(nppg)] * 2
+        assert float((m - dm).abs().max()) < 1e-12 * float(dm.abs().max())
+        assert float((v - dv).abs().max()) < 1e-9 * float(dv.abs().max()) + 1e-18
+    check()                                                  # before the first step (round 3: count 0, mean 0)
+    a.optimize(opt_iters=2, obstacle_spheres=sph)
+    check()                                                  # the per-step buffer
+    a.particle_means.mul_(1.01)                              # the caller edits the means
+    check()
+    a.optimize(obstacle_spheres=sph)
+    check()
+    a.reset()                                                # new initial means, same engine
+    check()
+
+
 def test_two_chain_steps_with_the_rccl_statistics_allreduce(one_rank_group):
     """optimize(opt_iters=K) with a communicator attached: the iterations run as two particle-half chains, each
     accumulating into its own block of the statistics ring slot; the all-reduce waits for both update kernels
