@@ -225,18 +225,18 @@ __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_
         int k = 0;
         if (use_part) {
             if constexpr (sizeof(real) == 4 && VW == 4) {
-                for (int j = 0; j < gpp; j += 4) {           // (gpp is a multiple of ... any count: the tail below)
+                for (int j = 0; j < gpp; j += 8) {           // eight partial rows in flight per thread (S / 8 of them: 16 at config 3)
                     typedef float f4 __attribute__((ext_vector_type(4)));
-                    f4 v[4];
-                    double cj[4];
+                    f4 v[8];
+                    double cj[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         const int jj = j + u < gpp ? j + u : gpp - 1;
                         cj[u] = j + u < gpp ? coef[jj] : 0.;
                         v[u] = *reinterpret_cast<const f4*>(partials + (size_t)jj * (M + 4) + 4 + m);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < 8; ++u)
 #pragma unroll
                         for (int i = 0; i < VW; ++i) acc[i] = fma(cj[u], (double)v[u][i], acc[i]);
                 }
