@@ -365,6 +365,19 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     // vector instructions (every wave stages the tables), 1-2 % slower as a single launch: not the default.
     const size_t dyn = fused_wave_dyn_lds(n_spheres, F.has_goal ? F.goal.dim0 : 0);
     const bool wave_groups = !with_tail && tg.wave_groups && fused_wave_static_lds<CCp::N>() + dyn <= 10240;
+    // -DSGPMP_FUSED_COEF_LDS=1 (round 4, measured SLOWER, not in the default build): the scan coefficients from an LDS table when the
+    // whole table and the (then dynamic) sphere / state tables leave four workgroups per CU (T <= 64, few spheres); bit-identical.
+#if SGPMP_FUSED_COEF_LDS
+    const size_t cl_dyn = fused_cl_dyn_lds(T, n_spheres, F.has_goal ? F.goal.dim0 : 0);
+    const bool coef_lds = !with_tail && !wave_groups && !tg.no_coef_lds && fused_cl_static_lds<CCp::N>() + cl_dyn <= 40960;
+    if (coef_lds) {
+#define FUSED_LAUNCH_CL(FT_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false, 4, true>), dim3((unsigned)blocks), dim3(256), (unsigned)cl_dyn, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
+        if (ft == SGPMP_FIELD_RBF) FUSED_LAUNCH_CL(SGPMP_FIELD_RBF);
+        else if (ft == SGPMP_FIELD_SDF) FUSED_LAUNCH_CL(SGPMP_FIELD_SDF);
+        else FUSED_LAUNCH_CL(SGPMP_FIELD_OCCUPANCY);
+#undef FUSED_LAUNCH_CL
+    } else
+#endif
     if (wave_groups) {
         long long wblocks = nitems;
         if (tg.k3_blocks > 0 && wblocks > 4 * tg.k3_blocks) wblocks = 4 * tg.k3_blocks;
