@@ -111,7 +111,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
     {"tail_update", &SgpmpToggles::tail_update}, {"small_step", &SgpmpToggles::small_step}, {"comm_packet_event", &SgpmpToggles::comm_packet_event},
-    {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"wave_groups", &SgpmpToggles::wave_groups}, {"no_coef_lds", &SgpmpToggles::no_coef_lds},
+    {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"wave_groups", &SgpmpToggles::wave_groups}, {"no_coef_lds", &SgpmpToggles::no_coef_lds}, {"fused_pipe", &SgpmpToggles::fused_pipe},
     {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
 };
 

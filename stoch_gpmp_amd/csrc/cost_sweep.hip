@@ -378,6 +378,14 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
 #undef FUSED_LAUNCH_CL
     } else
 #endif
+    // `fused_pipe` (round 4, verdict item 1a): the noise phase of chunk c + 1 software-pipelined into the kinematics block of chunk c
+    if (!with_tail && !wave_groups && tg.fused_pipe) {
+#define FUSED_LAUNCH_P(FT_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false, 4, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
+        if (ft == SGPMP_FIELD_RBF) FUSED_LAUNCH_P(SGPMP_FIELD_RBF);
+        else if (ft == SGPMP_FIELD_SDF) FUSED_LAUNCH_P(SGPMP_FIELD_SDF);
+        else FUSED_LAUNCH_P(SGPMP_FIELD_OCCUPANCY);
+#undef FUSED_LAUNCH_P
+    } else
     if (wave_groups) {
         long long wblocks = nitems;
         if (tg.k3_blocks > 0 && wblocks > 4 * tg.k3_blocks) wblocks = 4 * tg.k3_blocks;

@@ -118,6 +118,7 @@ struct SgpmpToggles {
     int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
     int gpmp_cholesky;        // SGPMP_GPMP_CHOLESKY        GPMP solve by round 3's block Cholesky through LDS instead of the register-resident block-Thomas kernel
     int no_dense_partials;    // SGPMP_NO_DENSE_PARTIALS    update_kernel re-reads all rows with weight even when the weights are spread (round 3)
+    int fused_pipe;           // SGPMP_FUSED_PIPE           fused launch with the next chunk's noise phase inside the current chunk's kinematics block (software pipeline in the wave)
     int no_coef_lds;          // SGPMP_NO_COEF_LDS          noise loop of the fused launch reads its scan coefficients by scalar loads (round 2-3) even where the LDS table fits
     int wave_groups;          // SGPMP_WAVE_GROUPS          fused launch as one-wave workgroups with dynamic LDS tables (round 4: measured level, +2.5 % instructions) instead of 256-thread ones
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)

@@ -618,6 +618,28 @@ def test_config2_free_running_ten_iterations_against_the_dense_oracle(golden):
     assert rec["tracking_fraction_per_iteration"][0] == 1.0
 
 
+def test_fused_launch_variants_of_round_4_are_bit_identical():
+    """`wave_groups` (one wave per workgroup, tables in dynamic LDS) and `fused_pipe` (the next chunk's noise phase inside the
+    current chunk's kinematics block, on all 64 lanes) re-cut the fused launch without touching its arithmetic: samples, costs and
+    means equal the default launch's bit for bit over several iterations, rbf and sdf."""
+    for field_type in ("rbf", "sdf"):
+        sph = torch.as_tensor(SC.panda_spheres(num=5)).to(**F32)
+        pls = {}
+        for name in ("default", "wave_groups", "fused_pipe"):
+            pl = hip_panda_planner(SC.PANDA, 64, 40, 32, F32, seed=27, field_type=field_type)
+            if name != "default":
+                pl._engine.set_option(name, 1)
+            pls[name] = pl
+        for it in range(3):
+            for pl in pls.values():
+                pl.optimize(opt_iters=1, obstacle_spheres=sph)
+                assert pl._engine.last_cost_kernel() == "fused_step_kernel"
+            for name in ("wave_groups", "fused_pipe"):
+                a, b = pls["default"], pls[name]
+                assert torch.equal(a.state_samples, b.state_samples), (name, it)
+                assert torch.equal(a._costs, b._costs) and torch.equal(a.particle_means, b.particle_means), (name, it)
+
+
 # --------------------------------------------------------------------------- dense-weight regime of the update
 def test_dense_weight_update_adds_partials_of_the_fused_launch_instead_of_rereading_the_rows():
     """planner.py:263-275 is a softmax.  With the reference's hyper-parameters it is one-hot and update_kernel reads one row;
