@@ -129,12 +129,12 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * on a live context.  Names: force_generic_fk, no_flat_program, no_chain_codegen, no_dual_sweep,
  * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, comm_packet_event,
  * gpmp_cholesky (GPMP solve by round 3's LDS block-Cholesky kernel), no_dense_partials (dense-weight regime: update_kernel re-reads every row with weight, as in round 3),
- * wave_groups (fused launch as one-wave workgroups; measured level, not the default), no_coef_lds (scan coefficients of the
- * fused launch's noise loop by scalar loads even where their LDS table fits),
+
  * no_planar_seg (planar one-launch step through the LDS tile, fused_planar_kernel, even where the lane-per-sample launch applies),
  * pipe_split (1..15) and k3_blocks (count); and, ONLY in a library built with `make EXPERIMENTS=1` (launches that
  * measured slower and are kept for the record; the default library answers SGPMP_EINVAL "unknown option"):
- * tail_update, small_step (0/1: whole-iteration-in-one-launch variants), planar_slabs (0, 2, 4).
+ * tail_update, small_step (0/1: whole-iteration-in-one-launch variants), planar_slabs (0, 2, 4), wave_groups (fused launch as
+ * one-wave workgroups), fused_pipe (the next chunk's noise phase software-pipelined into the current chunk's kinematics block).
  * No reference counterpart. */
 int sgpmp_set_option(sgpmp_ctx* ctx, const char* name, long long value);
 /* Name of the cost-sweep kernel the dispatcher chose at the last sgpmp_cost_eval / sgpmp_step

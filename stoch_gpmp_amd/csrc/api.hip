@@ -128,7 +128,7 @@ static void toggles_from_env(SgpmpToggles& tg) {
     if (const char* e = getenv("SGPMP_TAIL_DEBUG")) tg.tail_debug = atoll(e);
     if (const char* e = getenv("SGPMP_PLANAR_SLABS")) tg.planar_slabs = atoll(e);
 #if !SGPMP_EXPERIMENTS
-    tg.planar_slabs = 0; tg.tail_update = 0; tg.small_step = 0;
+    tg.planar_slabs = 0; tg.tail_update = 0; tg.small_step = 0; tg.wave_groups = 0; tg.fused_pipe = 0;
 #endif
 }
 
@@ -212,7 +212,7 @@ extern "C" int sgpmp_set_option(sgpmp_ctx* c, const char* name, long long value)
     if (std::strcmp(name, "pipe_split") == 0) { c->tg.pipe_split = value; return SGPMP_OK; }
 #if !SGPMP_EXPERIMENTS
     // launches that were measured slower live in `make EXPERIMENTS=1` builds only (csrc/Makefile): unknown here
-    for (const char* x : {"planar_slabs", "tail_update", "small_step"})
+    for (const char* x : {"planar_slabs", "tail_update", "small_step", "wave_groups", "fused_pipe"})
         if (std::strcmp(name, x) == 0)
             return fail(SGPMP_EINVAL, std::string("sgpmp_set_option: unknown option ") + name + " (an EXPERIMENTS=1 build has it)");
 #endif

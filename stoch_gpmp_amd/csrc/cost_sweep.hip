@@ -360,6 +360,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
 #undef FUSED_LAUNCH
 #define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
 #endif
+#if SGPMP_EXPERIMENTS           // round-4 re-cuts of the launch that measured level or slower: `make EXPERIMENTS=1` builds only
     // Opt-in `wave_groups` (round 4): one wave per workgroup when sixteen of them fit the LDS of a CU -- a SIMD's slot is then
     // refilled when its own wave ends, not when the slowest of four does.  Bit-identical; measured level in rate with 2.5 % more
     // vector instructions (every wave stages the tables), 1-2 % slower as a single launch: not the default.
@@ -396,6 +397,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         else FUSED_LAUNCH_W(SGPMP_FIELD_OCCUPANCY);
 #undef FUSED_LAUNCH_W
     } else
+#endif
     if (ft == SGPMP_FIELD_RBF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_RBF, true); else FUSED_LAUNCH(SGPMP_FIELD_RBF, false); }
     else if (ft == SGPMP_FIELD_SDF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_SDF, true); else FUSED_LAUNCH(SGPMP_FIELD_SDF, false); }
     else { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, true); else FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, false); }

@@ -150,7 +150,7 @@ static void run_planner(int n, int T, int P, int P_global, int offset, int S, in
         CHECK(sgpmp_get_prior(c, SGPMP_PRIOR_INIT, nullptr, G_.data(), H_.data()));
     }
     EXPECT(sgpmp_set_option(c, "no_such_switch", 1), SGPMP_EINVAL);
-    for (const char* name : {"no_fused_step", "no_step_pipeline", "no_dense_partials", "wave_groups", "gpmp_cholesky", "comm_packet_event"}) {
+    for (const char* name : {"no_fused_step", "no_step_pipeline", "no_dense_partials", "gpmp_cholesky", "comm_packet_event"}) {
         CHECK(sgpmp_set_option(c, name, 1));
         step(400, 0);
         CHECK(sgpmp_set_option(c, name, 0));

@@ -628,7 +628,7 @@ def test_fused_launch_variants_of_round_4_are_bit_identical():
         for name in ("default", "wave_groups", "fused_pipe"):
             pl = hip_panda_planner(SC.PANDA, 64, 40, 32, F32, seed=27, field_type=field_type)
             if name != "default":
-                pl._engine.set_option(name, 1)
+                _experimental(pl, name, 1)               # (`make EXPERIMENTS=1` builds only)
             pls[name] = pl
         for it in range(3):
             for pl in pls.values():
