@@ -1078,6 +1078,7 @@ def _one_vs_two_launches(build, iters, obs, soft=None, expect_one=True):
     atomics commute only up to the order of the additions)."""
     a, b = build(), build()
     _experimental(a, "tail_update", 1)
+    b._engine.set_option("no_dense_partials", 1)          # (spread weights: the row-reading update is the in-launch update's twin, bit for bit)
     if soft is not None:                                  # a temperature at which many samples carry weight:
         probe = build()                                   # a sixth of the typical cost spread over a particle's samples
         probe.optimize(**obs)
