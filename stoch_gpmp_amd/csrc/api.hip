@@ -144,6 +144,7 @@ static int alloc_prior(sgpmp_ctx* c, PriorDev& p) {
     HIPCHK(hipMalloc(&p.H, sizeof(double) * T * d * d));
     HIPCHK(hipMalloc(&p.iso64, sizeof(double) * T * 8));
     HIPCHK(hipMalloc(&p.iso32, sizeof(float) * T * 8));
+    HIPCHK(hipMalloc(&p.iso32p, sizeof(float) * T * 8));
     HIPCHK(hipMalloc(&p.slabpre, sizeof(float) * 5 * T * 4));
     HIPCHK(hipMalloc(&p.Qinv, sizeof(double) * d * d));
     HIPCHK(hipMalloc(&p.G32, sizeof(float) * T * d * d));
@@ -153,7 +154,7 @@ static int alloc_prior(sgpmp_ctx* c, PriorDev& p) {
 }
 
 static void free_prior(PriorDev& p) {
-    hipFree(p.blocks); hipFree(p.G); hipFree(p.H); hipFree(p.iso64); hipFree(p.iso32); hipFree(p.slabpre);
+    hipFree(p.blocks); hipFree(p.G); hipFree(p.H); hipFree(p.iso64); hipFree(p.iso32); hipFree(p.iso32p); hipFree(p.slabpre);
     hipFree(p.Qinv); hipFree(p.G32); hipFree(p.H32); hipFree(p.status); hipFree(p.Dm); hipFree(p.Em);
     std::memset(&p, 0, sizeof(p));
 }

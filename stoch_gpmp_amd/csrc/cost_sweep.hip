@@ -258,7 +258,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     a.rpp_shift = log2_exact(S);
     a.rpg_shift = F.has_goal ? log2_exact(F.goal.rows_per_goal) : -1;
     FusedArgs fs;
-    fs.coef = prior.iso32; fs.means = (const float*)means; fs.samples = (float*)samples;
+    fs.coef = prior.iso32; fs.coefp = prior.iso32p; fs.means = (const float*)means; fs.samples = (float*)samples;
     fs.seed = seed; fs.draw = draw; fs.mode_offset = mode_offset; fs.S = S;
     fs.gpp = S / SGPMP_FUSED_SPW; fs.gpp_shift = log2_exact(fs.gpp);
     fs.zero_stats = zero_stats;

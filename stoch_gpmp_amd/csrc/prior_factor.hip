@@ -26,6 +26,11 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define TS SGPMP_TILE
 
+// slot of iso32 element l = (g11 g21 g22 h11 h12 h21 h22 0) in a row of iso32p = (g11 g21 | h11 h21 | h12 h22 | g22 0)
+__device__ __forceinline__ int iso_pair_slot(int l) {
+    return l == 0 ? 0 : l == 1 ? 1 : l == 2 ? 6 : l == 3 ? 2 : l == 4 ? 4 : l == 5 ? 3 : l == 6 ? 5 : 7;
+}
+
 // C = alpha * op(A) * op(B) + beta * Cin, all 16x16 row-major tiles in LDS, executed by one wave.
 // v_mfma_f64_16x16x4_f64 operand maps: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
 // D[row = (l>>4) + 4*r][col = l&15], r = 0..3.
@@ -190,6 +195,7 @@ prior_factor_kernel(int n, int T, double c11, double c12, double c22, double dt,
             }
             out.iso64[t * 8 + l] = v;
             out.iso32[t * 8 + l] = (float)v;
+            out.iso32p[t * 8 + iso_pair_slot(l)] = (float)v;
         }
         if (t >= 1) {
             // ---- Schur complement: S = D_{t-1} - C^T C
@@ -292,7 +298,10 @@ prior_factor_iso_kernel(int n, int T, double c11, double c12, double c22, double
         out.G[e] = g; out.H[e] = h;
         out.G32[e] = (float)g; out.H32[e] = (float)h;
     }
-    for (int e = l; e < T * 8; e += 64) { out.iso64[e] = iso_l[e]; out.iso32[e] = (float)iso_l[e]; }
+    for (int e = l; e < T * 8; e += 64) {
+        out.iso64[e] = iso_l[e]; out.iso32[e] = (float)iso_l[e];
+        out.iso32p[(e & ~7) + iso_pair_slot(e & 7)] = (float)iso_l[e];
+    }
 }
 
 hipError_t launch_prior_factor(int n, int T, double dt, double ks, double kg, const double* d_qc_inv,

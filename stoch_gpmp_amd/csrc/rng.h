@@ -86,6 +86,51 @@ __device__ __forceinline__ void box_muller_f64(uint32_t a, uint32_t b, uint32_t 
     z1 = r * s;
 }
 
+// ---- one step of the scan recurrence  y_t = H_t y_{t-1} + G_t eps_t  of an isotropic prior, per (sample, dof):
+//     pn = g11 e_pos + h11 p + h12 v,     vn = g21 e_pos + g22 e_vel + h21 p + h22 v
+// in ONE evaluation order, every product-sum an explicit fma, so that hipcc has no choice of which multiply to fuse with which
+// add (left to -ffp-contract it pairs them differently from kernel to kernel -- and from one unroll factor to another: the
+// round-4 `fused_pipe` experiment came out 1 ulp off the default launch for exactly that reason).  Every launch that samples
+// with the native stream on an isotropic prior goes through this order -- scalar here, two-wide in scan_step2 below -- which
+// makes "the fused launch's samples = sample_iso_kernel's" a property of the source instead of an observation.
+// c: row of PriorDev::iso64 / iso32 = [g11 g21 g22 h11 h12 h21 h22 0].
+__device__ __forceinline__ float sg_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double sg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename real, typename CP>
+__device__ __forceinline__ void scan_step(CP c, real e_pos, real e_vel, real& p, real& v) {
+    real tp = c[0] * e_pos;
+    real tv = sg_fma((real)c[2], e_vel, c[1] * e_pos);
+    tp = sg_fma((real)c[3], p, tp);
+    tv = sg_fma((real)c[5], p, tv);
+    p = sg_fma((real)c[4], v, tp);
+    v = sg_fma((real)c[6], v, tv);
+}
+
+// The same step on the packed-fp32 unit: (p, v) as one register pair, four instructions (v_pk_mul, v_fma, 2 x v_pk_fma with the
+// broadcast operand selected by op_sel) instead of the seven the compiler made of the scalar form.  c: row of PriorDev::iso32p =
+// [g11 g21 | h11 h21 | h12 h22 | g22 0] -- the pairs a packed instruction takes as ONE aligned scalar-register pair.
+typedef float sg_f2 __attribute__((ext_vector_type(2)));
+template <typename CP>
+__device__ __forceinline__ void scan_step2(CP c, float e_pos, float e_vel, sg_f2& pv) {
+    const sg_f2 g = {c[0], c[1]}, h1 = {c[2], c[3]}, h2 = {c[4], c[5]};
+    sg_f2 t = g * (sg_f2){e_pos, e_pos};
+    t.y = __builtin_fmaf(c[6], e_vel, t.y);
+    t = __builtin_elementwise_fma(h1, (sg_f2){pv.x, pv.x}, t);
+    pv = __builtin_elementwise_fma(h2, (sg_f2){pv.y, pv.y}, t);
+}
+
+// Box-Muller for both pairs of one Philox block, the plain multiplies / fmas two-wide: same operations on the same values as
+// two box_muller_f32 calls (z02 = (z0, z2), z13 = (z1, z3)).
+__device__ __forceinline__ void box_muller2_f32(const Philox4& r, sg_f2& z02, sg_f2& z13) {
+    const sg_f2 k = {2.3283064365386963e-10f, 2.3283064365386963e-10f}, h = {1.1641532182693481e-10f, 1.1641532182693481e-10f};
+    const sg_f2 u1 = __builtin_elementwise_fma((sg_f2){(float)r.x, (float)r.z}, k, h);
+    const sg_f2 u2 = (sg_f2){(float)r.y, (float)r.w} * k;          // revolutions
+    const sg_f2 m = (sg_f2){__log2f(u1.x), __log2f(u1.y)} * (sg_f2){-2.0f * 0.6931471805599453f, -2.0f * 0.6931471805599453f};
+    const sg_f2 rr = {__builtin_amdgcn_sqrtf(m.x), __builtin_amdgcn_sqrtf(m.y)};
+    z02 = rr * (sg_f2){__builtin_amdgcn_cosf(u2.x), __builtin_amdgcn_cosf(u2.y)};
+    z13 = rr * (sg_f2){__builtin_amdgcn_sinf(u2.x), __builtin_amdgcn_sinf(u2.y)};
+}
+
 // Noise for waypoint t, dof k of (mode, sample): returns (eps[t, k], eps[t, n + k]).
 // fp32: one Philox call serves waypoints (t, t^1); the caller may cache it via `cache`.
 template <typename real> struct NoiseGen;
@@ -115,6 +160,11 @@ template <> struct NoiseGen<float> {
         const Philox4 r = philox4x32_r((uint32_t)(t_even >> 1) | kk, c1, c2, c3, k0, k1);
         box_muller_f32(r.x, r.y, e[0], e[1]);
         box_muller_f32(r.z, r.w, e[2], e[3]);
+    }
+    // the same four normals as register pairs: z02 = (pos_t, pos_{t+1}), z13 = (vel_t, vel_{t+1})
+    __device__ __forceinline__ void get4p(int t_even, sg_f2& z02, sg_f2& z13) {
+        const Philox4 r = philox4x32_r((uint32_t)(t_even >> 1) | kk, c1, c2, c3, k0, k1);
+        box_muller2_f32(r, z02, z13);
     }
 };
 

@@ -93,10 +93,7 @@ sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*
             if (erow) {
                 const real* e = erow + (size_t)t0 * d + k;
                 for (int tt = 0; tt < tc; ++tt, c += 8, o += d, e += d) {
-                    const real e1 = e[0], e2 = e[n];
-                    const real pn = c[0] * e1 + c[3] * p + c[4] * v;
-                    const real vn = c[1] * e1 + c[2] * e2 + c[5] * p + c[6] * v;
-                    p = pn; v = vn;
+                    scan_step(c, e[0], e[n], p, v);
                     o[0] = p; o[n] = v;
                 }
             } else {
@@ -104,19 +101,15 @@ sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*
                 for (; tt + 2 <= tc; tt += 2, c += 16, o += 2 * d) {     // t0 is even: one RNG block
                     real e[4];
                     gen.get4(t0 + tt, e);
-                    real pn = c[0] * e[0] + c[3] * p + c[4] * v;
-                    real vn = c[1] * e[0] + c[2] * e[1] + c[5] * p + c[6] * v;
-                    o[0] = pn; o[n] = vn;
-                    p = c[8] * e[2] + c[11] * pn + c[12] * vn;
-                    v = c[9] * e[2] + c[10] * e[3] + c[13] * pn + c[14] * vn;
+                    scan_step(c, e[0], e[1], p, v);
+                    o[0] = p; o[n] = v;
+                    scan_step(c + 8, e[2], e[3], p, v);
                     o[d] = p; o[d + n] = v;
                 }
                 if (tt < tc) {                                       // odd tail (last waypoint)
                     real e1, e2;
                     gen.get(t0 + tt, e1, e2);
-                    const real pn = c[0] * e1 + c[3] * p + c[4] * v;
-                    const real vn = c[1] * e1 + c[2] * e2 + c[5] * p + c[6] * v;
-                    p = pn; v = vn;
+                    scan_step(c, e1, e2, p, v);
                     o[0] = p; o[n] = v;
                 }
             }
@@ -215,10 +208,7 @@ sample_iso_small_kernel(int n, int T, int S, const real* __restrict__ coef, cons
             real* o = tile + (size_t)sl_scan * pitch + k_scan;
 #pragma unroll 4
             for (int tt = 0; tt < tc; ++tt, c += 8, o += d) {
-                const real e1 = o[0], e2 = o[n];
-                const real pn = c[0] * e1 + c[3] * p + c[4] * v;
-                const real vn = c[1] * e1 + c[2] * e2 + c[5] * p + c[6] * v;
-                p = pn; v = vn;
+                scan_step(c, o[0], o[n], p, v);
                 o[0] = p; o[n] = v;
             }
         }

@@ -23,6 +23,7 @@ struct PriorDev {
     double* H;         // [T][d][d]
     double* iso64;     // [T][8]  g11 g21 g22 h11 h12 h21 h22 0   (valid when isotropic)
     float* iso32;      // [T][8]
+    float* iso32p;     // [T][8]  g11 g21 | h11 h21 | h12 h22 | g22 0: the same numbers in the pair order of rng.h scan_step2 (fused_step_kernel)
     float* slabpre;    // [5][T][4] (tables 3, 4: segments of 8 and of 16 waypoints, fused_planar_seg.inc)  isotropic priors: prefix products H_t .. H_{start} of the scan's 2 x 2 propagators from the
                        //            start of t's time slab (2 slabs, 4 slabs) and of its in-chunk segment
                        //            (fused_planar_slab.inc), built by the host in fp64
