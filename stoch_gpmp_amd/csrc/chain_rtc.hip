@@ -299,8 +299,8 @@ void rtc_stats(const RtcChain* c, double* compile_s, int* compiled, int* from_ca
     if (from_cache) *from_cache = c ? c->from_cache : 0;
 }
 
-hipError_t rtc_launch(hipFunction_t f, unsigned blocks, hipStream_t stream, void** args, hipEvent_t done) {
-    return hipExtModuleLaunchKernel(f, blocks * 256u, 1, 1, 256, 1, 1, 0, stream, args, nullptr, nullptr, done, 0);
+hipError_t rtc_launch(hipFunction_t f, unsigned blocks, unsigned dyn_lds, hipStream_t stream, void** args, hipEvent_t done) {
+    return hipExtModuleLaunchKernel(f, blocks * 256u, 1, 1, 256, 1, 1, dyn_lds, stream, args, nullptr, nullptr, done, 0);
 }
 
 // Does the generated code describe THIS chain?  Link positions of the distinct links at pseudo-random joint vectors against

@@ -345,26 +345,31 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         if (!f) return hipSuccess;                // (not launched: the caller takes the two-launch path)
         std::memset(&fs.tail, 0, sizeof(fs.tail));
         void* args[] = {&a, &F, &fs};
-        const hipError_t e = rtc_launch(f, (unsigned)blocks, stream, args, nullptr);
+        const hipError_t e = rtc_launch(f, (unsigned)blocks, (unsigned)fused_wave_dyn_lds(n_spheres, F.has_goal ? F.goal.dim0 : 0), stream, args, nullptr);
         if (picked) *picked = "fused_step_kernel (run-time chain code)";
         *launched = e == hipSuccess;
         return e;
     }
+#ifndef SGPMP_FUSED_EXTRA_LDS   // occupancy diagnostic: unused bytes per workgroup, e.g. 8000 -> four workgroups per CU instead of five
+#define SGPMP_FUSED_EXTRA_LDS 0
+#endif
+    // the launch sizes the sphere / state tables (dynamic LDS): 30.7 KB of tiles + these per workgroup, five workgroups per CU while
+    // they stay under 2 KB
+    const size_t dyn = fused_wave_dyn_lds(n_spheres, F.has_goal ? F.goal.dim0 : 0);
     // (`done`, multi-GPU statistics: signalled by this kernel's own dispatch packet -- hipExtLaunchKernelGGL stop
     // event -- instead of a separate barrier packet behind it)
-#define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, TAIL_>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
+#define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, TAIL_>), dim3((unsigned)blocks), dim3(256), (unsigned)dyn + SGPMP_FUSED_EXTRA_LDS, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
 #if SGPMP_EXPERIMENTS
     const bool with_tail = fs.tail.arrive != nullptr;
 #else
     constexpr bool with_tail = false;                     // (fused_tail_eligible is false in this build: fs.tail stays zero)
 #undef FUSED_LAUNCH
-#define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
+#define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false>), dim3((unsigned)blocks), dim3(256), (unsigned)dyn + SGPMP_FUSED_EXTRA_LDS, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
 #endif
 #if SGPMP_EXPERIMENTS           // round-4 re-cuts of the launch that measured level or slower: `make EXPERIMENTS=1` builds only
     // Opt-in `wave_groups` (round 4): one wave per workgroup when sixteen of them fit the LDS of a CU -- a SIMD's slot is then
     // refilled when its own wave ends, not when the slowest of four does.  Bit-identical; measured level in rate with 2.5 % more
     // vector instructions (every wave stages the tables), 1-2 % slower as a single launch: not the default.
-    const size_t dyn = fused_wave_dyn_lds(n_spheres, F.has_goal ? F.goal.dim0 : 0);
     const bool wave_groups = !with_tail && tg.wave_groups && fused_wave_static_lds<CCp::N>() + dyn <= 10240;
     // -DSGPMP_FUSED_COEF_LDS=1 (round 4, measured SLOWER, not in the default build): the scan coefficients from an LDS table when the
     // whole table and the (then dynamic) sphere / state tables leave four workgroups per CU (T <= 64, few spheres); bit-identical.
@@ -479,7 +484,7 @@ static hipError_t cost_dispatch(int n, int T, const CostProgram& h_prog, const C
                 hipFunction_t rf = cg_rtc ? rtc_kernel((RtcChain*)h_chain.rtc, cft, true) : nullptr;
                 if (cg_rtc && rf) {                       // the chain's own kernels, compiled at run time (chain_rtc.hip)
                     void* args[] = {&a, &F, &fs};
-                    const hipError_t e = rtc_launch(rf, (unsigned)cblocks, stream, args, nullptr);
+                    const hipError_t e = rtc_launch(rf, (unsigned)cblocks, 0u, stream, args, nullptr);
                     *picked = "cost_sweep_chunked_kernel (run-time chain code)";
                     return e;
                 }

@@ -159,7 +159,7 @@ const char* comm_allgather(SgpmpComm* c, const void* send, void* recv, size_t by
 struct RtcChain;
 const char* rtc_chain_get(const char* struct_src, int n_dof, RtcChain** out);       // null on success, else the reason
 hipFunction_t rtc_kernel(RtcChain* c, int field_type, bool sweep);                   // compiled on first use; null: unavailable
-hipError_t rtc_launch(hipFunction_t f, unsigned blocks, hipStream_t stream, void** args, hipEvent_t done);
+hipError_t rtc_launch(hipFunction_t f, unsigned blocks, unsigned dyn_lds, hipStream_t stream, void** args, hipEvent_t done);
 const char* rtc_verify(RtcChain* c, const ChainDev& chain, int field_type_hint);     // generated code == this chain?
 const char* rtc_error(const RtcChain* c);
 void rtc_stats(const RtcChain* c, double* compile_s, int* compiled, int* from_cache);
