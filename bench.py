@@ -241,7 +241,10 @@ def other_configs(torch, dev, copy_gbs=None):
     for label, key, spec, steps in specs:
         pl, obs, name = build_planner(torch, dev=dev, **spec)
         time_loop(torch, pl, obs, 150, 0)                        # (clock and chain-stream warm-up, see main())
-        el = time_loop(torch, pl, obs, steps, 10)
+        # (two passes, the faster one reported and both kept: these runs last 7-40 ms, and one host hiccup inside a pass --
+        # round 4 saw a 29 ms stall once -- would otherwise be read as a 5 x slower kernel.  The headline is one pass of K.)
+        els = [time_loop(torch, pl, obs, steps, 10), time_loop(torch, pl, obs, steps, 0)]
+        el = min(els)
         el1 = time_loop(torch, pl, obs, steps, 10, one_call=False)
         kms = kernel_profile(torch, pl, obs, min(steps, 30))
         kernel = pl._engine.last_cost_kernel()
@@ -252,7 +255,7 @@ def other_configs(torch, dev, copy_gbs=None):
                                         spec["P_local"] * spec["S"] * 8, fused, key, copy_gbs,
                                         step_ms=1e3 * el / steps, step_mode="optimize(opt_iters=K)")
         out.append({"config": label, "workload": name, "iterations_per_s": steps / el,
-                    "ms_per_step": 1e3 * el / steps, "steps": steps,
+                    "ms_per_step": 1e3 * el / steps, "steps": steps, "ms_per_step_of_each_pass": [1e3 * e / steps for e in els],
                     "iterations_per_s_single_iteration_calls": steps / el1, "kernel_ms_per_step": kms,
                     "cost_kernel": kernel, "roofline": roof, "roofline_detail": roof_detail,
                     "dtype": "f32" if spec["dtype"] == f32 else "f64"})
