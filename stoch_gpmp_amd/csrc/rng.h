@@ -119,6 +119,17 @@ __device__ __forceinline__ void scan_step2(CP c, float e_pos, float e_vel, sg_f2
     pv = __builtin_elementwise_fma(h2, (sg_f2){pv.y, pv.y}, t);
 }
 
+// ... with the two coefficient rows of a Philox block (waypoints t, t + 1) already in 16 scalar registers (one s_load_dwordx16)
+typedef float sg_f16 __attribute__((ext_vector_type(16)));
+template <int R>
+__device__ __forceinline__ void scan_step2v(const sg_f16& c, float e_pos, float e_vel, sg_f2& pv) {
+    const sg_f2 g = {c[R + 0], c[R + 1]}, h1 = {c[R + 2], c[R + 3]}, h2 = {c[R + 4], c[R + 5]};
+    sg_f2 t = g * (sg_f2){e_pos, e_pos};
+    t.y = __builtin_fmaf(c[R + 6], e_vel, t.y);
+    t = __builtin_elementwise_fma(h1, (sg_f2){pv.x, pv.x}, t);
+    pv = __builtin_elementwise_fma(h2, (sg_f2){pv.y, pv.y}, t);
+}
+
 // Box-Muller for both pairs of one Philox block, the plain multiplies / fmas two-wide: same operations on the same values as
 // two box_muller_f32 calls (z02 = (z0, z2), z13 = (z1, z3)).
 __device__ __forceinline__ void box_muller2_f32(const Philox4& r, sg_f2& z02, sg_f2& z13) {
