@@ -646,6 +646,24 @@ def test_fused_launch_variants_of_round_4_keep_the_arithmetic():
             assert float((a.particle_means - c.particle_means).abs().max()) <= 5e-6, it
 
 
+def test_fused_launch_equals_the_two_launch_path_bitwise_at_every_shape():
+    """Round 4 (`rng.h: scan_step`): every sampler kernel evaluates the scan recurrence in ONE explicit-fma order (the fused
+    launch two-wide, `scan_step2`), so samples, costs and means of the fused launch equal the sampler + sweep pair's bit for
+    bit at EVERY shape -- also where the stand-alone sampler is the small-problem kernel (before, hipcc's choice of which
+    multiply to contract with which add made them differ by an ulp below full size)."""
+    sph = torch.as_tensor(SC.panda_spheres(num=5)).to(**F32)
+    for T, nppg, S in ((64, 40, 32), (32, 8, 8), (16, 3, 8), (48, 5, 24), (128, 6, 16)):
+        a = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=27)
+        b = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=27)
+        b._engine.set_option("no_fused_step", 1)
+        for it in range(2):
+            a.optimize(opt_iters=1, obstacle_spheres=sph)
+            b.optimize(opt_iters=1, obstacle_spheres=sph)
+            assert a._engine.last_cost_kernel() == "fused_step_kernel" and b._engine.last_cost_kernel() != "fused_step_kernel"
+            assert torch.equal(a.state_samples, b.state_samples), (T, nppg, S, it)
+            assert torch.equal(a._costs, b._costs) and torch.equal(a.particle_means, b.particle_means), (T, nppg, S, it)
+
+
 # --------------------------------------------------------------------------- dense-weight regime of the update
 def test_dense_weight_update_adds_partials_of_the_fused_launch_instead_of_rereading_the_rows():
     """planner.py:263-275 is a softmax.  With the reference's hyper-parameters it is one-hot and update_kernel reads one row;
