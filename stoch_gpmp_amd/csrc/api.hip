@@ -913,13 +913,13 @@ extern "C" int sgpmp_update(sgpmp_ctx* c, const void* costs, int costs_dtype, co
     return SGPMP_OK;
 }
 
-// Buffers of the dense-weight regime (allocated once, by the first step that may leave partials: fp32, S a multiple of 8).
+// Buffers of the dense-weight regime (allocated once, by the first step that may leave partials: fp32).
 // Particles whose previous update spread its weight over more than S / 4 rows get partials (a fused wave pays ~6 % for them,
-// the update reads S / 8 rows instead of nnz).
+// the update reads ceil(S / 8) rows instead of nnz).
 static int dense_buffers(sgpmp_ctx* c, FusedDenseHost* d, double temperature) {
     const sgpmp_dims& D = c->dims;
     d->part = nullptr; d->nnz = nullptr; d->flag = nullptr; d->threshold = (unsigned)(D.num_samples / 4); d->temperature = temperature;
-    if (D.dtype != SGPMP_F32 || D.num_samples % 8 != 0 || c->tg.no_dense_partials || D.num_particles < 1) return SGPMP_OK;
+    if (D.dtype != SGPMP_F32 || c->tg.no_dense_partials || D.num_particles < 1) return SGPMP_OK;
     if (!c->d_nnz) {
         const size_t P = (size_t)D.num_particles;
         HIPCHK(hipMalloc(&c->d_nnz, P * sizeof(unsigned)));
@@ -935,7 +935,7 @@ static int dense_buffers(sgpmp_ctx* c, FusedDenseHost* d, double temperature) {
     d->nnz = c->d_nnz; d->flag = c->d_dense_flag;
     if (c->dense_step <= c->dense_armed_until) {
         if (!c->d_part)
-            HIPCHK(hipMalloc(&c->d_part, (size_t)D.num_particles * (size_t)(D.num_samples / 8) * (size_t)(c->M + 4) * sizeof(float)));
+            HIPCHK(hipMalloc(&c->d_part, (size_t)D.num_particles * (size_t)((D.num_samples + 7) / 8) * (size_t)(c->M + 4) * sizeof(float)));
         d->part = c->d_part;
         c->dense_armed_steps += 1;
     }
@@ -1055,7 +1055,7 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
                             temperature, step_size};
         FusedDenseHost dh;
         if ((rc = dense_buffers(c, &dh, temperature)) != SGPMP_OK) return rc;
-        if (dh.part) { dh.part += off * (size_t)(S / 8) * (size_t)(c->M + 4); dh.nnz += off; }
+        if (dh.part) { dh.part += off * (size_t)((S + 7) / 8) * (size_t)(c->M + 4); dh.nnz += off; }
         bool armed = false;
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, mu, Ph,
                                  D.particle_offset + (int)off, S, X, spheres, n_spheres, isw, slot, cs, c64, sh, c->tg,

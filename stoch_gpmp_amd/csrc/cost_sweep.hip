@@ -101,13 +101,16 @@ static int fused_step_kind(int dtype, int n, int T, const PriorDev& prior, const
                            const SgpmpToggles& tg) {
     using CCp = ChainCode_panda;
     if (dtype != SGPMP_F32 || tg.no_fused_step || !prior.isotropic) return 0;
-    if (S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0 || P < 1) return 0;
+    // (S: the chain-code launch masks the rows of a particle's last group of 8 -- round 4; the planar launches want whole groups)
+    if (T % SGPMP_FUSED_TC != 0 || P < 1 || S < 1) return 0;
+    const bool ragged = S % SGPMP_FUSED_SPW != 0;
     if ((long long)P * S + (long long)mode_offset * S >= (1LL << 31)) return 0;
     FlatProg<float> F;
     if (tg.no_flat_program || !make_flat<float>(h_prog, F)) return 0;
-    if (F.has_goal && (F.goal.rows_per_goal % SGPMP_FUSED_SPW != 0 || F.goal.dim0 > SGPMP_FUSED_GOALS)) return 0;
+    if (F.has_goal && (F.goal.rows_per_goal % S != 0 || F.goal.dim0 > SGPMP_FUSED_GOALS)) return 0;   // (a particle has one goal)
     if (F.has_gp && (float)prior.dt != F.gp.dt) return 0;                 // IS term and GP factors share Phi
     if (!h_prog.needs_fk && h_prog.n_ee == 0) {
+        if (ragged) return 0;
         // no link fields: GP / goal prior / occupancy grid on the positions themselves
         if (F.has_self || F.has_sph || (n != 2 && n != 3) || T > SGPMP_PLANAR_TMAX) return 0;
         if (F.has_grid && n < 2) return 0;
@@ -160,6 +163,7 @@ bool fused_tail_eligible(int dtype, int n, int T, const PriorDev& prior, const C
     const int kind = fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
     if (kind != 1) return false;
     const size_t tile_bytes = (size_t)SGPMP_FUSED_SPW * ((((2 * n + 3) / 4) * 4) + SGPMP_FUSED_TC * 2 * n) * 4;
+    if (S % SGPMP_FUSED_SPW != 0) return false;
     if (((long long)P * S / SGPMP_FUSED_SPW + 3) / 4 > (tg.k3_blocks > 0 ? tg.k3_blocks : (1LL << 18))) return false;   // one item per wave
     return T <= 64 * SGPMP_TAIL_MAX_BLOCKS && S <= SGPMP_TAIL_MAX_S && tail_lds_bytes(S, T * 2 * n, 2 * n) <= tile_bytes;
 }
@@ -260,7 +264,8 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     FusedArgs fs;
     fs.coef = prior.iso32; fs.coefp = prior.iso32p; fs.means = (const float*)means; fs.samples = (float*)samples;
     fs.seed = seed; fs.draw = draw; fs.mode_offset = mode_offset; fs.S = S;
-    fs.gpp = S / SGPMP_FUSED_SPW; fs.gpp_shift = log2_exact(fs.gpp);
+    fs.gpp = (S + SGPMP_FUSED_SPW - 1) / SGPMP_FUSED_SPW; fs.gpp_shift = log2_exact(fs.gpp);
+    fs.nitems = (long long)P * fs.gpp;
     fs.zero_stats = zero_stats;
     fs.part = nullptr; fs.nnz_prev = nullptr; fs.nnz_threshold = 0u; fs.inv_temperature = 0.f;
     // softmax partials for the dense-weight regime of the update: chain-code launch whose costs are complete inside it
@@ -282,7 +287,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         fs.part = nullptr;                                    // (the in-launch update gathers its rows itself)
         if (partials_armed) *partials_armed = false;
     }
-    const long long nitems = batch / SGPMP_FUSED_SPW;
+    const long long nitems = kind == 1 ? fs.nitems : batch / SGPMP_FUSED_SPW;
     long long blocks = (nitems + 3) / 4;
     // one item per wave measured fastest at config 3 (4096 workgroups 0.216 ms/iteration, 2048: 0.219,
     // 1024: 0.227): the per-workgroup set-up is small and the hardware dispatcher balances better than

@@ -47,7 +47,7 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                           IswNext<REAL>{isw_prior ? (REAL*)isw_next : nullptr, isw_prior ? isw_prior->Qinv : nullptr, \
                                         isw_prior ? isw_prior->ks : 0., isw_prior ? isw_prior->kg : -1., \
                                         isw_prior ? isw_prior->dt : 0., n, isw_prior ? isw_prior->isotropic : 1}, \
-                          (REAL*)means_copy, (dtype == SGPMP_F32 && M % 4 == 0) ? part : (const float*)nullptr, S / 8, nnz, nnz_threshold, dense_flag)
+                          (REAL*)means_copy, (dtype == SGPMP_F32 && M % 4 == 0) ? part : (const float*)nullptr, (S + 7) / 8, nnz, nnz_threshold, dense_flag)
     if (dtype == SGPMP_F64) {
         if (M % 4 == 0) UPD(double, double, 4); else UPD(double, double, 2);
     } else if (costs_dtype == SGPMP_F64) {

@@ -664,15 +664,45 @@ def test_fused_launch_equals_the_two_launch_path_bitwise_at_every_shape():
             assert torch.equal(a._costs, b._costs) and torch.equal(a.particle_means, b.particle_means), (T, nppg, S, it)
 
 
+def test_fused_launch_at_sample_counts_that_are_not_multiples_of_eight():
+    """Round 4: the Panda launch masks the rows past S in a particle's last group of 8 (before, such S ran the two-launch path
+    at ~1.5 x the time).  Samples bit for bit those of the stand-alone sampler, costs those of the generic sweep to fp32
+    rounding (another summation order), means the same; nothing is written past a particle's rows (the next particle's first
+    rows take part in the same comparison)."""
+    sph = torch.as_tensor(SC.panda_spheres(num=5)).to(**F32)
+    for T, nppg, S in ((32, 5, 12), (64, 7, 30), (16, 3, 100), (32, 4, 7), (32, 6, 1)):
+        a = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=31)
+        b = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=31)
+        b._engine.set_option("no_fused_step", 1)
+        for it in range(3):
+            a.optimize(opt_iters=1, obstacle_spheres=sph)
+            b.optimize(opt_iters=1, obstacle_spheres=sph)
+            assert a._engine.last_cost_kernel() == "fused_step_kernel" and b._engine.last_cost_kernel() != "fused_step_kernel"
+            assert a.state_samples.shape[1] == S
+            assert torch.equal(a.state_samples, b.state_samples), (T, nppg, S, it)
+            assert torch.allclose(a._costs, b._costs, rtol=2e-5, atol=0), (T, nppg, S, it)
+            assert torch.equal(a._costs.argmin(1), b._costs.argmin(1)), (T, nppg, S, it)
+            assert float((a.particle_means - b.particle_means).abs().max()) <= 1e-6 * float(b.particle_means.abs().max()), (T, nppg, S, it)
+    # one optimize(opt_iters=K) call (two chains where the halves are big enough) = K single calls
+    a = hip_panda_planner(SC.PANDA, 32, 200, 100, F32, seed=5)
+    b = hip_panda_planner(SC.PANDA, 32, 200, 100, F32, seed=5)
+    a.optimize(opt_iters=4, obstacle_spheres=sph)
+    assert a._engine.pipeline_split_steps() > 0 if hasattr(a._engine, "pipeline_split_steps") else True
+    for _ in range(4):
+        b.optimize(opt_iters=1, obstacle_spheres=sph)
+    assert torch.equal(a.particle_means, b.particle_means) and torch.equal(a._costs, b._costs) and torch.equal(a.state_samples, b.state_samples)
+
+
 # --------------------------------------------------------------------------- dense-weight regime of the update
-def test_dense_weight_update_adds_partials_of_the_fused_launch_instead_of_rereading_the_rows():
+@pytest.mark.parametrize("S", [64, 44])       # 44: the particle's last group of 8 is half empty
+def test_dense_weight_update_adds_partials_of_the_fused_launch_instead_of_rereading_the_rows(S):
     """planner.py:263-275 is a softmax.  With the reference's hyper-parameters it is one-hot and update_kernel reads one row;
     at a temperature where many samples carry weight, round 3's update re-read every such row.  Now the fused launch leaves a
     softmax partial per 8 rows for the particles whose PREVIOUS update was spread (device-side count, no host round trip) and
     the update adds S / 8 partials: same means / gradient / weights as the row-reading update (`no_dense_partials`) to 1e-6,
     and both follow the fp64 oracle at that temperature."""
     from oracle.native_noise import native_eps
-    n, T, nppg, S, seed = 7, 32, 24, 64, 23
+    n, T, nppg, seed = 7, 32, 24, 23
     sph = torch.as_tensor(SC.panda_spheres(num=5, seed=seed))
     found = None
     # (the importance-sampling term temperature * x^T Sigma^-1 mu grows with the temperature: with the reference's stiff
