@@ -142,9 +142,14 @@ static int alloc_prior(sgpmp_ctx* c, PriorDev& p) {
     HIPCHK(hipMalloc(&p.blocks, sizeof(double) * 4 * d * d));
     HIPCHK(hipMalloc(&p.G, sizeof(double) * T * d * d));
     HIPCHK(hipMalloc(&p.H, sizeof(double) * T * d * d));
+    // (the fp32 tables hold whole chunks of 16 rows, zero past T: the fused launch's last chunk reads them with one scalar load per
+    // two rows whatever T is)
+    const size_t Tpad = ((size_t)T + 15) / 16 * 16;
     HIPCHK(hipMalloc(&p.iso64, sizeof(double) * T * 8));
-    HIPCHK(hipMalloc(&p.iso32, sizeof(float) * T * 8));
-    HIPCHK(hipMalloc(&p.iso32p, sizeof(float) * T * 8));
+    HIPCHK(hipMalloc(&p.iso32, sizeof(float) * Tpad * 8));
+    HIPCHK(hipMalloc(&p.iso32p, sizeof(float) * Tpad * 8));
+    HIPCHK(hipMemset(p.iso32, 0, sizeof(float) * Tpad * 8));
+    HIPCHK(hipMemset(p.iso32p, 0, sizeof(float) * Tpad * 8));
     HIPCHK(hipMalloc(&p.slabpre, sizeof(float) * 5 * T * 4));
     HIPCHK(hipMalloc(&p.Qinv, sizeof(double) * d * d));
     HIPCHK(hipMalloc(&p.G32, sizeof(float) * T * d * d));

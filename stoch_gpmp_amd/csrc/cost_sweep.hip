@@ -102,8 +102,9 @@ static int fused_step_kind(int dtype, int n, int T, const PriorDev& prior, const
     using CCp = ChainCode_panda;
     if (dtype != SGPMP_F32 || tg.no_fused_step || !prior.isotropic) return 0;
     // (S: the chain-code launch masks the rows of a particle's last group of 8 -- round 4; the planar launches want whole groups)
-    if (T % SGPMP_FUSED_TC != 0 || P < 1 || S < 1) return 0;
-    const bool ragged = S % SGPMP_FUSED_SPW != 0;
+    // (T: the chain-code launch masks the columns and cost lanes past T in the last chunk of 16 -- T even: 16-byte rows)
+    if (T < 2 || T % 2 != 0 || P < 1 || S < 1) return 0;
+    const bool ragged = S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0;
     if ((long long)P * S + (long long)mode_offset * S >= (1LL << 31)) return 0;
     FlatProg<float> F;
     if (tg.no_flat_program || !make_flat<float>(h_prog, F)) return 0;
@@ -163,7 +164,7 @@ bool fused_tail_eligible(int dtype, int n, int T, const PriorDev& prior, const C
     const int kind = fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
     if (kind != 1) return false;
     const size_t tile_bytes = (size_t)SGPMP_FUSED_SPW * ((((2 * n + 3) / 4) * 4) + SGPMP_FUSED_TC * 2 * n) * 4;
-    if (S % SGPMP_FUSED_SPW != 0) return false;
+    if (S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0) return false;
     if (((long long)P * S / SGPMP_FUSED_SPW + 3) / 4 > (tg.k3_blocks > 0 ? tg.k3_blocks : (1LL << 18))) return false;   // one item per wave
     return T <= 64 * SGPMP_TAIL_MAX_BLOCKS && S <= SGPMP_TAIL_MAX_S && tail_lds_bytes(S, T * 2 * n, 2 * n) <= tile_bytes;
 }
@@ -346,7 +347,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     if (!fs.tail.arrive) done = nullptr;          // (the statistics are complete after update_kernel, which then carries the event)
     const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
     if (h_chain.plan.codegen_id == 2) {           // this chain's kernels were compiled at run time (chain_rtc.hip)
-        hipFunction_t f = rtc_kernel((RtcChain*)h_chain.rtc, ft, false);
+        hipFunction_t f = rtc_kernel((RtcChain*)h_chain.rtc, ft, false, S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0);
         if (!f) return hipSuccess;                // (not launched: the caller takes the two-launch path)
         std::memset(&fs.tail, 0, sizeof(fs.tail));
         void* args[] = {&a, &F, &fs};
@@ -375,12 +376,13 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     // Opt-in `wave_groups` (round 4): one wave per workgroup when sixteen of them fit the LDS of a CU -- a SIMD's slot is then
     // refilled when its own wave ends, not when the slowest of four does.  Bit-identical; measured level in rate with 2.5 % more
     // vector instructions (every wave stages the tables), 1-2 % slower as a single launch: not the default.
-    const bool wave_groups = !with_tail && tg.wave_groups && fused_wave_static_lds<CCp::N>() + dyn <= 10240;
+    const bool on_grid = S % SGPMP_FUSED_SPW == 0 && T % SGPMP_FUSED_TC == 0;       // (the experimental launches: whole groups / chunks only)
+    const bool wave_groups = on_grid && !with_tail && tg.wave_groups && fused_wave_static_lds<CCp::N>() + dyn <= 10240;
     // -DSGPMP_FUSED_COEF_LDS=1 (round 4, measured SLOWER, not in the default build): the scan coefficients from an LDS table when the
     // whole table and the (then dynamic) sphere / state tables leave four workgroups per CU (T <= 64, few spheres); bit-identical.
 #if SGPMP_FUSED_COEF_LDS
     const size_t cl_dyn = fused_cl_dyn_lds(T, n_spheres, F.has_goal ? F.goal.dim0 : 0);
-    const bool coef_lds = !with_tail && !wave_groups && !tg.no_coef_lds && fused_cl_static_lds<CCp::N>() + cl_dyn <= 40960;
+    const bool coef_lds = on_grid && !with_tail && !wave_groups && !tg.no_coef_lds && fused_cl_static_lds<CCp::N>() + cl_dyn <= 40960;
     if (coef_lds) {
 #define FUSED_LAUNCH_CL(FT_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false, 4, true>), dim3((unsigned)blocks), dim3(256), (unsigned)cl_dyn, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
         if (ft == SGPMP_FIELD_RBF) FUSED_LAUNCH_CL(SGPMP_FIELD_RBF);
@@ -390,7 +392,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     } else
 #endif
     // `fused_pipe` (round 4, verdict item 1a): the noise phase of chunk c + 1 software-pipelined into the kinematics block of chunk c
-    if (!with_tail && !wave_groups && tg.fused_pipe) {
+    if (on_grid && !with_tail && !wave_groups && tg.fused_pipe) {
 #define FUSED_LAUNCH_P(FT_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false, 4, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
         if (ft == SGPMP_FIELD_RBF) FUSED_LAUNCH_P(SGPMP_FIELD_RBF);
         else if (ft == SGPMP_FIELD_SDF) FUSED_LAUNCH_P(SGPMP_FIELD_SDF);
@@ -408,6 +410,14 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
 #undef FUSED_LAUNCH_W
     } else
 #endif
+    // S, T off the launch's grid of 8 rows x 16 waypoints: the instantiation with the masks (fused_step.inc: RAG)
+    if (S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0) {
+#define FUSED_LAUNCH_R(FT_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false, 4, false, false, true>), dim3((unsigned)blocks), dim3(256), (unsigned)dyn, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
+        if (ft == SGPMP_FIELD_RBF) FUSED_LAUNCH_R(SGPMP_FIELD_RBF);
+        else if (ft == SGPMP_FIELD_SDF) FUSED_LAUNCH_R(SGPMP_FIELD_SDF);
+        else FUSED_LAUNCH_R(SGPMP_FIELD_OCCUPANCY);
+#undef FUSED_LAUNCH_R
+    } else
     if (ft == SGPMP_FIELD_RBF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_RBF, true); else FUSED_LAUNCH(SGPMP_FIELD_RBF, false); }
     else if (ft == SGPMP_FIELD_SDF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_SDF, true); else FUSED_LAUNCH(SGPMP_FIELD_SDF, false); }
     else { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, true); else FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, false); }

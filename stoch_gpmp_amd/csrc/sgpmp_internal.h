@@ -158,7 +158,7 @@ const char* comm_allgather(SgpmpComm* c, const void* send, void* recv, size_t by
 // ---------------------------------------------------------------------------------- run-time chain kernels (chain_rtc.hip)
 struct RtcChain;
 const char* rtc_chain_get(const char* struct_src, int n_dof, RtcChain** out);       // null on success, else the reason
-hipFunction_t rtc_kernel(RtcChain* c, int field_type, bool sweep);                   // compiled on first use; null: unavailable
+hipFunction_t rtc_kernel(RtcChain* c, int field_type, bool sweep, bool rag = false); // compiled on first use; null: unavailable (rag: the fused launch for S, T off its 8 x 16 grid)
 hipError_t rtc_launch(hipFunction_t f, unsigned blocks, unsigned dyn_lds, hipStream_t stream, void** args, hipEvent_t done);
 const char* rtc_verify(RtcChain* c, const ChainDev& chain, int field_type_hint);     // generated code == this chain?
 const char* rtc_error(const RtcChain* c);

@@ -293,10 +293,11 @@ def test_panda_fp32_config5_kernel_means_match_fp64_oracle(fused, kernel):
     frac = _report(f"Panda 2 goals x 6 x 16 x 128 rbf ({kernel})", recs)
     assert max(r["cost_rel"] for r in recs) < 5e-3
     assert frac >= 0.99, frac                          # measured: 1.0000
-    # T = 66 is not a multiple of the fused launch's 16-waypoint chunk: always the two-launch path
+    # T = 66 is not a multiple of the fused launch's 16-waypoint chunk: its last chunk holds two waypoints (round 4: the launch
+    # masks the rest; before, such T always ran the two-launch path) -- against the fp64 oracle like every other shape
     recs = _fp32_panda_run(T=66, nppg=6, S=16, iters=3, goals=goals, n_sph=7, field_type='sdf',
-                           expect_kernel="cost_sweep_dual_pf_multi_kernel", fused=fused)
-    frac = _report("Panda 2 goals x 6 x 16 x 66 sdf (dual_pf_multi)", recs)
+                           expect_kernel="fused_step_kernel" if fused is True else "cost_sweep_dual_pf_multi_kernel", fused=fused)
+    frac = _report("Panda 2 goals x 6 x 16 x 66 sdf", recs)
     assert max(r["cost_rel"] for r in recs) < 5e-3 and frac >= 0.99
 
 
@@ -664,13 +665,14 @@ def test_fused_launch_equals_the_two_launch_path_bitwise_at_every_shape():
             assert torch.equal(a._costs, b._costs) and torch.equal(a.particle_means, b.particle_means), (T, nppg, S, it)
 
 
-def test_fused_launch_at_sample_counts_that_are_not_multiples_of_eight():
-    """Round 4: the Panda launch masks the rows past S in a particle's last group of 8 (before, such S ran the two-launch path
-    at ~1.5 x the time).  Samples bit for bit those of the stand-alone sampler, costs those of the generic sweep to fp32
+def test_fused_launch_at_sample_counts_and_lengths_off_its_grid():
+    """Round 4: the Panda launch masks the rows past S in a particle's last group of 8 and the columns / cost lanes past T in
+    the last chunk of 16 waypoints (T even; before, such S or T ran the two-launch path at ~1.5 x the time).  Samples bit for bit those of the stand-alone sampler, costs those of the generic sweep to fp32
     rounding (another summation order), means the same; nothing is written past a particle's rows (the next particle's first
     rows take part in the same comparison)."""
     sph = torch.as_tensor(SC.panda_spheres(num=5)).to(**F32)
-    for T, nppg, S in ((32, 5, 12), (64, 7, 30), (16, 3, 100), (32, 4, 7), (32, 6, 1)):
+    for T, nppg, S in ((32, 5, 12), (64, 7, 30), (16, 3, 100), (32, 4, 7), (32, 6, 1),
+                       (50, 5, 16), (18, 3, 24), (34, 4, 8), (100, 3, 8), (50, 6, 30), (2, 3, 8), (4, 3, 8), (6, 2, 16), (14, 2, 5)):
         a = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=31)
         b = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=31)
         b._engine.set_option("no_fused_step", 1)
@@ -684,8 +686,8 @@ def test_fused_launch_at_sample_counts_that_are_not_multiples_of_eight():
             assert torch.equal(a._costs.argmin(1), b._costs.argmin(1)), (T, nppg, S, it)
             assert float((a.particle_means - b.particle_means).abs().max()) <= 1e-6 * float(b.particle_means.abs().max()), (T, nppg, S, it)
     # one optimize(opt_iters=K) call (two chains where the halves are big enough) = K single calls
-    a = hip_panda_planner(SC.PANDA, 32, 200, 100, F32, seed=5)
-    b = hip_panda_planner(SC.PANDA, 32, 200, 100, F32, seed=5)
+    a = hip_panda_planner(SC.PANDA, 50, 200, 100, F32, seed=5)
+    b = hip_panda_planner(SC.PANDA, 50, 200, 100, F32, seed=5)
     a.optimize(opt_iters=4, obstacle_spheres=sph)
     assert a._engine.pipeline_split_steps() > 0 if hasattr(a._engine, "pipeline_split_steps") else True
     for _ in range(4):
@@ -836,6 +838,16 @@ def test_any_serial_chain_runs_the_fused_launch_through_run_time_chain_code(arm,
                                    is_weights=isw, rows_per_particle=S).reshape(nppg, S)
     assert "run-time chain code" not in pl._engine.last_cost_kernel()
     assert rel_err(generic, fused_costs) < 2e-5
+    # S and T off the fused launch's grid of 8 rows x 16 waypoints: the chain's masked instantiation, against the two-launch path
+    a2 = hip_panda_planner(c, 24, 5, 12, F32, seed=seed, field_type=field_type, chain=chain)
+    b2 = hip_panda_planner(c, 24, 5, 12, F32, seed=seed, field_type=field_type, chain=chain)
+    b2._engine.set_option("no_fused_step", 1)
+    for it in range(2):
+        a2.optimize(obstacle_spheres=sph.to(**F32))
+        b2.optimize(obstacle_spheres=sph.to(**F32))
+        assert a2._engine.last_cost_kernel() == "fused_step_kernel (run-time chain code)", a2._engine.last_cost_kernel()
+        assert torch.equal(a2.state_samples, b2.state_samples) and rel_err(a2._costs, b2._costs) < 2e-5
+        assert float((a2.particle_means - b2.particle_means).abs().max()) <= 1e-6 * float(b2.particle_means.abs().max())
 
 
 def test_chain_code_of_another_robot_is_refused():
@@ -1014,8 +1026,10 @@ def test_api_surface_and_errors(golden):
     (2, 1, 8, 80, "rbf", 64, True),           # five chunks, the sphere-staging limit of the fused launch
     (2, 1, 8, 32, "sdf", 64, True),
     (2, 1, 8, 32, "rbf", 65, False),          # one sphere too many -> sampler + two-trajectory sweep
-    (2, 1, 12, 32, "rbf", 5, False),          # S not a multiple of 8
-    (2, 1, 8, 24, "rbf", 5, False),           # T not a multiple of 16
+    (2, 1, 12, 32, "rbf", 5, True),           # S not a multiple of 8: the launch's masked instantiation (round 4)
+    (2, 1, 8, 24, "rbf", 5, True),            # T not a multiple of 16: likewise
+    (2, 2, 12, 40, "sdf", 5, True),           # both, two goals
+    (2, 1, 8, 25, "rbf", 5, False),           # T odd (rows of 14 T floats are not 16-byte multiples) -> two launches
 ])
 def test_fused_step_corners_match_the_two_launch_path(nppg, G, S, T, field_type, n_sph, fused):
     """sgpmp_step's fused launch (fused_step.inc) against the same step as sampler + sweep: identical
