@@ -1,5 +1,5 @@
 """Are the fused launch's samples the stand-alone samplers' bit for bit at small and odd shapes too?  (rng.h scan_step: one
-evaluation order for every sampler kernel.)  python3 tools/pipe_dbg.py on the GPU box."""
+evaluation order for every sampler kernel.)  python3 tools/fused_vs_two_launch_bits.py on the GPU box."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
