@@ -563,6 +563,31 @@ def test_config3_free_running_ten_iterations_against_the_dense_oracle():
     assert rec["tracking_fraction_per_iteration"][0] == 1.0
 
 
+def test_off_grid_shape_free_running_ten_iterations_against_the_dense_oracle():
+    """The masked instantiation of the fused launch (round 4: S = 100 is not a multiple of 8, T = 50 not of 16) the same way:
+    Panda 256 x 100 x 50, fp32, particles 0, 7, 128, 255, ten iterations without resynchronisation against the dense fp64
+    oracle."""
+    from oracle.native_noise import native_eps
+    T, S, P, seed, n = 50, 100, 256, 59, 7
+    sph = torch.as_tensor(SC.panda_spheres(num=5))
+    pl = hip_panda_planner(SC.PANDA, T, P, S, F32, seed=seed)
+    sub = [0, 7, 128, 255]
+    ora = SC.oracle_panda_planner(SC.PANDA, T, len(sub), S, seed=seed,
+                                  eps_init=torch.zeros(len(sub), 1, T * 2 * n, dtype=torch.float64))
+
+    def set_means(mu):
+        ora.particle_means.copy_(mu)
+        ora.prior.set_mean(ora.particle_means.view(len(sub), -1))
+
+    def step(gidx, draw):
+        eps = torch.from_numpy(native_eps(seed, draw, gidx, S, T, n, "float32")).double()
+        costs, _ = ora.step(eps=eps, obstacle_spheres=sph)
+        return costs, ora.particle_means.clone()
+    rec = _free_run("off the grid: Panda 256 x 100 x 50 fp32 (fused launch, masked instantiation)", pl, sub, set_means, step, 10,
+                    {"obstacle_spheres": sph.to(**F32)}, "fused_step_kernel")
+    assert rec["tracking_fraction_per_iteration"][0] == 1.0
+
+
 def test_config5_share_free_running_ten_iterations_against_the_banded_oracle():
     """BASELINE configs[4]'s per-GPU share (4 goals x 1024 x 256 x 128, shard 3 of 8), three particles, ten free iterations
     against oracle/banded_equiv.py (pinned to the dense oracle at 1e-9)."""
