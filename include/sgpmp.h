@@ -32,9 +32,11 @@ extern "C" {
 #endif
 
 /* 2: sgpmp_step gained `flags`, sgpmp_set_priors / pipeline_* / comm_* appeared (round 2); 3: round 3 (see git log);
- * 4: sgpmp_comm_library, sgpmp_set_fk_codegen / _info / _compile, sgpmp_dense_particles (round 4).
+ * 4: sgpmp_comm_library, sgpmp_set_fk_codegen / _info / _compile, sgpmp_dense_particles (round 4);
+ * 5: SGPMP_STEP_NO_SAMPLES, sgpmp_row_counts_get / _set, sgpmp_store_free_steps, sgpmp_step honours per-mode sampling
+ *    precisions; the options of the retired experiments are gone (round 5).
  * The Python binding refuses any other value at load time. */
-#define SGPMP_ABI_VERSION 4
+#define SGPMP_ABI_VERSION 5
 
 enum { SGPMP_F32 = 0, SGPMP_F64 = 1 };
 enum { SGPMP_PRIOR_INIT = 0, SGPMP_PRIOR_SAMPLE = 1 };
@@ -129,12 +131,10 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * on a live context.  Names: force_generic_fk, no_flat_program, no_chain_codegen, no_dual_sweep,
  * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, comm_packet_event,
  * gpmp_cholesky (GPMP solve by round 3's LDS block-Cholesky kernel), no_dense_partials (dense-weight regime: update_kernel re-reads every row with weight, as in round 3),
-
  * no_planar_seg (planar one-launch step through the LDS tile, fused_planar_kernel, even where the lane-per-sample launch applies),
- * pipe_split (1..15) and k3_blocks (count); and, ONLY in a library built with `make EXPERIMENTS=1` (launches that
- * measured slower and are kept for the record; the default library answers SGPMP_EINVAL "unknown option"):
- * tail_update, small_step (0/1: whole-iteration-in-one-launch variants), planar_slabs (0, 2, 4), wave_groups (fused launch as
- * one-wave workgroups), fused_pipe (the next chunk's noise phase software-pipelined into the current chunk's kinematics block).
+ * planar_store_free (store-free steps also for the lane-per-sample planar launch: bit-identical, measured slower at BASELINE configs[1]),
+ * pipe_split (1..15) and k3_blocks (count).  (The launches that measured slower -- tail_update, small_step, planar_slabs,
+ * wave_groups, fused_pipe -- were removed in round 5; DESIGN.md 8 keeps their numbers and the commit that last held them.)
  * No reference counterpart. */
 int sgpmp_set_option(sgpmp_ctx* ctx, const char* name, long long value);
 /* Name of the cost-sweep kernel the dispatcher chose at the last sgpmp_cost_eval / sgpmp_step
@@ -241,10 +241,17 @@ int sgpmp_update(sgpmp_ctx* ctx, const void* costs, int costs_dtype, const void*
 /* Diagnostic (synchronous): the number of particles whose last update (inside sgpmp_step) spread its weight over more than
  * S / 4 samples.  For those the next step's fused launch leaves softmax partials of every 8 rows and the update adds S / 8
  * partials instead of re-reading the rows (planner.py:263-275 is a softmax; with the reference's hyper-parameters it is
- * one-hot and the count is 0).  -1: the step has not run on that path yet.  The partials are ARMED only while update kernels
- * report such particles (a pinned host word the host reads without synchronising, so arming lags a step or two; it lapses 64
- * steps after the last report): *armed_steps (may be NULL) counts the steps launched with partials so far. */
+ * one-hot and the count is 0).  -1: no fp32 step has run yet.  Which particles get partials is decided on the device, per
+ * particle, from the row count its previous update left (stream-ordered: the same in every run; round 4 armed the partials
+ * from a host word read without synchronisation).  *armed_steps (may be NULL): steps launched with the partials buffer so far. */
 int sgpmp_dense_particles(sgpmp_ctx* ctx, int64_t* count, int64_t* armed_steps);
+/* Those per-particle row counts are state of a run (they decide per particle how the NEXT update forms its sum -- gathered /
+ * regenerated rows, or partials: equal to 1e-6, not bit for bit): StochGPMP.state_dict carries them, reset() clears them.
+ * Synchronous.  get: out HOST uint32[P] (zeros before the first fp32 step); set: in HOST uint32[P], or NULL = all zero. */
+int sgpmp_row_counts_get(sgpmp_ctx* ctx, uint32_t* out);
+int sgpmp_row_counts_set(sgpmp_ctx* ctx, const uint32_t* in);
+/* steps of this context that ran store-free so far (SGPMP_STEP_NO_SAMPLES honoured; tests and bench.py report it) */
+long long sgpmp_store_free_steps(sgpmp_ctx* ctx);
 
 /* One body of the loop at planner.py:289-299 for the context's particle shard:
  * K5 -> K2 -> K3 -> K4 on `stream` (K2 + K3 as ONE launch when the configuration qualifies, see
@@ -264,6 +271,17 @@ int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, in
                                       update kernel prepared for them are then used, and the K5 launch is skipped
                                       (on every path: the fused launch, or else the sampler, zeroes `stats`).
                                       Without the flag (or after anything else wrote the means) K5 runs. */
+#define SGPMP_STEP_NO_SAMPLES 2    /* the caller will not read `samples` of THIS step (iterations 1 .. K - 1 of
+                                      optimize(opt_iters = K): the reference returns the last iteration's tensors only,
+                                      planner.py:289-317).  Where the step runs as one fused launch (fused_step_kernel,
+                                      fused_planar_seg_kernel) it then does not write them -- 470 MB per launch at BASELINE
+                                      configs[2] -- and update_kernel REGENERATES the rows that carry weight from their noise
+                                      keys (one row per particle with the reference's one-hot weights), bit for bit what the
+                                      launch would have stored: means, costs, weights, gradient come out identical to a
+                                      storing step's.  Rows of particles whose previous update spread its weight over more
+                                      than 4 samples are still written (`samples` must be a valid buffer).  A permission,
+                                      not a demand: steps on other paths store as always.  After such a step `samples`
+                                      holds rows of earlier steps. */
 
 /* The loop of planner.py:289-299 itself (`for opt_step in range(opt_iters)`), when its iterations follow each
  * other without the caller looking at the buffers in between: bracket the sgpmp_step calls of one optimize() with
@@ -278,11 +296,8 @@ int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, in
  * usual inside the bracket.  Switch: SGPMP_NO_STEP_PIPELINE / "no_step_pipeline". */
 int sgpmp_pipeline_begin(sgpmp_ctx* ctx, void* stream);
 int sgpmp_pipeline_end(sgpmp_ctx* ctx, void* stream);
-/* Kernels the last sgpmp_step enqueued for its particle range (per chain when it ran as two): 1 = the whole iteration
- * -- sampler, cost sweep, update and the next step's importance-sampling weights -- in ONE launch (csrc/fused_tail.inc:
- * the last wave of every particle updates it; opt-in through the "tail_update" switch, bit-identical results, measured
- * slower than two launches at BASELINE's sizes: DESIGN.md); 2 = fused sampler + sweep, then update_kernel (the default);
- * 3-4 = separate kernels. */
+/* Kernels the last sgpmp_step enqueued for its particle range (per chain when it ran as two): 2 = fused sampler + sweep,
+ * then update_kernel (the default); 3-4 = separate kernels. */
 int sgpmp_last_step_launches(sgpmp_ctx* ctx);
 /* how many steps of this context ran as two chains so far (tests and bench.py report it) */
 long long sgpmp_pipeline_split_steps(sgpmp_ctx* ctx);

@@ -19,7 +19,8 @@ MAX_TERMS, MAX_JOINTS, MAX_DOF, MAX_INTERP = 8, 16, 8, 8
 STAT_SHARDS = 64
 OK, EINVAL, ENOTPD, EHIP, ESTATE = 0, -1, -2, -3, -4
 STEP_MEANS_KEPT = 1
-ABI_VERSION = 4                      # include/sgpmp.h SGPMP_ABI_VERSION
+STEP_NO_SAMPLES = 2
+ABI_VERSION = 5                      # include/sgpmp.h SGPMP_ABI_VERSION
 
 
 class Dims(C.Structure):
@@ -85,6 +86,9 @@ SIGNATURES = {
     "sgpmp_is_weights": (_I, [_P, _P, _I, _D, _P, _P]),
     "sgpmp_update": (_I, [_P, _P, _I, _P, _P, _D, _D, _P, _P, _P, _P, _P]),
     "sgpmp_dense_particles": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
+    "sgpmp_row_counts_get": (_I, [_P, C.POINTER(C.c_uint32)]),
+    "sgpmp_row_counts_set": (_I, [_P, C.POINTER(C.c_uint32)]),
+    "sgpmp_store_free_steps": (C.c_longlong, [_P]),
     "sgpmp_step": (_I, [_P, _U64, _U64, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _D, _D, _P, _I, _P]),
     "sgpmp_fk": (_I, [_P, _P, _I64, _P, _P]),
     "sgpmp_grid_lookup": (_I, [_P, _I, _P, _I64, _P, _P]),

@@ -77,12 +77,6 @@ struct sgpmp_ctx {
     double isw_temperature;
     const char* last_cost_kernel; // name of the cost-sweep kernel the dispatcher picked last
     StepPipe pipe;                // two-chain execution of consecutive steps (sgpmp_pipeline_begin / _end)
-    // K4 inside the fused launch (fused_tail.inc): per-particle arrival counters, per-launch finished-particle
-    // counters and statistics accumulators ([0]: whole range / first half, [1]: second half of a two-chain step);
-    // all zero between launches by construction (the launch's last waves reset them)
-    unsigned* d_arrive = nullptr;    // [P]
-    unsigned* d_done = nullptr;      // [2]
-    double* d_tail_acc = nullptr;    // [2][SGPMP_STAT_SHARDS][4]
     // per-goal mean statistics once per iteration (sgpmp_set_step_mode_stats): the update kernel leaves a snapshot of
     // the new means, a side stream reduces it per goal and all-reduces the sums -- nothing on the steps' own stream
     double* ms_buf = nullptr;        // caller's [G][M+1][2] buffer, or null: off
@@ -92,12 +86,12 @@ struct sgpmp_ctx {
     hipStream_t ms_side = nullptr;   // the side stream when no communicator is attached
     bool ms_used[2] = {false, false};
     unsigned long long ms_step = 0;
-    // dense-weight regime of the update: softmax partials of the fused launch + per-particle row counts (FusedArgs::part)
-    float* d_part = nullptr;         // [P][S / 8][4 + M], allocated by the first step that can use it
-    unsigned* d_nnz = nullptr;       // [P]
-    unsigned* h_dense_flag = nullptr;   // pinned host word: an update kernel found a particle with spread weights
-    unsigned* d_dense_flag = nullptr;   // ... its device address
-    long long dense_step = 0, dense_armed_until = -1, dense_armed_steps = 0;
+    // per particle: rows that carried weight in its last in-step update (written by update_kernel, read by the NEXT step's
+    // launch: which particles get softmax partials -- dense-weight regime, FusedArgs::part -- and, in a store-free step,
+    // which particles' rows are written at all); + the partials themselves
+    float* d_part = nullptr;         // [P][ceil(S / 8)][4 + M], allocated by the first step that can use it
+    unsigned* d_nnz = nullptr;       // [P], allocated (zero) by the first fp32 step
+    long long dense_armed_steps = 0, store_free_steps = 0;
     int last_step_launches = 0;      // kernels the last sgpmp_step enqueued for its particle range (1: everything in one launch)
     hipStream_t k1_side = nullptr;   // sgpmp_set_priors: the second factorisation's stream
     hipEvent_t k1_fork = nullptr;
@@ -110,8 +104,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"k3_no_one", &SgpmpToggles::k3_no_one}, {"k3_no_lds_prefetch", &SgpmpToggles::k3_no_lds_prefetch},
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
-    {"tail_update", &SgpmpToggles::tail_update}, {"small_step", &SgpmpToggles::small_step}, {"comm_packet_event", &SgpmpToggles::comm_packet_event},
-    {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"wave_groups", &SgpmpToggles::wave_groups}, {"no_coef_lds", &SgpmpToggles::no_coef_lds}, {"fused_pipe", &SgpmpToggles::fused_pipe},
+    {"comm_packet_event", &SgpmpToggles::comm_packet_event}, {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"planar_store_free", &SgpmpToggles::planar_store_free},
     {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
 };
 
@@ -125,11 +118,6 @@ static void toggles_from_env(SgpmpToggles& tg) {
     }
     if (const char* e = getenv("SGPMP_K3_BLOCKS")) tg.k3_blocks = atoll(e);
     if (const char* e = getenv("SGPMP_PIPE_SPLIT")) tg.pipe_split = atoll(e);
-    if (const char* e = getenv("SGPMP_TAIL_DEBUG")) tg.tail_debug = atoll(e);
-    if (const char* e = getenv("SGPMP_PLANAR_SLABS")) tg.planar_slabs = atoll(e);
-#if !SGPMP_EXPERIMENTS
-    tg.planar_slabs = 0; tg.tail_update = 0; tg.small_step = 0; tg.wave_groups = 0; tg.fused_pipe = 0;
-#endif
 }
 
 extern "C" int sgpmp_abi_version(void) { return SGPMP_ABI_VERSION; }
@@ -202,12 +190,6 @@ extern "C" int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out) {
     const size_t P = (size_t)(dims->num_particles > 0 ? dims->num_particles : 1);
     HIPCHK(hipMalloc(&c->d_isw, P * (dims->traj_len + 1) * c->d * c->esz));
     HIPCHK(hipMalloc(&c->d_costs64, P * dims->num_samples * sizeof(double)));
-    HIPCHK(hipMalloc(&c->d_arrive, P * sizeof(unsigned)));
-    HIPCHK(hipMalloc(&c->d_done, 2 * sizeof(unsigned)));
-    HIPCHK(hipMalloc(&c->d_tail_acc, 2 * SGPMP_STAT_SHARDS * 4 * sizeof(double)));
-    HIPCHK(hipMemset(c->d_arrive, 0, P * sizeof(unsigned)));
-    HIPCHK(hipMemset(c->d_done, 0, 2 * sizeof(unsigned)));
-    HIPCHK(hipMemset(c->d_tail_acc, 0, 2 * SGPMP_STAT_SHARDS * 4 * sizeof(double)));
     *out = c;
     return SGPMP_OK;
 }
@@ -216,13 +198,6 @@ extern "C" int sgpmp_set_option(sgpmp_ctx* c, const char* name, long long value)
     if (!c || !name) return fail(SGPMP_EINVAL, "sgpmp_set_option: null argument");
     if (std::strcmp(name, "k3_blocks") == 0) { c->tg.k3_blocks = value; return SGPMP_OK; }
     if (std::strcmp(name, "pipe_split") == 0) { c->tg.pipe_split = value; return SGPMP_OK; }
-#if !SGPMP_EXPERIMENTS
-    // launches that were measured slower live in `make EXPERIMENTS=1` builds only (csrc/Makefile): unknown here
-    for (const char* x : {"planar_slabs", "tail_update", "small_step", "wave_groups", "fused_pipe"})
-        if (std::strcmp(name, x) == 0)
-            return fail(SGPMP_EINVAL, std::string("sgpmp_set_option: unknown option ") + name + " (an EXPERIMENTS=1 build has it)");
-#endif
-    if (std::strcmp(name, "planar_slabs") == 0) { c->tg.planar_slabs = value; return SGPMP_OK; }
     for (const auto& t : kToggleNames)
         if (std::strcmp(name, t.name) == 0) { c->tg.*(t.flag) = value != 0; return SGPMP_OK; }
     return fail(SGPMP_EINVAL, std::string("sgpmp_set_option: unknown option ") + name);
@@ -361,9 +336,8 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     free_prior(c->prior[0]);
     free_prior(c->prior[1]);
     hipFree(c->d_qc); hipFree(c->d_prog); hipFree(c->d_chain); hipFree(c->d_isw);
-    hipFree(c->d_costs64); hipFree(c->d_arrive); hipFree(c->d_done); hipFree(c->d_tail_acc);
+    hipFree(c->d_costs64);
     hipFree(c->d_part); hipFree(c->d_nnz);
-    if (c->h_dense_flag) hipHostFree(c->h_dense_flag);
     if (c->ms_side) { hipStreamSynchronize(c->ms_side); hipStreamDestroy(c->ms_side); }
     for (int i = 0; i < 2; ++i) { hipFree(c->ms_snap[i]); if (c->ms_read[i]) hipEventDestroy(c->ms_read[i]); }
     if (c->ms_ready) hipEventDestroy(c->ms_ready);
@@ -383,9 +357,9 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     delete c;
 }
 
-// Prefix products of the scan's 2 x 2 propagators H_t = [[h11, h12], [h21, h22]] from the start of a time slab, for 2 and
-// for 4 slabs per trajectory: what the slab-parallel planar launch (fused_planar_slab.inc) needs to carry a slab's true
-// start state through the slab.  Once per factorisation, in fp64 on the host from K1's coefficients (T x 8 doubles).
+// Prefix products of the scan's 2 x 2 propagators H_t = [[h11, h12], [h21, h22]] from the start of a time segment: what the
+// planar launches need to carry a segment's true start state through the segment (fused_planar.inc: the in-chunk segments,
+// fused_planar_seg.inc: a wave's 8 or 16 waypoints).  Once per factorisation, in fp64 on the host from K1's coefficients.
 static int upload_slab_prefix(sgpmp_ctx* c, PriorDev& p, hipStream_t st) {
     // (only the point-mass launches use the tables: programs without forward kinematics run for n = 2, 3)
     if (!p.isotropic || (c->dims.n_dof != 2 && c->dims.n_dof != 3)) return SGPMP_OK;
@@ -394,12 +368,10 @@ static int upload_slab_prefix(sgpmp_ctx* c, PriorDev& p, hipStream_t st) {
     HIPCHK(hipMemcpyAsync(iso.data(), p.iso64, sizeof(double) * T * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     std::vector<float> tab((size_t)5 * T * 4, 0.f);
-    for (int wi = 0; wi < 5; ++wi) {       // tables: 2 slabs, 4 slabs, the scan's own segments, segments of 8, of 16
-        const int W = wi == 0 ? 2 : 4;
-        if (wi < 2 && T % W) continue;
+    for (int wi = 2; wi < 5; ++wi) {       // tables: (0, 1: unused since round 5,) the scan's own segments, segments of 8, of 16
         // (segments of the in-chunk scan: 16-waypoint chunks cut into 4 segments for n = 2, 2 for n = 3: fused_planar.inc;
         // segments of 8 / 16 waypoints: one wave each in fused_planar_seg.inc)
-        const int L = wi < 2 ? T / W : wi == 2 ? (c->dims.n_dof == 2 ? 4 : 8) : wi == 3 ? 8 : 16;
+        const int L = wi == 2 ? (c->dims.n_dof == 2 ? 4 : 8) : wi == 3 ? 8 : 16;
         double p00 = 1., p01 = 0., p10 = 0., p11 = 1.;
         for (int t = 0; t < T; ++t) {
             if (t % L == 0) { p00 = 1.; p01 = 0.; p10 = 0.; p11 = 1.; }
@@ -918,31 +890,30 @@ extern "C" int sgpmp_update(sgpmp_ctx* c, const void* costs, int costs_dtype, co
     return SGPMP_OK;
 }
 
-// Buffers of the dense-weight regime (allocated once, by the first step that may leave partials: fp32).
+// Buffers the fused launch and update_kernel share across steps (allocated once, by the first fp32 step).
 // Particles whose previous update spread its weight over more than S / 4 rows get partials (a fused wave pays ~6 % for them,
-// the update reads ceil(S / 8) rows instead of nnz).
-static int dense_buffers(sgpmp_ctx* c, FusedDenseHost* d, double temperature) {
+// the update reads ceil(S / 8) rows instead of nnz).  Everything here is a function of stream-ordered device state -- the
+// per-particle counts -- so a run is reproducible, equal as one optimize(K) call or K calls, sharded or not.  (Round 4 armed
+// the partials from a pinned host word read without synchronisation: the step at which a run switched from gathered rows to
+// partials, equal to 1e-6 only, depended on host timing -- advisor finding, round 4.)
+static int dense_buffers(sgpmp_ctx* c, FusedDenseHost* d, double temperature, bool chain_code_step) {
     const sgpmp_dims& D = c->dims;
-    d->part = nullptr; d->nnz = nullptr; d->flag = nullptr; d->threshold = (unsigned)(D.num_samples / 4); d->temperature = temperature;
-    if (D.dtype != SGPMP_F32 || c->tg.no_dense_partials || D.num_particles < 1) return SGPMP_OK;
+    std::memset(d, 0, sizeof(*d));
+    d->threshold = (unsigned)(D.num_samples / 4); d->temperature = temperature;
+    // rows of a store-free step: kept for particles that wanted more rows than update_kernel regenerates in one round --
+    // and for every particle that gets partials (they re-read the rows): never above the partials' threshold
+    d->store_threshold = d->threshold < 4u ? d->threshold : 4u;
+    if (D.dtype != SGPMP_F32 || D.num_particles < 1) return SGPMP_OK;
     if (!c->d_nnz) {
         const size_t P = (size_t)D.num_particles;
         HIPCHK(hipMalloc(&c->d_nnz, P * sizeof(unsigned)));
         HIPCHK(hipMemset(c->d_nnz, 0, P * sizeof(unsigned)));
-        HIPCHK(hipHostMalloc((void**)&c->h_dense_flag, sizeof(unsigned), hipHostMallocDefault));
-        *c->h_dense_flag = 0u;
-        HIPCHK(hipHostGetDevicePointer((void**)&c->d_dense_flag, c->h_dense_flag, 0));
     }
-    // The partials are ARMED only while update kernels keep reporting spread weights (the pinned word, read without any
-    // synchronisation -- it may lag a step or two): with the reference's one-hot weights the fused launch stays exactly round 3's.
-    c->dense_step += 1;
-    if (*(volatile unsigned*)c->h_dense_flag) { c->dense_armed_until = c->dense_step + 64; *(volatile unsigned*)c->h_dense_flag = 0u; }
-    d->nnz = c->d_nnz; d->flag = c->d_dense_flag;
-    if (c->dense_step <= c->dense_armed_until) {
+    d->nnz = c->d_nnz;
+    if (chain_code_step && !c->tg.no_dense_partials && c->M % 4 == 0) {
         if (!c->d_part)
             HIPCHK(hipMalloc(&c->d_part, (size_t)D.num_particles * (size_t)((D.num_samples + 7) / 8) * (size_t)(c->M + 4) * sizeof(float)));
         d->part = c->d_part;
-        c->dense_armed_steps += 1;
     }
     return SGPMP_OK;
 }
@@ -962,6 +933,31 @@ extern "C" int sgpmp_dense_particles(sgpmp_ctx* c, int64_t* count, int64_t* arme
     *count = k;
     return SGPMP_OK;
 }
+
+// The per-particle row counts are part of a run's state (they decide, per particle, how the next step's update forms its
+// sum: gathered / regenerated rows or partials -- equal to 1e-6, not bit for bit): a checkpoint carries them
+// (StochGPMP.state_dict), reset() clears them.  Synchronous.  get: out [P] (zeros before the first fp32 step);
+// set: in [P], or NULL = all zero.
+extern "C" int sgpmp_row_counts_get(sgpmp_ctx* c, uint32_t* out) {
+    if (!c || (!out && c->dims.num_particles > 0)) return fail(SGPMP_EINVAL, "sgpmp_row_counts_get: null argument");
+    const size_t P = (size_t)c->dims.num_particles;
+    if (P == 0) return SGPMP_OK;
+    if (!c->d_nnz) { std::memset(out, 0, P * sizeof(uint32_t)); return SGPMP_OK; }
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, c->d_nnz, P * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SGPMP_OK;
+}
+extern "C" int sgpmp_row_counts_set(sgpmp_ctx* c, const uint32_t* in) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_row_counts_set: null context");
+    const size_t P = (size_t)c->dims.num_particles;
+    if (P == 0 || c->dims.dtype != SGPMP_F32) return SGPMP_OK;
+    HIPCHK(hipDeviceSynchronize());
+    if (!c->d_nnz) HIPCHK(hipMalloc(&c->d_nnz, P * sizeof(unsigned)));
+    if (in) HIPCHK(hipMemcpy(c->d_nnz, in, P * sizeof(uint32_t), hipMemcpyHostToDevice));
+    else HIPCHK(hipMemset(c->d_nnz, 0, P * sizeof(unsigned)));
+    return SGPMP_OK;
+}
+extern "C" long long sgpmp_store_free_steps(sgpmp_ctx* c) { return c ? c->store_free_steps : 0; }
 
 // ---- two-chain steps (StepPipe) ----------------------------------------------------------------------------
 static int pipe_first_half(const sgpmp_ctx* c) {
@@ -1037,9 +1033,13 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
     const bool reduce = c->comm && stats;
     double* slots[2] = {stats, stats ? c->pipe.stats2 : nullptr};
     hipEvent_t k4_done[2] = {nullptr, nullptr};
-    bool tail[2] = {false, false};
+    bool isw_next[2] = {false, false};
     if (reduce)
         COMMCHK(comm_step_begin2(c->comm, c->pipe.side[0], c->pipe.side[1], &slots[0], &slots[1], &k4_done[0], &k4_done[1]));
+    FusedDenseHost dense;                                        // (once per step: both halves share the buffers)
+    if ((rc = dense_buffers(c, &dense, temperature, c->h_prog.needs_fk != 0)) != SGPMP_OK) return rc;
+    dense.nostore = (flags & SGPMP_STEP_NO_SAMPLES) ? 1 : 0;
+    if (dense.part) c->dense_armed_steps += 1;
     for (int h = 0; h < 2; ++h) {
         const size_t off = h ? (size_t)P0 : 0;
         const int Ph = h ? P - P0 : P0;
@@ -1055,19 +1055,16 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
         char* wh = weights ? weights + off * S * w : nullptr;
         char* gh = grad ? grad + off * M * w : nullptr;
         char* mph = means_prev ? means_prev + off * M * w : nullptr;
-        // the update inside the launch when the half qualifies (its last particle writes the statistics into `slot`)
-        FusedTailHost th = {c->d_arrive + off, c->d_done + h, c->d_tail_acc + (size_t)h * SGPMP_STAT_SHARDS * 4, slot, wh, gh, mph,
-                            temperature, step_size};
-        FusedDenseHost dh;
-        if ((rc = dense_buffers(c, &dh, temperature)) != SGPMP_OK) return rc;
-        if (dh.part) { dh.part += off * (size_t)((S + 7) / 8) * (size_t)(c->M + 4); dh.nnz += off; }
+        FusedDenseHost dh = dense;
+        if (dh.part) dh.part += off * (size_t)((S + 7) / 8) * (size_t)(c->M + 4);
+        if (dh.nnz) dh.nnz += off;
         bool armed = false;
+        RegenHost rgh;
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, mu, Ph,
                                  D.particle_offset + (int)off, S, X, spheres, n_spheres, isw, slot, cs, c64, sh, c->tg,
-                                 &c->last_cost_kernel, &launched, &th, k4_done[h], &tail[h], &dh, &armed));
+                                 &c->last_cost_kernel, &launched, &dh, &armed, &rgh));
         if (!launched) return fail(SGPMP_ESTATE, "sgpmp_step: a half of a pipelined step did not qualify for the fused launch");
         c->last_step_launches = 1;
-        if (tail[h]) continue;
         for (int i = 0; i < c->h_prog.n_terms; ++i)
             if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) {
                 HIPCHK(launch_ee_goal(D.dtype, D.n_dof, D.traj_len, c->h_prog.terms[i], c->d_chain, X,
@@ -1075,12 +1072,13 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
                 c->last_step_launches += 1;
             }
         HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, Ph, S, c64, SGPMP_F64, X, mu, temperature, step_size, wh, gh, mph,
-                             slot, sh, c->tg.comm_packet_event ? k4_done[h] : nullptr, &pr, isw, &tail[h], nullptr,
-                             armed ? dh.part : nullptr, dh.nnz, dh.threshold, dh.flag));
+                             slot, sh, c->tg.comm_packet_event ? k4_done[h] : nullptr, &pr, isw, &isw_next[h], nullptr,
+                             armed ? dh.part : nullptr, dh.nnz, dh.threshold, &rgh));
+        if (h == 0 && rgh.recipe != 0) c->store_free_steps += 1;
         if (!c->tg.comm_packet_event && k4_done[h]) HIPCHK(hipEventRecord(k4_done[h], sh));
         c->last_step_launches += 1;
     }
-    c->isw_ready = tail[0] && tail[1]; c->isw_means = means; c->isw_temperature = temperature;
+    c->isw_ready = isw_next[0] && isw_next[1]; c->isw_means = means; c->isw_temperature = temperature;
     if (reduce) COMMCHK(comm_step_end(c->comm, stats, true));
     c->pipe.last_stats = reduce ? nullptr : stats;
     c->pipe.split_steps += 1;
@@ -1181,42 +1179,20 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         HIPCHK(launch_is_weights(D.dtype, D.n_dof, D.traj_len, pr, means, P, temperature, c->d_isw, acc_stats, st));
     if (se) { HIPCHK(hipEventRecord(se->ev[1], st)); se->has[0] = !prepared; }
     c->last_step_launches = prepared ? 0 : 1;
-    // Small problem without forward kinematics: the whole iteration -- sampler, costs, update, next step's weights --
-    // as ONE launch, a workgroup per particle (small_step.inc); bit-identical to the separate launches
-    if (!eps && samples && small_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, P, S, c->tg)) {
-        const int slot = (int)(c->ms_step & 1);
-        if (c->ms_buf && c->ms_used[slot] && hipEventQuery(c->ms_read[slot]) != hipSuccess)
-            HIPCHK(hipStreamWaitEvent(st, c->ms_read[slot], 0));
-        FusedTailHost th = {nullptr, c->d_done, c->d_tail_acc, acc_stats, weights, grad, means_prev, temperature, step_size};
-        if (se) { HIPCHK(hipEventRecord(se->ev[2], st)); se->has[1] = false; }
-        HIPCHK(launch_small_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, seed, draw, means, P, D.particle_offset, S, samples,
-                                 c->d_isw, costs, c->d_costs64, th, c->d_isw, c->ms_buf ? c->ms_snap[slot] : nullptr, st,
-                                 c->tg.comm_packet_event ? k4_done : nullptr));
-        if (!c->tg.comm_packet_event && k4_done) HIPCHK(hipEventRecord(k4_done, st));
-        c->last_cost_kernel = "small_step_kernel";
-        c->last_step_launches += 1;
-        c->isw_ready = true; c->isw_means = means; c->isw_temperature = temperature;
-        if (se) { HIPCHK(hipEventRecord(se->ev[3], st)); HIPCHK(hipEventRecord(se->ev[4], st)); se->has[3] = false; }
-        if (c->ms_buf) {
-            if ((rc = step_mode_stats(c, slot, st)) != SGPMP_OK) return rc;
-            c->ms_step += 1;
-        }
-        if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats, false));
-        return SGPMP_OK;
-    }
-    bool tail_ran = false;                                       // the update ran inside the fused launch
-    FusedDenseHost dense = {nullptr, nullptr, 0u, temperature, nullptr};   // softmax partials for the dense-weight regime of the update
+    FusedDenseHost dense;                                        // what the launch and the update share per particle (row counts, partials)
+    std::memset(&dense, 0, sizeof(dense));
     bool partials = false;
+    RegenHost regen;                                             // store-free step: how the update regenerates rows
+    std::memset(&regen, 0, sizeof(regen));
     if (fused) {
         if (se) { HIPCHK(hipEventRecord(se->ev[2], st)); se->has[1] = false; }   // (fused: the whole launch is booked on the sweep)
-        // ... and the update too when the step qualifies (fused_tail.inc): ONE launch per iteration
-        FusedTailHost th = {c->d_arrive, c->d_done, c->d_tail_acc, acc_stats, weights, grad, means_prev, temperature, step_size};
-        if ((rc = dense_buffers(c, &dense, temperature)) != SGPMP_OK) return rc;
+        if ((rc = dense_buffers(c, &dense, temperature, c->h_prog.needs_fk != 0)) != SGPMP_OK) return rc;
+        // (per-goal mean statistics and the profiler read nothing of the samples either: they do not stand in the way)
+        dense.nostore = (flags & SGPMP_STEP_NO_SAMPLES) ? 1 : 0;
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, means, P,
                                  D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, acc_stats, costs,
-                                 c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, c->ms_buf ? nullptr : &th, k4_done,
-                                 &tail_ran, &dense, &partials));
-        if (fused) c->last_step_launches += 1;
+                                 c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, &dense, &partials, &regen));
+        if (fused) { c->last_step_launches += 1; if (partials) c->dense_armed_steps += 1; if (regen.recipe != 0) c->store_free_steps += 1; }
         for (int i = 0; fused && i < c->h_prog.n_terms; ++i)
             if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) {
                 HIPCHK(launch_ee_goal(D.dtype, D.n_dof, D.traj_len, c->h_prog.terms[i], c->d_chain, samples,
@@ -1236,8 +1212,8 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     if (se) HIPCHK(hipEventRecord(se->ev[3], st));
     // (the update also prepares the NEXT step's importance-sampling weights -- unless, as a kernel of its own, the new
     // means do not fit its LDS beside the weights: launch_update decides)
-    bool isw_written = tail_ran;
-    if (!tail_ran) {
+    bool isw_written = false;
+    {
         // per-goal mean statistics (sgpmp_set_step_mode_stats): the update kernel also leaves a snapshot of the new
         // means for the side stream; a snapshot is reused two steps later -- by then its reduction has long finished
         // (host-side query; the stream wait is the never-taken fallback)
@@ -1248,7 +1224,8 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
                              temperature, step_size, weights, grad, means_prev, acc_stats, st,
                              c->tg.comm_packet_event ? k4_done : nullptr, &pr, c->d_isw,
                              &isw_written, c->ms_buf ? c->ms_snap[slot] : nullptr,
-                             (fused && partials) ? dense.part : nullptr, dense.nnz, dense.threshold, dense.flag));
+                             (fused && partials) ? dense.part : nullptr, fused ? dense.nnz : nullptr, dense.threshold,
+                             (fused && regen.recipe != 0) ? &regen : nullptr));
         if (!c->tg.comm_packet_event && k4_done) HIPCHK(hipEventRecord(k4_done, st));
         c->last_step_launches += 1;
         if (c->ms_buf) {
@@ -1257,7 +1234,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         }
     }
     c->isw_ready = isw_written; c->isw_means = means; c->isw_temperature = temperature;
-    if (se) { HIPCHK(hipEventRecord(se->ev[4], st)); se->has[3] = !tail_ran; }
+    if (se) { HIPCHK(hipEventRecord(se->ev[4], st)); se->has[3] = true; }
     // multi-GPU: sum the statistics over all ranks on the side stream (never gates the next step)
     if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats, false));
     return SGPMP_OK;

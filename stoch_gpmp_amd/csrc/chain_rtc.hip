@@ -75,7 +75,7 @@ const char* load_hiprtc() {
 
 // every file the run-time translation unit includes (a change of any of them changes the cache key)
 const char* const kSources[] = {"sgpmp_internal.h", "rng.h", "update_common.h", "cost_device.h", "cost_sweep_kernel.inc",
-                                "cost_sweep_dual.inc", "fused_tail.inc", "fused_step.inc", "../../include/sgpmp.h"};
+                                "cost_sweep_dual.inc", "fused_step.inc", "../../include/sgpmp.h"};
 
 bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 
@@ -143,13 +143,13 @@ static std::string translation_unit(const RtcChain& c) {
           "#include \"fused_step.inc\"\n"
           "extern \"C\" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGPMP_FUSED_WAVES, SGPMP_FUSED_WAVES)))\n"
           "sgpmp_rtc_fused(const CostArgs<float> a, const FlatProg<float> F, const FusedArgs s) {\n"
-          "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, false, false>(a, F, s);\n}\n"
+          "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, false>(a, F, s);\n}\n"
           "extern \"C\" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGPMP_FUSED_WAVES, SGPMP_FUSED_WAVES)))\n"
           "sgpmp_rtc_fused_rag(const CostArgs<float> a, const FlatProg<float> F, const FusedArgs s) {\n"
-          "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, false, false, 4, false, false, true>(a, F, s);\n}\n"
+          "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, false, true>(a, F, s);\n}\n"
           "extern \"C\" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGPMP_FUSED_WAVES, SGPMP_FUSED_WAVES)))\n"
           "sgpmp_rtc_sweep(const CostArgs<float> a, const FlatProg<float> F, const FusedArgs s) {\n"
-          "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, true, false>(a, F, s);\n}\n"
+          "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, true>(a, F, s);\n}\n"
           // what the host checks the generated code against: link positions at given joint vectors and the link / pair tables
           "extern \"C\" __global__ void sgpmp_rtc_probe(const float* __restrict__ q, int K, float* __restrict__ pos, float* __restrict__ tab) {\n"
           "    using CC = ChainCode_rt;\n"
@@ -179,9 +179,8 @@ static bool compile_tu(const std::string& tu, const std::string& dir, int ft, st
         return false;
     }
     const std::string inc = "-I" + dir, ftd = "-DSGPMP_RTC_FT=" + std::to_string(ft),
-                      rounds = "-DSGPMP_PHILOX_ROUNDS=" + std::to_string(SGPMP_PHILOX_ROUNDS),
-                      exper = "-DSGPMP_EXPERIMENTS=" + std::to_string(SGPMP_EXPERIMENTS);
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str(), ftd.c_str(), rounds.c_str(), exper.c_str()};
+                      rounds = "-DSGPMP_PHILOX_ROUNDS=" + std::to_string(SGPMP_PHILOX_ROUNDS);
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str(), ftd.c_str(), rounds.c_str()};
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     const hiprtcResult r = g_rtc.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
@@ -230,7 +229,7 @@ static bool build_module(RtcChain& c, int ft) {
     const std::string tu = translation_unit(c);
     // cache key: the translation unit, the field type, the build parameters and the state of every included file
     uint64_t key = fnv1a(14695981039346656037ull, tu.data(), tu.size());
-    const int params[4] = {ft, SGPMP_PHILOX_ROUNDS, SGPMP_ABI_VERSION, SGPMP_EXPERIMENTS};
+    const int params[3] = {ft, SGPMP_PHILOX_ROUNDS, SGPMP_ABI_VERSION};
     key = fnv1a(key, params, sizeof(params));
     for (const char* f : kSources) {
         struct stat st;

@@ -89,10 +89,6 @@ static bool make_flat(const CostProgram& p, FlatProg<real>& f) {
 #include "fused_step.inc"
 #include "fused_planar.inc"
 #include "fused_planar_seg.inc"
-#if SGPMP_EXPERIMENTS            // measured slower, kept for the record (make EXPERIMENTS=1)
-#include "fused_planar_slab.inc"
-#include "small_step.inc"
-#endif
 
 // Does a step qualify for a fused launch?  1: chain-code program (fused_step.inc), 2: program without forward
 // kinematics (fused_planar.inc), 0: no.
@@ -151,90 +147,22 @@ bool planar_seg_step(int dtype, int n, int T, const PriorDev& prior, const CostP
            planar_seg_len(n, T, S, tg) != 0;
 }
 
-// Can the fused launch also do the update (K4 by the last wave of every particle, fused_tail.inc)?  The step must
-// qualify for the fused launch, its costs must be complete inside the launch (no end-effector term: ee_goal_kernel
-// adds to them afterwards) and the tail's scratch must fit a wave's tile.
-bool fused_tail_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
-                         const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
-                         const SgpmpToggles& tg) {
-#if !SGPMP_EXPERIMENTS
-    return false;                                        // (fused_tail.inc is compiled under make EXPERIMENTS=1 only)
-#endif
-    if (!tg.tail_update || h_prog.n_ee > 0) return false;
+// Which rows would update_kernel have to regenerate if this step ran store-free?  1: fused_step_kernel's, 2:
+// fused_planar_seg_kernel's (*seg_len waypoints per segment), 0: the step's launch has no store-free form (the tile launch
+// fused_planar_kernel, the two-launch paths) or its costs are not complete inside the launch (ee_goal_kernel reads the rows).
+int fused_step_regen_recipe(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
+                            int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg, int* seg_len) {
+    if (seg_len) *seg_len = 0;
     const int kind = fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
-    if (kind != 1) return false;
-    const size_t tile_bytes = (size_t)SGPMP_FUSED_SPW * ((((2 * n + 3) / 4) * 4) + SGPMP_FUSED_TC * 2 * n) * 4;
-    if (S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0) return false;
-    if (((long long)P * S / SGPMP_FUSED_SPW + 3) / 4 > (tg.k3_blocks > 0 ? tg.k3_blocks : (1LL << 18))) return false;   // one item per wave
-    return T <= 64 * SGPMP_TAIL_MAX_BLOCKS && S <= SGPMP_TAIL_MAX_S && tail_lds_bytes(S, T * 2 * n, 2 * n) <= tile_bytes;
-}
-
-// ---- the whole iteration in one launch for small problems without forward kinematics (small_step.inc)
-static size_t small_step_lds(int n, int T, int S, size_t esz) {
-    const size_t M = (size_t)T * 2 * n;
-    const size_t upd = (((size_t)S * 12 + 15) & ~(size_t)15) + M * esz;                 // update_particle's scratch ...
-    const size_t scan = ((size_t)T * 4 + (size_t)S * n * 8 * 2) * esz;                   // ... which the slab scan uses first
-    return (size_t)S * (M + 4) * esz + (size_t)T * 8 * esz + (M + (size_t)(T + 1) * 2 * n + 4 * n + 2) * esz + (size_t)S * 8 +
-           (upd > scan ? upd : scan) + 64;
-}
-
-bool small_step_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, int P, int S,
-                         const SgpmpToggles& tg) {
-#if !SGPMP_EXPERIMENTS
-    return false;                                        // (small_step.inc is compiled under make EXPERIMENTS=1 only)
-#endif
-    if (!tg.small_step || !prior.isotropic || h_prog.needs_fk || h_prog.n_ee > 0 || (n != 2 && n != 3) || P < 1) return false;
-    if (dtype == SGPMP_F32) { FlatProg<float> F; if (!make_flat<float>(h_prog, F) || (F.has_gp && (float)prior.dt != F.gp.dt)) return false; }
-    else { FlatProg<double> F; if (!make_flat<double>(h_prog, F) || (F.has_gp && prior.dt != F.gp.dt)) return false; }
-    // one workgroup per particle holds its S x T x d samples in LDS; worth it while the launch is a handful of
-    // workgroups per CU (beyond that the per-kernel launches are not latency-bound any more)
-    return small_step_lds(n, T, S, dtype == SGPMP_F64 ? 8 : 4) <= 64 * 1024 && P <= 1024;
-}
-
-#if SGPMP_EXPERIMENTS
-template <typename real>
-static hipError_t small_step_launch(int n, int T, const PriorDev& prior, const CostProgram& h_prog, uint64_t seed, uint64_t draw,
-                                    void* means, int P, int mode_offset, int S, void* samples, const void* isw, void* costs,
-                                    double* costs64, const FusedTailHost& th, void* isw_next, void* means_copy,
-                                    hipStream_t stream, hipEvent_t done) {
-    FlatProg<real> F;
-    make_flat<real>(h_prog, F);
-    CostArgs<real> a;
-    std::memset(&a, 0, sizeof(a));
-    a.T = T; a.batch = (long long)P * S; a.batch_offset = (long long)mode_offset * S; a.isw = (const real*)isw;
-    a.rows_per_particle = S; a.is_dt = (real)prior.dt; a.costs = (real*)costs; a.costs64 = costs64;
-    a.rpp_shift = a.rpg_shift = -1;
-    SmallArgs s;
-    std::memset(&s, 0, sizeof(s));
-    s.coef = sizeof(real) == 8 ? (const void*)prior.iso64 : (const void*)prior.iso32;
-    s.means = means; s.samples = samples; s.seed = seed; s.draw = draw; s.mode_offset = mode_offset; s.S = S; s.P = P;
-    s.temperature = th.temperature; s.step_size = th.step_size; s.weights = th.weights; s.grad = th.grad;
-    s.means_prev = th.means_prev; s.done = th.done; s.acc = th.acc; s.stats_out = th.stats_out; s.means_copy = means_copy;
-    IswNext<real> nx{(real*)isw_next, prior.Qinv, prior.ks, prior.kg, prior.dt, n, prior.isotropic};
-    const size_t lds = small_step_lds(n, T, S, sizeof(real));
-    if (n == 2)
-        hipExtLaunchKernelGGL((small_step_kernel<real, 2>), dim3((unsigned)P), dim3(SGPMP_SMALL_THREADS), (unsigned)lds, stream, (hipEvent_t) nullptr, done,
-                              0u, a, F, s, nx);
-    else
-        hipExtLaunchKernelGGL((small_step_kernel<real, 3>), dim3((unsigned)P), dim3(SGPMP_SMALL_THREADS), (unsigned)lds, stream, (hipEvent_t) nullptr, done,
-                              0u, a, F, s, nx);
-    return hipGetLastError();
-}
-
-#endif
-hipError_t launch_small_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, uint64_t seed,
-                             uint64_t draw, void* means, int P, int mode_offset, int S, void* samples, const void* isw,
-                             void* costs, double* costs64, const FusedTailHost& th, void* isw_next, void* means_copy,
-                             hipStream_t stream, hipEvent_t done) {
-#if !SGPMP_EXPERIMENTS
-    return hipErrorNotSupported;                          // (never reached: small_step_eligible is false in this build)
-#else
-    if (dtype == SGPMP_F64)
-        return small_step_launch<double>(n, T, prior, h_prog, seed, draw, means, P, mode_offset, S, samples, isw, costs, costs64,
-                                         th, isw_next, means_copy, stream, done);
-    return small_step_launch<float>(n, T, prior, h_prog, seed, draw, means, P, mode_offset, S, samples, isw, costs, costs64, th,
-                                    isw_next, means_copy, stream, done);
-#endif
+    if (kind == 0 || h_prog.n_ee > 0) return 0;
+    if (kind == 1) return 1;
+    // (the lane-per-sample planar launch: built, bit-identical, and measured slower store-free at config 2 -- its update kernel is
+    // not hidden under another chain's launch, and regenerating a row costs it more than the launch saves: opt-in)
+    if (!tg.planar_store_free) return 0;
+    const int L = planar_seg_len(n, T, S, tg);
+    if (!L || (long long)P * S / 64 > (1LL << 20)) return 0;
+    if (seg_len) *seg_len = L;
+    return 2;
 }
 
 // K2 + K3 in one launch when the step qualifies; *launched says whether it did.
@@ -243,11 +171,10 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                              int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
                              const void* isw, double* zero_stats, void* costs, double* costs64,
                              hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched,
-                             const FusedTailHost* tail, hipEvent_t done, bool* tail_ran, const FusedDenseHost* dense,
-                             bool* partials_armed) {
+                             const FusedDenseHost* dense, bool* partials_armed, RegenHost* regen) {
     *launched = false;
-    if (tail_ran) *tail_ran = false;
     if (partials_armed) *partials_armed = false;
+    if (regen) std::memset(regen, 0, sizeof(*regen));
     using CCp = ChainCode_panda;
     const int kind = (!samples || !isw) ? 0 : fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
     if (kind == 0) return hipSuccess;
@@ -269,24 +196,25 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     fs.nitems = (long long)P * fs.gpp;
     fs.zero_stats = zero_stats;
     fs.part = nullptr; fs.nnz_prev = nullptr; fs.nnz_threshold = 0u; fs.inv_temperature = 0.f;
+    fs.nostore = 0; fs.store_threshold = 0u;
+    if (dense && dense->nnz) fs.nnz_prev = dense->nnz;
     // softmax partials for the dense-weight regime of the update: chain-code launch whose costs are complete inside it
     if (kind == 1 && dense && dense->part && dense->nnz && h_prog.n_ee == 0 && !tg.no_dense_partials && (T * 2 * n) % 4 == 0) {
-        fs.part = dense->part; fs.nnz_prev = dense->nnz; fs.nnz_threshold = dense->threshold;
+        fs.part = dense->part; fs.nnz_threshold = dense->threshold;
         fs.inv_temperature = (float)(1. / dense->temperature);
         if (partials_armed) *partials_armed = true;
     }
-    std::memset(&fs.tail, 0, sizeof(fs.tail));
-    if (tail && fused_tail_eligible(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg)) {
-        TailArgs& t = fs.tail;
-        t.arrive = tail->arrive; t.done = tail->done; t.acc = tail->acc; t.stats_out = tail->stats_out;
-        t.means = (float*)const_cast<void*>(means); t.weights = (float*)tail->weights; t.grad = (float*)tail->grad;
-        t.means_prev = (float*)tail->means_prev; t.isw_next = (float*)const_cast<void*>(isw);
-        t.Qinv = prior.Qinv; t.ks = prior.ks; t.kg = prior.kg; t.dt = prior.dt;
-        t.temperature = tail->temperature; t.step_size = tail->step_size; t.isotropic = prior.isotropic; t.P = P;
-        t.debug = (int)tg.tail_debug;
-        fs.zero_stats = nullptr;                              // (the launch's last particle writes the statistics)
-        fs.part = nullptr;                                    // (the in-launch update gathers its rows itself)
-        if (partials_armed) *partials_armed = false;
+    // store-free step: the caller does not read this step's samples and the update behind the launch can regenerate rows
+    if (dense && dense->nostore && dense->nnz && regen) {
+        int L = 0;
+        const int recipe = fused_step_regen_recipe(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg, &L);
+        if (recipe != 0 && update_regen_rows(dtype, n, T, S, recipe) > 0) {
+            fs.nostore = 1; fs.store_threshold = dense->store_threshold;
+            regen->recipe = recipe; regen->L = L; regen->seed = seed; regen->draw = draw; regen->mode_offset = mode_offset;
+            regen->coef = recipe == 1 ? prior.iso32p : prior.iso32;
+            regen->pre = recipe == 2 ? prior.slabpre + (size_t)(L == 8 ? 3 : 4) * T * 4 : nullptr;
+            regen->store_threshold = dense->store_threshold;
+        }
     }
     const long long nitems = kind == 1 ? fs.nitems : batch / SGPMP_FUSED_SPW;
     long long blocks = (nitems + 3) / 4;
@@ -297,30 +225,6 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     if (tg.k3_blocks > 0) cap = tg.k3_blocks;
     if (blocks > cap) blocks = cap;
     if (kind == 2) {
-        // Opt-in (planar_slabs = 2 / 4): the trajectory split into W time slabs over the waves of a workgroup
-        // (fused_planar_slab.inc), when the slabs are whole 16-waypoint chunks of at most 64 waypoints and the items
-        // fill the workgroups.  Same results; measured level with fused_planar_kernel at config 2 (23.2 vs 22.4 us:
-        // 35 % more vector instructions and two rounds of workgroups eat what the shorter chains gain).
-#if SGPMP_EXPERIMENTS
-        int W = 0;
-        const long long force = tg.planar_slabs;
-        auto fits = [&](int w) { return T % (SGPMP_FUSED_TC * w) == 0 && T / w <= 64 && nitems % (4 / w) == 0 && nitems * w / 4 <= cap; };
-        if (force == 4 && fits(4)) W = 4;
-        else if ((force == 2 || force == 4) && fits(2)) W = 2;
-        if (W) {
-            const int d = 2 * n, head = ((d + 3) / 4) * 4, L = T / W;
-            const size_t lds = (size_t)4 * ((size_t)SGPMP_FUSED_SPW * (head + L * d) + (size_t)2 * L * d + (size_t)L * 16) * sizeof(float);
-            const float* tab = prior.slabpre + (size_t)(W == 4 ? 1 : 0) * T * 4;
-            const unsigned wgs = (unsigned)(nitems * W / 4);
-#define SLAB_LAUNCH(NN, WW) hipLaunchKernelGGL((fused_planar_slab_kernel<NN, WW>), dim3(wgs), dim3(256), (unsigned)lds, stream, a, F, fs, tab)
-            if (n == 2) { if (W == 4) SLAB_LAUNCH(2, 4); else SLAB_LAUNCH(2, 2); }
-            else { if (W == 4) SLAB_LAUNCH(3, 4); else SLAB_LAUNCH(3, 2); }
-#undef SLAB_LAUNCH
-            if (picked) *picked = W == 4 ? "fused_planar_slab_kernel<4 slabs>" : "fused_planar_slab_kernel<2 slabs>";
-            *launched = true;
-            return hipGetLastError();
-        }
-#endif
         // lane = sample, wave = time segment (fused_planar_seg.inc) where the shape allows; picked from (S, T, n) alone
         {
             const int L = planar_seg_len(n, T, S, tg), G = L ? T / L : 0;
@@ -344,12 +248,10 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         *launched = true;
         return hipGetLastError();
     }
-    if (!fs.tail.arrive) done = nullptr;          // (the statistics are complete after update_kernel, which then carries the event)
     const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
     if (h_chain.plan.codegen_id == 2) {           // this chain's kernels were compiled at run time (chain_rtc.hip)
         hipFunction_t f = rtc_kernel((RtcChain*)h_chain.rtc, ft, false, S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0);
         if (!f) return hipSuccess;                // (not launched: the caller takes the two-launch path)
-        std::memset(&fs.tail, 0, sizeof(fs.tail));
         void* args[] = {&a, &F, &fs};
         const hipError_t e = rtc_launch(f, (unsigned)blocks, (unsigned)fused_wave_dyn_lds(n_spheres, F.has_goal ? F.goal.dim0 : 0), stream, args, nullptr);
         if (picked) *picked = "fused_step_kernel (run-time chain code)";
@@ -362,68 +264,14 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     // the launch sizes the sphere / state tables (dynamic LDS): 30.7 KB of tiles + these per workgroup, five workgroups per CU while
     // they stay under 2 KB
     const size_t dyn = fused_wave_dyn_lds(n_spheres, F.has_goal ? F.goal.dim0 : 0);
-    // (`done`, multi-GPU statistics: signalled by this kernel's own dispatch packet -- hipExtLaunchKernelGGL stop
-    // event -- instead of a separate barrier packet behind it)
-#define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, TAIL_>), dim3((unsigned)blocks), dim3(256), (unsigned)dyn + SGPMP_FUSED_EXTRA_LDS, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
-#if SGPMP_EXPERIMENTS
-    const bool with_tail = fs.tail.arrive != nullptr;
-#else
-    constexpr bool with_tail = false;                     // (fused_tail_eligible is false in this build: fs.tail stays zero)
-#undef FUSED_LAUNCH
-#define FUSED_LAUNCH(FT_, TAIL_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false>), dim3((unsigned)blocks), dim3(256), (unsigned)dyn + SGPMP_FUSED_EXTRA_LDS, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
-#endif
-#if SGPMP_EXPERIMENTS           // round-4 re-cuts of the launch that measured level or slower: `make EXPERIMENTS=1` builds only
-    // Opt-in `wave_groups` (round 4): one wave per workgroup when sixteen of them fit the LDS of a CU -- a SIMD's slot is then
-    // refilled when its own wave ends, not when the slowest of four does.  Bit-identical; measured level in rate with 2.5 % more
-    // vector instructions (every wave stages the tables), 1-2 % slower as a single launch: not the default.
-    const bool on_grid = S % SGPMP_FUSED_SPW == 0 && T % SGPMP_FUSED_TC == 0;       // (the experimental launches: whole groups / chunks only)
-    const bool wave_groups = on_grid && !with_tail && tg.wave_groups && fused_wave_static_lds<CCp::N>() + dyn <= 10240;
-    // -DSGPMP_FUSED_COEF_LDS=1 (round 4, measured SLOWER, not in the default build): the scan coefficients from an LDS table when the
-    // whole table and the (then dynamic) sphere / state tables leave four workgroups per CU (T <= 64, few spheres); bit-identical.
-#if SGPMP_FUSED_COEF_LDS
-    const size_t cl_dyn = fused_cl_dyn_lds(T, n_spheres, F.has_goal ? F.goal.dim0 : 0);
-    const bool coef_lds = on_grid && !with_tail && !wave_groups && !tg.no_coef_lds && fused_cl_static_lds<CCp::N>() + cl_dyn <= 40960;
-    if (coef_lds) {
-#define FUSED_LAUNCH_CL(FT_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false, 4, true>), dim3((unsigned)blocks), dim3(256), (unsigned)cl_dyn, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
-        if (ft == SGPMP_FIELD_RBF) FUSED_LAUNCH_CL(SGPMP_FIELD_RBF);
-        else if (ft == SGPMP_FIELD_SDF) FUSED_LAUNCH_CL(SGPMP_FIELD_SDF);
-        else FUSED_LAUNCH_CL(SGPMP_FIELD_OCCUPANCY);
-#undef FUSED_LAUNCH_CL
-    } else
-#endif
-    // `fused_pipe` (round 4, verdict item 1a): the noise phase of chunk c + 1 software-pipelined into the kinematics block of chunk c
-    if (on_grid && !with_tail && !wave_groups && tg.fused_pipe) {
-#define FUSED_LAUNCH_P(FT_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false, 4, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
-        if (ft == SGPMP_FIELD_RBF) FUSED_LAUNCH_P(SGPMP_FIELD_RBF);
-        else if (ft == SGPMP_FIELD_SDF) FUSED_LAUNCH_P(SGPMP_FIELD_SDF);
-        else FUSED_LAUNCH_P(SGPMP_FIELD_OCCUPANCY);
-#undef FUSED_LAUNCH_P
-    } else
-    if (wave_groups) {
-        long long wblocks = nitems;
-        if (tg.k3_blocks > 0 && wblocks > 4 * tg.k3_blocks) wblocks = 4 * tg.k3_blocks;
-        if (wblocks > (1LL << 20)) wblocks = 1LL << 20;
-#define FUSED_LAUNCH_W(FT_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false, 1>), dim3((unsigned)wblocks), dim3(64), (unsigned)dyn, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
-        if (ft == SGPMP_FIELD_RBF) FUSED_LAUNCH_W(SGPMP_FIELD_RBF);
-        else if (ft == SGPMP_FIELD_SDF) FUSED_LAUNCH_W(SGPMP_FIELD_SDF);
-        else FUSED_LAUNCH_W(SGPMP_FIELD_OCCUPANCY);
-#undef FUSED_LAUNCH_W
-    } else
-#endif
     // S, T off the launch's grid of 8 rows x 16 waypoints: the instantiation with the masks (fused_step.inc: RAG)
-    if (S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0) {
-#define FUSED_LAUNCH_R(FT_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, false, 4, false, false, true>), dim3((unsigned)blocks), dim3(256), (unsigned)dyn, stream, (hipEvent_t) nullptr, done, 0u, a, F, fs)
-        if (ft == SGPMP_FIELD_RBF) FUSED_LAUNCH_R(SGPMP_FIELD_RBF);
-        else if (ft == SGPMP_FIELD_SDF) FUSED_LAUNCH_R(SGPMP_FIELD_SDF);
-        else FUSED_LAUNCH_R(SGPMP_FIELD_OCCUPANCY);
-#undef FUSED_LAUNCH_R
-    } else
-    if (ft == SGPMP_FIELD_RBF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_RBF, true); else FUSED_LAUNCH(SGPMP_FIELD_RBF, false); }
-    else if (ft == SGPMP_FIELD_SDF) { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_SDF, true); else FUSED_LAUNCH(SGPMP_FIELD_SDF, false); }
-    else { if (with_tail) FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, true); else FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, false); }
+#define FUSED_LAUNCH(FT_, RAG_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, RAG_>), dim3((unsigned)blocks), dim3(256), (unsigned)dyn + SGPMP_FUSED_EXTRA_LDS, stream, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0u, a, F, fs)
+    const bool rag = S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0;
+    if (ft == SGPMP_FIELD_RBF) { if (rag) FUSED_LAUNCH(SGPMP_FIELD_RBF, true); else FUSED_LAUNCH(SGPMP_FIELD_RBF, false); }
+    else if (ft == SGPMP_FIELD_SDF) { if (rag) FUSED_LAUNCH(SGPMP_FIELD_SDF, true); else FUSED_LAUNCH(SGPMP_FIELD_SDF, false); }
+    else { if (rag) FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, true); else FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, false); }
 #undef FUSED_LAUNCH
     if (picked) *picked = "fused_step_kernel";
-    if (tail_ran) *tail_ran = fs.tail.arrive != nullptr;
     *launched = true;
     return hipGetLastError();
 }

@@ -347,7 +347,6 @@ gpmp_thomas_kernel(GpmpArgs a, real* __restrict__ means, real* __restrict__ d_th
     double* y = mu + (size_t)T * TS;                      // [T][TS] r_t, then the solution
     double* fv = y + (size_t)T * TS;                      // [F][T]    (index t-1)
     double* fg = fv + (size_t)a.n_fields * T;             // [F][T][8]
-    real* mp = means + (size_t)p * T * D;
     double* scr = a.scratch + (size_t)p * T * D * D;      // [T][D][D] M_t, element (row, column) at [t][column][row]
     for (int q = 0; q < PPW; ++q) {                       // all 64 lanes stage each particle of the wave
         const int pq = min(blockIdx.x * PPW + q, a.P - 1);

@@ -130,6 +130,20 @@ __device__ __forceinline__ void scan_step2v(const sg_f16& c, float e_pos, float 
     pv = __builtin_elementwise_fma(h2, (sg_f2){pv.y, pv.y}, t);
 }
 
+// ---- the segment form of the same scan (fused_planar_seg.inc: a wave owns L waypoints; update.hip regenerates a row in that form):
+// the in-segment recurrence is scan_step from a zero state; a segment's true start state is the chain  y <- z_j + A_j y  over
+// the earlier segments (A_j: the segment's 2 x 2 propagator, z_j: its zero-start end state), and the fix-up adds Pre_t y_start.
+// Explicit fmas here too: the update kernel's regenerated row must equal the launch's row bit for bit.
+__device__ __forceinline__ void seg_chain(float a00, float a01, float a10, float a11, float zx, float zy, float& yp, float& yv) {
+    const float np_ = __builtin_fmaf(a01, yv, __builtin_fmaf(a00, yp, zx));
+    const float nv_ = __builtin_fmaf(a11, yv, __builtin_fmaf(a10, yp, zy));
+    yp = np_; yv = nv_;
+}
+__device__ __forceinline__ void seg_fixup(float p00, float p01, float p10, float p11, float ysp, float ysv, float& y_pos, float& y_vel) {
+    y_pos = y_pos + __builtin_fmaf(p01, ysv, p00 * ysp);
+    y_vel = y_vel + __builtin_fmaf(p11, ysv, p10 * ysp);
+}
+
 // Box-Muller for both pairs of one Philox block, the plain multiplies / fmas two-wide: same operations on the same values as
 // two box_muller_f32 calls (z02 = (z0, z2), z13 = (z1, z3)).
 __device__ __forceinline__ void box_muller2_f32(const Philox4& r, sg_f2& z02, sg_f2& z13) {

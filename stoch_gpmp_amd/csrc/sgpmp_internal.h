@@ -11,9 +11,6 @@
 #define SGPMP_MAX_LINKS (SGPMP_MAX_JOINTS + 1)
 #define SGPMP_MAX_POINTS 32                 // links + interpolated points per field term
 #define SGPMP_WAVE 64
-#ifndef SGPMP_EXPERIMENTS
-#define SGPMP_EXPERIMENTS 0                  // 1 (make EXPERIMENTS=1): also the launches that were measured slower (Makefile)
-#endif
 
 // ---------------------------------------------------------------------------------- prior factor
 // Device-resident result of K1 for one prior (INIT or SAMPLE).
@@ -24,9 +21,9 @@ struct PriorDev {
     double* iso64;     // [T][8]  g11 g21 g22 h11 h12 h21 h22 0   (valid when isotropic)
     float* iso32;      // [T][8]
     float* iso32p;     // [T][8]  g11 g21 | h11 h21 | h12 h22 | g22 0: the same numbers in the pair order of rng.h scan_step2 (fused_step_kernel)
-    float* slabpre;    // [5][T][4] (tables 3, 4: segments of 8 and of 16 waypoints, fused_planar_seg.inc)  isotropic priors: prefix products H_t .. H_{start} of the scan's 2 x 2 propagators from the
-                       //            start of t's time slab (2 slabs, 4 slabs) and of its in-chunk segment
-                       //            (fused_planar_slab.inc), built by the host in fp64
+    float* slabpre;    // [5][T][4]  isotropic priors, n = 2, 3: prefix products H_t .. H_{start} of the scan's 2 x 2 propagators from the
+                       //            start of t's segment, built by the host in fp64 (table 2: the in-chunk segments of fused_planar.inc;
+                       //            tables 3, 4: segments of 8 and of 16 waypoints, fused_planar_seg.inc; 0, 1: unused since round 5)
     double* Qinv;      // [d][d]   one-step GP precision of this prior
     float* G32;        // [T][d][d] fp32 copies for the dense sampler
     float* H32;
@@ -119,15 +116,9 @@ struct SgpmpToggles {
     int no_step_pipeline;     // SGPMP_NO_STEP_PIPELINE     sgpmp_pipeline_begin .. _end run their steps as one chain
     int gpmp_cholesky;        // SGPMP_GPMP_CHOLESKY        GPMP solve by round 3's block Cholesky through LDS instead of the register-resident block-Thomas kernel
     int no_dense_partials;    // SGPMP_NO_DENSE_PARTIALS    update_kernel re-reads all rows with weight even when the weights are spread (round 3)
-    int fused_pipe;           // SGPMP_FUSED_PIPE           fused launch with the next chunk's noise phase inside the current chunk's kinematics block (software pipeline in the wave)
-    int no_coef_lds;          // SGPMP_NO_COEF_LDS          noise loop of the fused launch reads its scan coefficients by scalar loads (round 2-3) even where the LDS table fits
-    int wave_groups;          // SGPMP_WAVE_GROUPS          fused launch as one-wave workgroups with dynamic LDS tables (round 4: measured level, +2.5 % instructions) instead of 256-thread ones
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
-    long long planar_slabs;   // SGPMP_PLANAR_SLABS         time slabs of the planar one-launch step: 0 none (fused_planar_kernel, default), 2, 4 (fused_planar_slab.inc, where the shape allows)
+    int planar_store_free;    // SGPMP_PLANAR_STORE_FREE    store-free steps (SGPMP_STEP_NO_SAMPLES) also for fused_planar_seg_kernel: measured SLOWER at config 2 (the launch saves 3.8 us, the update's regeneration costs 5.2: 42.4 k -> 40.0 k it/s, profiles/r05), hence opt-in
     int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
-    int small_step;           // SGPMP_SMALL_STEP           small no-FK problems as ONE launch, a workgroup per particle (small_step.inc); measured slower than the separate launches, hence opt-in
-    int tail_update;          // SGPMP_TAIL_UPDATE          the update INSIDE the fused launch (fused_tail.inc) instead of update_kernel as a second launch: one launch per iteration; measured slower at config 3, hence opt-in
-    long long tail_debug;     // SGPMP_TAIL_DEBUG           timing experiments on the in-launch update (wrong results): 1, 2, 3
     long long pipe_split;     // SGPMP_PIPE_SPLIT           first chain's share of the particles in 16ths (0 = default 8)
     long long k3_blocks;      // SGPMP_K3_BLOCKS            workgroup cap of the dual sweep (0: default)
 };
@@ -186,41 +177,39 @@ hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const
                        const void* is_weights, int rows_per_particle, double is_dt, void* costs,
                        double* costs64, hipStream_t stream, const SgpmpToggles& tg, const char** picked);
 
-// K4 inside the fused launch (fused_tail.inc): what the host hands over; null = update_kernel follows the launch
-// Dense-weight regime of the update (FusedArgs::part): buffers the fused launch may leave softmax partials in
+// What the fused launch and the update behind it agree on, per particle, through the count of rows that carried weight in
+// the particle's PREVIOUS update (a device word: stream-ordered, no host round trip, the same in every run):
+//  * dense-weight regime (FusedArgs::part): particles above `threshold` get softmax partials from the launch;
+//  * store-free steps (FusedArgs::nostore): only particles above `store_threshold` have their rows written.
 struct FusedDenseHost {
-    float* part;                  // [P][S / 8][4 + T d]; null while no update has reported spread weights (the launch is then round 3's)
+    float* part;                  // [P][ceil(S / 8)][4 + T d], or null (not an fp32 chain-code step, switched off)
     unsigned* nnz;                // [P] rows with weight in each particle's previous update
     unsigned threshold;           // partials for particles with nnz above it
     double temperature;
-    unsigned* flag;               // device view of the host-visible "some particle is dense" word update_kernel sets
+    int nostore;                  // the caller does not need this step's samples (SGPMP_STEP_NO_SAMPLES) and the update can regenerate rows
+    unsigned store_threshold;     // ... rows are then stored for particles with nnz above it only
 };
-struct FusedTailHost {
-    unsigned* arrive;             // [P] arrival counters of the launch's particles (zero between launches)
-    unsigned* done;               // finished-particle counter (zero between launches)
-    double* acc;                  // [SGPMP_STAT_SHARDS][4] statistics accumulators (zero between launches)
-    double* stats_out;            // the step's statistics buffer or null
-    void* weights; void* grad; void* means_prev;   // K4's optional outputs (context dtype)
-    double temperature, step_size;
+// How update_kernel regenerates the rows a store-free step did not write (update_common.h: RegenArgs)
+struct RegenHost {
+    int recipe;                   // 0: all rows are in memory; 1: fused_step_kernel's rows; 2: fused_planar_seg_kernel's (segments of L)
+    int L;
+    uint64_t seed, draw;
+    int mode_offset;              // global index of the launch's particle 0
+    const float* coef;            // recipe 1: PriorDev::iso32p; 2: PriorDev::iso32
+    const float* pre;             // recipe 2: the segment table of PriorDev::slabpre
+    unsigned store_threshold;
 };
-bool fused_tail_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
-                         const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
-                         const SgpmpToggles& tg);
-// The whole iteration in ONE launch for small problems without forward kinematics (small_step.inc)
-bool small_step_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, int P, int S,
-                         const SgpmpToggles& tg);
-hipError_t launch_small_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, uint64_t seed,
-                             uint64_t draw, void* means, int P, int mode_offset, int S, void* samples, const void* isw,
-                             void* costs, double* costs64, const FusedTailHost& th, void* isw_next, void* means_copy,
-                             hipStream_t stream, hipEvent_t done);
+int update_regen_rows(int dtype, int n, int T, int S, int recipe);   // rows per round update_kernel can regenerate; 0: not this shape
 // K2 + K3 fused (cost_sweep.hip / fused_step.inc): launches only when the step qualifies (*launched)
 hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                              const ChainDev& h_chain, uint64_t seed, uint64_t draw, const void* means, int P,
                              int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
                              const void* isw, double* zero_stats, void* costs, double* costs64,
                              hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched,
-                             const FusedTailHost* tail = nullptr, hipEvent_t done = nullptr, bool* tail_ran = nullptr,
-                             const FusedDenseHost* dense = nullptr, bool* partials_armed = nullptr);
+                             const FusedDenseHost* dense = nullptr, bool* partials_armed = nullptr, RegenHost* regen = nullptr);
+// the recipe update_kernel would need to regenerate this step's rows (0: the step's launch cannot run store-free)
+int fused_step_regen_recipe(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
+                            int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg, int* seg_len);
 bool planar_seg_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
                      int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg);
 // does the step qualify for the fused launch? (same conditions, no launch)
@@ -238,7 +227,7 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                          hipStream_t stream, hipEvent_t done = nullptr, const PriorDev* isw_prior = nullptr,
                          void* isw_next = nullptr, bool* isw_written = nullptr, void* means_copy = nullptr,
                          const float* part = nullptr, unsigned* nnz = nullptr, unsigned nnz_threshold = 0,
-                         unsigned* dense_flag = nullptr);
+                         const RegenHost* regen = nullptr);
 
 hipError_t launch_stats_add(double* dst, const double* src, hipStream_t stream);
 hipError_t launch_mode_stats(int dtype, int n, int T, int P, long long p_offset, int nppg, int G, const void* means,

@@ -15,18 +15,37 @@
 // (x_{T-1} . K_g mu_{T-1}) is re-expressed on (x_0, e_0, ..) and folded into the first T blocks, so
 // K3 needs exactly one weight vector per waypoint.
 #include <hip/hip_ext.h>
+#include <cstring>
 
 #include "sgpmp_internal.h"
 #include "update_common.h"
+
+// LDS of update_kernel without the regeneration: weights + indices (+ the new means for the tail when they fit)
+static size_t update_base_lds(int dtype, int n, int T, int S) {
+    const size_t M = (size_t)T * 2 * n, lds = (size_t)S * (sizeof(double) + sizeof(int));
+    const size_t with_tail = ((lds + 15) & ~(size_t)15) + M * (dtype == SGPMP_F64 ? 8 : 4);
+    return with_tail + 256 <= 65536 ? with_tail : lds;
+}
+
+// Rows update_kernel can regenerate per round for this shape (4, 2, 1), or 0: a store-free step is not possible (the caller
+// then stores the samples as always).  fp32, M a multiple of 4 (16-byte elements), T even (a Philox block is two waypoints).
+int update_regen_rows(int dtype, int n, int T, int S, int recipe) {
+    if (dtype != SGPMP_F32 || (T * 2 * n) % 4 != 0 || T % 2 != 0 || recipe < 1 || recipe > 2) return 0;
+    const size_t base = (update_base_lds(dtype, n, T, S) + 15) & ~(size_t)15;
+    for (int R = 4; R >= 1; R >>= 1)
+        if (base + regen_lds_bytes(recipe, T, n, R) + 256 <= 65536) return R;
+    return 0;
+}
 
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int costs_dtype,
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
                          hipStream_t stream, hipEvent_t done, const PriorDev* isw_prior, void* isw_next,
                          bool* isw_written, void* means_copy, const float* part, unsigned* nnz, unsigned nnz_threshold,
-                         unsigned* dense_flag) {
+                         const RegenHost* regen) {
     const int M = T * 2 * n;
     size_t lds = (size_t)S * (sizeof(double) + sizeof(int));
+    // (the softmax coefficients of the partials reuse the index array as doubles: 8 bytes per group of 8 rows fit its 4 S)
     if (isw_prior) {
         // + the new means for the tail.  Shapes whose weights fit the 64 KB of a workgroup but not together with
         // the means (e.g. S = 4096, T = 512, n = 7 in fp32: 77 KB) run WITHOUT the tail: the next step then
@@ -37,6 +56,21 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
     }
     if (isw_written) *isw_written = isw_prior != nullptr && P > 0;
     if (P <= 0) return hipSuccess;
+    // store-free step: the rows with weight are regenerated behind the kernel's usual scratch
+    RegenArgs rg;
+    std::memset(&rg, 0, sizeof(rg));
+    unsigned regen_off = 0;
+    if (regen && regen->recipe != 0) {
+        if (dtype != SGPMP_F32 || !nnz) return hipErrorInvalidValue;
+        const int R = update_regen_rows(dtype, n, T, S, regen->recipe);
+        if (R < 1) return hipErrorInvalidValue;                  // (the caller asked update_regen_rows before the launch that skipped the stores)
+        rg.recipe = regen->recipe; rg.N = n; rg.L = regen->L; rg.R = R; rg.seed = regen->seed; rg.draw = regen->draw;
+        rg.mode_offset = regen->mode_offset; rg.coef = regen->coef; rg.pre = regen->pre; rg.store_threshold = regen->store_threshold;
+        regen_off = (unsigned)((update_base_lds(dtype, n, T, S) + 15) & ~(size_t)15);
+        // (the scratch sized WITH the tail's means: without them the offset is merely generous)
+        if (lds < regen_off) lds = regen_off;
+        lds = regen_off + regen_lds_bytes(rg.recipe, T, n, R);
+    }
     dim3 grid(P), block(256);
     // `done` (multi-GPU statistics): the event is signalled by this kernel's own dispatch packet
     // (hipExtLaunchKernelGGL stop event) instead of a separate barrier packet behind it
@@ -47,7 +81,7 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                           IswNext<REAL>{isw_prior ? (REAL*)isw_next : nullptr, isw_prior ? isw_prior->Qinv : nullptr, \
                                         isw_prior ? isw_prior->ks : 0., isw_prior ? isw_prior->kg : -1., \
                                         isw_prior ? isw_prior->dt : 0., n, isw_prior ? isw_prior->isotropic : 1}, \
-                          (REAL*)means_copy, (dtype == SGPMP_F32 && M % 4 == 0) ? part : (const float*)nullptr, (S + 7) / 8, nnz, nnz_threshold, dense_flag)
+                          (REAL*)means_copy, (dtype == SGPMP_F32 && M % 4 == 0) ? part : (const float*)nullptr, (S + 7) / 8, nnz, nnz_threshold, rg, regen_off)
     if (dtype == SGPMP_F64) {
         if (M % 4 == 0) UPD(double, double, 4); else UPD(double, double, 2);
     } else if (costs_dtype == SGPMP_F64) {

@@ -1,7 +1,9 @@
-// Arithmetic shared by the update kernel (update.hip) and the in-launch update of the fused step launches
-// (fused_tail.inc): the importance-sampling weight element (K5) and the descriptor of "the next step's weights".
+// Arithmetic of the update kernel (update.hip): the importance-sampling weight element (K5, also its own kernel), the
+// descriptor of "the next step's weights", the update of one particle, and the regeneration of sample rows from their
+// noise keys for store-free steps.
 #pragma once
 #include "sgpmp_internal.h"
+#include "rng.h"
 
 // K5 element: component e = t * d + i of one particle's importance-sampling weight vector [T+1][d], from that
 // particle's means mu [T][d] (fp64 arithmetic on the context-dtype means).
@@ -94,13 +96,114 @@ template <typename T> __device__ __forceinline__ T block_reduce(T v, T* scratch,
     return r;
 }
 
-// The update of ONE particle by one 256-thread workgroup -- update_kernel's body, also the last phase of the
-// whole-iteration launch for small problems (small_step.inc).  `c`: the particle's S costs (global or LDS), `X`: its S
-// sample rows, `x_pitch` elements apart (global [S][M], or an LDS tile), `lds_raw`: S * 12 (+ 16-byte round-up + M
-// elements when nx.out) bytes of workgroup scratch.  `stats` are ACCUMULATED into by atomics (shard p & 63).
+// ---- store-free steps: the rows a particle's update needs, regenerated from their noise keys -----------------------------
+// A step whose samples nobody reads (SGPMP_STEP_NO_SAMPLES: iterations 1 .. K - 1 of optimize(opt_iters = K); the reference
+// returns the last iteration's tensors only, planner.py:289-317) does not write them: 470 MB per launch at config 3.  With the
+// reference's hyper-parameters the softmax of planner.py:263-275 is one-hot, so the update wants ONE row per particle -- and
+// every row is a pure function of (seed, draw, global particle, sample) and the particle's means: Philox + Box-Muller, the
+// scan recurrence, x = mu + y.  Evaluated here with the calls the launch itself makes (rng.h: get4p / get4, scan_step2 /
+// scan_step, seg_chain, seg_fixup: every product-sum an explicit fma), the row comes out bit for bit as the launch would have
+// stored it, so a store-free iteration leaves the same means, weights and gradient as a storing one.
+struct RegenArgs {
+    int recipe;                 // 0: every row is in memory; 1: the scan order of sample_iso_kernel = fused_step_kernel; 2: fused_planar_seg_kernel's segments of L waypoints
+    int N, L, R;                // dofs; waypoints per segment (recipe 2); rows regenerated per round (sized by the launch's LDS)
+    unsigned long long seed, draw;
+    int mode_offset;            // global index of local particle 0 (noise key)
+    const float* coef;          // recipe 1: PriorDev::iso32p [T][8] (pair order); recipe 2: PriorDev::iso32 [T][8]
+    const float* pre;           // recipe 2: [T][4] prefix products of the propagators inside each segment (PriorDev::slabpre)
+    unsigned store_threshold;   // the launch stored the rows of particle p iff nnz_prev[p] > store_threshold
+};
+
+// Rows idx[0 .. nb) of particle p (global index gp) -> ybuf [nb][M] as PERTURBATIONS y (the caller forms x = mu + y in fp32,
+// the launch's phase B).  tab: workgroup scratch of T * 12 floats, zl: nb * (T / L) * N * 2 floats (recipe 2).  All 256 threads
+// of the workgroup call; barriers inside; ybuf is complete on return.
+__device__ __forceinline__ void regen_rows(const RegenArgs& rg, int T, unsigned gp, const int* idx, int nb, float* ybuf, float* tab,
+                                           float* zl, int tid, int nthr, bool stage_tables) {
+    const int N = rg.N, D = 2 * N, M = T * D, half = T >> 1;
+    // the coefficient table(s) through LDS: the recurrence below is a dependent chain, a global load per step would dominate it
+    if (stage_tables) {
+        for (int i = tid; i < T * 8; i += nthr) tab[i] = rg.coef[i];
+        if (rg.recipe == 2) for (int i = tid; i < T * 4; i += nthr) tab[T * 8 + i] = rg.pre[i];
+    }
+    // noise: one Philox block = (waypoints 2 tp, 2 tp + 1) x (position, velocity) of dof k -- one block per thread and trip
+    for (int it = tid; it < nb * half * N; it += nthr) {
+        const int k = it % N, q = it / N, tp = q % half, r = q / half;
+        NoiseGen<float> gen;
+        gen.init((uint64_t)rg.seed, (uint64_t)rg.draw, (uint32_t)gp, (uint32_t)idx[r], (uint32_t)k);
+        float* o = ybuf + (size_t)r * M + (size_t)(2 * tp) * D;
+        if (rg.recipe == 1) {
+            sg_f2 z02, z13;
+            gen.get4p(2 * tp, z02, z13);
+            o[k] = z02.x; o[N + k] = z13.x; o[D + k] = z02.y; o[D + N + k] = z13.y;
+        } else {
+            float e[4];
+            gen.get4(2 * tp, e);
+            o[k] = e[0]; o[N + k] = e[1]; o[D + k] = e[2]; o[D + N + k] = e[3];
+        }
+    }
+    __syncthreads();
+    if (rg.recipe == 1) {
+        // the launch's phase A: lane = (sample, dof), two steps per Philox block, state carried over the whole trajectory
+        if (tid < nb * N) {
+            const int r = tid / N, k = tid - r * N;
+            float* o = ybuf + (size_t)r * M + k;
+            const float* c = tab;
+            sg_f2 pv = {0.f, 0.f};
+#pragma unroll 4
+            for (int t = 0; t < T; t += 2, c += 16, o += 2 * D) {
+                const float e0 = o[0], e1 = o[N], e2 = o[D], e3 = o[D + N];
+                scan_step2(c, e0, e1, pv);
+                o[0] = pv.x; o[N] = pv.y;
+                scan_step2(c + 8, e2, e3, pv);
+                o[D] = pv.x; o[D + N] = pv.y;
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    // recipe 2 -- fused_planar_seg_kernel: thread = (row, segment, dof); zero-start recurrence over the segment's L waypoints,
+    // the chain over the earlier segments' end states, the fix-up
+    const int L = rg.L, G = T / L;
+    const float* const pre = tab + T * 8;
+    if (tid < nb * G * N) {
+        const int k = tid % N, q = tid / N, g = q % G, r = q / G;
+        float* o = ybuf + (size_t)r * M + (size_t)(g * L) * D + k;
+        const float* c = tab + (size_t)(g * L) * 8;
+        float zp = 0.f, zv = 0.f;
+        for (int i = 0; i < L; ++i, c += 8, o += D) {
+            scan_step<float>(c, o[0], o[N], zp, zv);
+            o[0] = zp; o[N] = zv;
+        }
+        zl[((size_t)(r * G + g) * N + k) * 2] = zp;
+        zl[((size_t)(r * G + g) * N + k) * 2 + 1] = zv;
+    }
+    __syncthreads();
+    if (tid < nb * G * N) {
+        const int k = tid % N, q = tid / N, g = q % G, r = q / G;
+        float ysp = 0.f, ysv = 0.f;
+        for (int j = 0; j < g; ++j) {
+            const float* A = pre + (size_t)(j * L + L - 1) * 4;           // segment j's propagator: the prefix product at its last waypoint
+            const float* z = zl + ((size_t)(r * G + j) * N + k) * 2;
+            seg_chain(A[0], A[1], A[2], A[3], z[0], z[1], ysp, ysv);
+        }
+        float* o = ybuf + (size_t)r * M + (size_t)(g * L) * D + k;
+        const float* P = pre + (size_t)(g * L) * 4;
+        for (int i = 0; i < L; ++i, P += 4, o += D) seg_fixup(P[0], P[1], P[2], P[3], ysp, ysv, o[0], o[N]);
+    }
+    __syncthreads();
+}
+
+// LDS of the regeneration: rows + tables + segment end states + (more rows with weight than one round holds) the carried sums
+static inline size_t regen_lds_bytes(int recipe, int T, int n, int R) {
+    const size_t M = (size_t)T * 2 * n;
+    return (size_t)R * M * 4 + (size_t)T * 12 * 4 + (recipe == 2 ? (size_t)R * 16 * n * 2 * 4 : 0) + M * 8;
+}
+
+// The update of ONE particle by one 256-thread workgroup -- update_kernel's body.  `c`: the particle's S costs, `X`: its S
+// sample rows, `x_pitch` elements apart (global [S][M]), `lds_raw`: S * 12 (+ 16-byte round-up + M elements when nx.out)
+// bytes of workgroup scratch (+ regen_lds_bytes behind them when `rg`).  `stats` are ACCUMULATED into by atomics (shard p & 63).
 // VW = elements per thread and load (4 when M % 4 == 0, else 2; M = T * 2n is always even).
-// Workgroups wider than 256 threads (small_step.inc runs 1024) join the barriers, the first 256 threads do the work: the
-// reductions keep update_kernel's shape -- and its bits.
+// rg != null: the particle's rows are NOT in memory (store-free step) -- the rows that carry weight are regenerated.
 #define SGPMP_UPD_THREADS 256
 template <typename real, typename cost_t, int VW>
 __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_t* c, const real* X, size_t x_pitch,
@@ -108,7 +211,8 @@ __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_
                                                 real* __restrict__ weights, real* __restrict__ grad, real* __restrict__ means_prev,
                                                 double* __restrict__ stats, const IswNext<real>& nx, real* __restrict__ means_copy,
                                                 unsigned char* lds_raw, const real* mu_rd = nullptr,
-                                                const float* __restrict__ partials = nullptr, int gpp = 0, unsigned* __restrict__ nnz_out = nullptr) {
+                                                const float* __restrict__ partials = nullptr, int gpp = 0, unsigned* __restrict__ nnz_out = nullptr,
+                                                const RegenArgs* rg = nullptr, unsigned char* regen_lds = nullptr) {
     typedef real vec __attribute__((ext_vector_type(VW)));
     double* w = reinterpret_cast<double*>(lds_raw);                  // [S] weights
     int* idx = reinterpret_cast<int*>(lds_raw + (size_t)S * 8);      // [S] samples with weight != 0
@@ -217,7 +321,59 @@ __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_
     }
 
     real* mu = means + (size_t)p * M;
-    for (int m = tid < nthr ? tid * VW : M; m < M; m += nthr * VW) {
+    // what every path does with an element's finished sum: gradient, pre-update means, new means (+ copies)
+    auto finish = [&](int m, const vec& mu_m, const double (&acc)[VW]) {
+        vec g, mn;
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+            g[i] = (real)acc[i];
+            mn[i] = (real)fma(step_size, acc[i], (double)mu_m[i]);
+        }
+        if (grad) *reinterpret_cast<vec*>(grad + (size_t)p * M + m) = g;
+        if (means_prev) *reinterpret_cast<vec*>(means_prev + (size_t)p * M + m) = mu_m;
+        *reinterpret_cast<vec*>(mu + m) = mn;
+        if (means_copy) *reinterpret_cast<vec*>(means_copy + (size_t)p * M + m) = mn;   // (snapshot for the side stream's statistics)
+        if (nx.out) *reinterpret_cast<vec*>(mu_lds + m) = mn;
+    };
+    bool regenerated = false;
+    if constexpr (sizeof(real) == 4) {
+        if (rg != nullptr && !use_part) {
+            regenerated = true;
+            // Store-free step: rounds of R rows with weight -- regenerated into LDS as perturbations y, x = mu + y formed as the
+            // launch forms it (one fp32 add), then the row-gather's arithmetic in the row-gather's order (ascending sample index,
+            // one fma per row): the same sums, bit for bit.  One round is the rule (one-hot weights: one row).
+            const int Tn = M / (2 * rg->N), R = rg->R;
+            float* ybuf = reinterpret_cast<float*>(regen_lds);
+            float* tab = ybuf + (size_t)R * M;
+            float* zl = tab + (size_t)Tn * 12;
+            double* accl = reinterpret_cast<double*>(zl + (rg->recipe == 2 ? (size_t)R * 16 * rg->N * 2 : 0));
+            for (int b0 = 0; b0 < nnz; b0 += R) {
+                const int nb = nnz - b0 < R ? nnz - b0 : R;
+                regen_rows(*rg, Tn, (unsigned)(rg->mode_offset + p), idx + b0, nb, ybuf, tab, zl, tid, nthr, b0 == 0);
+                for (int m = tid < nthr ? tid * VW : M; m < M; m += nthr * VW) {
+                    const vec mu_m = *reinterpret_cast<const vec*>((mu_rd ? mu_rd : mu) + m);
+                    double acc[VW];
+#pragma unroll
+                    for (int i = 0; i < VW; ++i) acc[i] = b0 > 0 ? accl[m + i] : 0.;
+                    for (int k = 0; k < nb; ++k) {
+                        const double ws = w[idx[b0 + k]];
+                        const vec y = *reinterpret_cast<const vec*>(ybuf + (size_t)k * M + m);
+                        const vec x = y + mu_m;
+#pragma unroll
+                        for (int i = 0; i < VW; ++i) acc[i] = fma(ws, (double)(x[i] - mu_m[i]), acc[i]);
+                    }
+                    if (b0 + R < nnz) {
+#pragma unroll
+                        for (int i = 0; i < VW; ++i) accl[m + i] = acc[i];
+                    } else {
+                        finish(m, mu_m, acc);
+                    }
+                }
+                __syncthreads();                         // (the next round overwrites the rows; the tail below reads mu_lds)
+            }
+        }
+    }
+    for (int m = (tid < nthr && !regenerated) ? tid * VW : M; m < M; m += nthr * VW) {
         const vec mu_m = *reinterpret_cast<const vec*>((mu_rd ? mu_rd : mu) + m);   // (mu_rd: an LDS copy of the same means)
         double acc[VW];
 #pragma unroll
@@ -264,17 +420,7 @@ __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_
 #pragma unroll
             for (int i = 0; i < VW; ++i) acc[i] = fma(ws, (double)(v[i] - mu_m[i]), acc[i]);
         }
-        vec g, mn;
-#pragma unroll
-        for (int i = 0; i < VW; ++i) {
-            g[i] = (real)acc[i];
-            mn[i] = (real)fma(step_size, acc[i], (double)mu_m[i]);
-        }
-        if (grad) *reinterpret_cast<vec*>(grad + (size_t)p * M + m) = g;
-        if (means_prev) *reinterpret_cast<vec*>(means_prev + (size_t)p * M + m) = mu_m;
-        *reinterpret_cast<vec*>(mu + m) = mn;
-        if (means_copy) *reinterpret_cast<vec*>(means_copy + (size_t)p * M + m) = mn;   // (snapshot for the side stream's statistics)
-        if (nx.out) *reinterpret_cast<vec*>(mu_lds + m) = mn;
+        finish(m, mu_m, acc);
     }
     // The NEXT iteration's importance-sampling weights, from the means just written (K5's arithmetic, same
     // function): sgpmp_step then starts with the sampler + sweep launch instead of a K5 launch, provided the
@@ -297,18 +443,18 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
               real* __restrict__ weights, real* __restrict__ grad, real* __restrict__ means_prev,
               double* __restrict__ stats, IswNext<real> nx, real* __restrict__ means_copy,
               const float* __restrict__ part, int gpp, unsigned* __restrict__ nnz, unsigned nnz_threshold,
-              unsigned* __restrict__ dense_flag) {
+              RegenArgs rg, unsigned regen_lds_offset) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int p = blockIdx.x;
     // partials of this particle exist iff the fused launch of THIS step saw nnz[p] above the threshold: the same word,
-    // read here before this particle's new count replaces it
+    // read here before this particle's new count replaces it -- and, after a store-free step, its rows exist iff that word
+    // was above the store threshold
+    const unsigned prev = nnz ? nnz[p] : 0u;
     const float* part_p = nullptr;
-    if (part && nnz && nnz[p] > nnz_threshold) part_p = part + (size_t)p * gpp * (M + 4);
+    if (part && nnz && prev > nnz_threshold) part_p = part + (size_t)p * gpp * (M + 4);
+    const bool regen = rg.recipe != 0 && !(prev > rg.store_threshold);
     update_particle<real, cost_t, VW>(p, M, S, costs + (size_t)p * S, samples + (size_t)p * S * M, (size_t)M, means, temperature,
                                       step_size, weights, grad, means_prev, stats, nx, means_copy, lds_raw, nullptr, part_p, gpp,
-                                      nnz ? nnz + p : nullptr);
-    // a word in host-visible memory tells the host (no synchronisation: it looks when it enqueues a later step) that some
-    // particle's weights are spread -- only then does it arm the fused launch's partials (api.hip dense_buffers)
-    if (dense_flag && nnz && threadIdx.x == 0 && nnz[p] > nnz_threshold) *dense_flag = 1u;
+                                      nnz ? nnz + p : nullptr, regen ? &rg : nullptr, lds_raw + regen_lds_offset);
 }
 

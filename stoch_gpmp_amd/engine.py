@@ -93,6 +93,30 @@ class Engine:
         L.check(self.lib.sgpmp_dense_particles(self._ctx, C.byref(k), C.byref(a)))
         return a.value
 
+    def row_counts(self):
+        """Per particle: the rows that carried weight in its last in-step update (include/sgpmp.h: sgpmp_row_counts_get) --
+        state of a run: the next step's launch and update decide on it."""
+        import numpy as np
+        out = np.zeros(max(self.P, 1), dtype=np.uint32)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_row_counts_get(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out[:self.P]
+
+    def set_row_counts(self, counts=None):
+        """Restore the per-particle row counts (None: clear them, as a fresh run has them)."""
+        import numpy as np
+        ptr = None
+        if counts is not None:
+            arr = np.ascontiguousarray(np.asarray(counts, dtype=np.uint32))
+            assert arr.shape == (self.P,)
+            ptr = arr.ctypes.data_as(C.POINTER(C.c_uint32))
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_row_counts_set(self._ctx, ptr))
+
+    def store_free_steps(self):
+        """Steps of this context that did not write their samples (SGPMP_STEP_NO_SAMPLES honoured)."""
+        return int(self.lib.sgpmp_store_free_steps(self._ctx))
+
     def last_cost_kernel(self):
         """Name of the cost-sweep kernel the dispatcher picked at the last launch."""
         return self.lib.sgpmp_last_cost_kernel(self._ctx).decode()

@@ -34,6 +34,12 @@ Additions over the reference API (all optional keyword arguments):
   pipeline_steps=True        optimize(opt_iters >= 2) lets the context run the iterations of the call as two
                              particle-half chains on streams of its own (one half's update kernel under the
                              other half's sampler + sweep launch); same results, bit for bit.
+  store_free=True            optimize(opt_iters = K) returns the LAST iteration's tensors only (planner.py:289-317), so
+                             iterations 1 .. K - 1 do not write their samples (470 MB per iteration at 1024 x 128 x 64):
+                             the update regenerates the rows that carry weight from their noise keys, bit for bit
+                             (include/sgpmp.h: SGPMP_STEP_NO_SAMPLES).  The last iteration of every call -- and so every
+                             optimize(opt_iters=1) -- stores as always; all returned tensors, `particle_means` and
+                             `state_samples` are identical either way.  False: every iteration stores.
 """
 import itertools
 import time
@@ -152,6 +158,7 @@ class StochGPMP:
         self.pipeline_steps = bool(kwargs.get('pipeline_steps', True))
         self.mode_stats_every_step = bool(kwargs.get('mode_stats', False))
         self.clone_outputs = bool(kwargs.get('clone_outputs', True))
+        self.store_free = bool(kwargs.get('store_free', True))
         self._mode_buf = None
 
         self.reset(start_state, multi_goal_states, initial_particle_means=initial_particle_means)
@@ -274,6 +281,9 @@ class StochGPMP:
         self.state_samples = self._samples_buf
         self._costs64_fresh = False
         self._stats_slot = 0
+        # per-particle row counts of the last update (they steer the next step's launch and update per particle): a fresh
+        # problem starts without them, whatever ran on this context before
+        eng.set_row_counts(None)
         self._step_calls = {}
         self._pm_obj, self._pm_version = None, -1       # means tensor / version after our last fused step
         self._mode_fresh = False                        # _mode_buf holds the statistics of the current means
@@ -424,9 +434,11 @@ class StochGPMP:
         return mode_moments(buf, self.traj_len, self.d_state_opt)
 
     # ------------------------------------------------------------------------------- the loop
-    def step(self, _means_prev_out=None, **observation):
+    def step(self, _means_prev_out=None, _samples_unread=False, **observation):
         """One body of the loop at planner.py:289-299 on this rank's particle shard.  (_means_prev_out: where this step leaves
-        its pre-update means -- optimize() passes a fresh tensor for the step whose means it returns.)"""
+        its pre-update means -- optimize() passes a fresh tensor for the step whose means it returns.  _samples_unread:
+        optimize() vouches that nobody reads this step's samples -- it is not the call's last -- so the step need not
+        write them, include/sgpmp.h: SGPMP_STEP_NO_SAMPLES.)"""
         self.state_samples = self._samples_buf           # (sample_trajectories may have re-pointed it)
         prev_out = self._means_prev_buf if _means_prev_out is None else _means_prev_out
         self._means_prev = prev_out
@@ -457,7 +469,8 @@ class StochGPMP:
                 # means are the same tensor at the version recorded after our last step, only we wrote them
                 pm = self.particle_means
                 kept = pm is self._pm_obj and pm._version == self._pm_version
-                call(self._draw, L.STEP_MEANS_KEPT if kept else 0, None if _means_prev_out is None else L.ptr(prev_out))
+                flags = (L.STEP_MEANS_KEPT if kept else 0) | (L.STEP_NO_SAMPLES if _samples_unread and self.store_free else 0)
+                call(self._draw, flags, None if _means_prev_out is None else L.ptr(prev_out))
                 self._pm_obj, self._pm_version = pm, pm._version
                 self._mode_fresh = self.mode_stats_every_step
             else:
@@ -565,7 +578,8 @@ class StochGPMP:
                 start_time_iter = time.time()
                 if opt_step == opt_iters - 1 and self.clone_outputs and self.num_particles_local > 0:
                     fresh_prev = torch.empty_like(self._means_prev_buf)      # (caching allocator: no launch)
-                costs, approx_grad = self.step(_means_prev_out=fresh_prev, **observation)
+                costs, approx_grad = self.step(_means_prev_out=fresh_prev, _samples_unread=opt_step < opt_iters - 1,
+                                               **observation)
                 if debug and opt_step % 50 == 0:
                     print_info(opt_step, opt_iters, start_time_iter, start_time, costs)
         finally:
@@ -628,6 +642,9 @@ class StochGPMP:
             'stats': self._stats.detach().clone(),
             'temperature': self.temperature, 'step_size': self.step_size, 'noise': self.noise,
             'cost_version': self.cost.version() if self._native_cost else None,
+            # rows that carried weight in each particle's last update: the next step's launch / update decide on them per
+            # particle (partials or rows: equal to 1e-6 only), so a bit-for-bit continuation needs them
+            'row_counts': torch.from_numpy(self._engine.row_counts().astype('int64')),
         }
         if self.noise == 'torch':
             sd['torch_rng_state'] = torch.get_rng_state()
@@ -656,6 +673,12 @@ class StochGPMP:
         if (q0, q1) == (self.p0, self.p1) and sd['stats'].shape == self._stats.shape:
             self._stats.copy_(sd['stats'])               # (the last iteration's statistics: global_stats() answers as before)
         self.temperature, self.step_size = sd['temperature'], sd['step_size']
+        if self._native_cost and sd.get('cost_version') is not None and sd['cost_version'] != self.cost.version():
+            import warnings
+            warnings.warn("load_state_dict: the state was taken under another version of the cost program "
+                          f"({sd['cost_version']} != {self.cost.version()}); the run continues on the current one")
+        rc = sd.get('row_counts')
+        self._engine.set_row_counts(None if rc is None else rc[self.p0 - q0:self.p1 - q0].numpy())
         if self.noise == 'torch' and 'torch_rng_state' in sd:
             torch.set_rng_state(sd['torch_rng_state'])
 

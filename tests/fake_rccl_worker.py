@@ -58,13 +58,8 @@ def main():
     for k in (10, 1, 9, 2, 3):
         if k == 2:                                                              # the update kernel's own stop event as the hand-over
             shard2._engine.set_option("comm_packet_event", 1)
-        if k == 3:                                                              # the update inside the sampler + sweep launch
+        if k == 3:
             shard2._engine.set_option("comm_packet_event", 0)
-            try:                                                                # (in `make EXPERIMENTS=1` builds only)
-                shard2._engine.set_option("tail_update", 1)
-                full2._engine.set_option("tail_update", 1)
-            except ValueError as e:
-                assert "unknown option" in str(e)
         full2.optimize(opt_iters=k, obstacle_spheres=sph)
         shard2.optimize(opt_iters=k, obstacle_spheres=sph)
         gs2, gf2 = shard2.global_stats(), full2.global_stats()

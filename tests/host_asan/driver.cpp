@@ -103,8 +103,16 @@ static void run_planner(int n, int T, int P, int P_global, int offset, int S, in
     // two particle-half chains
     CHECK(sgpmp_pipeline_begin(c, nullptr));
     EXPECT(sgpmp_pipeline_begin(c, nullptr), SGPMP_ESTATE);
-    for (int i = 0; i < 11; ++i) step(200 + i, SGPMP_STEP_MEANS_KEPT);
+    for (int i = 0; i < 11; ++i) step(200 + i, SGPMP_STEP_MEANS_KEPT | (i < 10 ? SGPMP_STEP_NO_SAMPLES : 0));   // store-free but the last
     CHECK(sgpmp_pipeline_end(c, nullptr));
+    step(220, SGPMP_STEP_NO_SAMPLES);                           // ... and outside a bracket
+    {
+        std::vector<uint32_t> rc(Pn, 7u);
+        CHECK(sgpmp_row_counts_get(c, rc.data()));
+        CHECK(sgpmp_row_counts_set(c, rc.data()));
+        CHECK(sgpmp_row_counts_set(c, nullptr));
+        (void)sgpmp_store_free_steps(c);
+    }
     CHECK(sgpmp_pipeline_end(c, nullptr));                      // idempotent
     if (mode_stats) CHECK(sgpmp_mode_stats_wait(c, nullptr));
     CHECK(sgpmp_mode_stats(c, means.p, (double*)mode.p, nullptr));

@@ -58,27 +58,33 @@ hipError_t launch_cost(int dtype, int n, int T, const CostProgram&, const ChainD
     *picked = "stub_cost";
     return hipSuccess;
 }
-bool fused_tail_eligible(int, int, int, const PriorDev&, const CostProgram&, const ChainDev&, int, int, int, int, const SgpmpToggles&) { return false; }
-bool small_step_eligible(int, int, int, const PriorDev&, const CostProgram&, int, int, const SgpmpToggles&) { return false; }
-hipError_t launch_small_step(int, int, int, const PriorDev&, const CostProgram&, uint64_t, uint64_t, void*, int, int, int, void*, const void*, void*, double*,
-                             const FusedTailHost&, void*, void*, hipStream_t, hipEvent_t) { return hipErrorNotSupported; }
+int update_regen_rows(int dtype, int, int T, int, int recipe) { return dtype == SGPMP_F32 && T % 2 == 0 && recipe == 1 ? 4 : 0; }
+int fused_step_regen_recipe(int dtype, int n, int T, const PriorDev& pr, const CostProgram& prog, const ChainDev& ch, int P, int off, int S, int ns,
+                            const SgpmpToggles& tg, int* seg_len) {
+    if (seg_len) *seg_len = 0;
+    return fused_step_eligible(dtype, n, T, pr, prog, ch, P, off, S, ns, tg) && prog.n_ee == 0 ? 1 : 0;
+}
 bool planar_seg_step(int, int, int, const PriorDev&, const CostProgram&, const ChainDev&, int, int, int, int, const SgpmpToggles&) { return false; }
 bool fused_step_eligible(int dtype, int, int T, const PriorDev&, const CostProgram&, const ChainDev&, int P, int, int S, int, const SgpmpToggles& tg) {
     return env1("STUB_FUSED") && dtype == SGPMP_F32 && !tg.no_fused_step && T % 16 == 0 && S % 8 == 0 && P > 0;
 }
 hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& pr, const CostProgram& prog, const ChainDev& ch, uint64_t, uint64_t, const void* means,
                              int P, int off, int S, void* samples, const void* spheres, int ns, const void* isw, double* zero_stats, void* costs,
-                             double* c64, hipStream_t, const SgpmpToggles& tg, const char** picked, bool* launched, const FusedTailHost*, hipEvent_t,
-                             bool* tail_ran, const FusedDenseHost* dense, bool* armed) {
+                             double* c64, hipStream_t, const SgpmpToggles& tg, const char** picked, bool* launched, const FusedDenseHost* dense,
+                             bool* armed, RegenHost* regen) {
     *launched = fused_step_eligible(dtype, n, T, pr, prog, ch, P, off, S, ns, tg) && samples && isw;
-    if (tail_ran) *tail_ran = false;
     if (armed) *armed = false;
+    if (regen) std::memset(regen, 0, sizeof(*regen));
     if (!*launched) return hipSuccess;
     const size_t M = (size_t)T * 2 * n;
     rd(means, (size_t)P * M * 4); rd(isw, (size_t)P * (T + 1) * 2 * n * 4); rd(spheres, (size_t)ns * 16);
-    wr(samples, (size_t)P * S * M * 4); wr(costs, (size_t)P * S * 4); wr(c64, (size_t)P * S * 8); wr(zero_stats, sizeof(double) * SGPMP_STAT_SHARDS * 4);
+    const bool nostore = dense && dense->nostore && dense->nnz && regen && prog.n_ee == 0 && update_regen_rows(dtype, n, T, S, 1) > 0;
+    if (nostore) { regen->recipe = 1; regen->coef = pr.iso32p; regen->store_threshold = dense->store_threshold; regen->mode_offset = off; }
+    else wr(samples, (size_t)P * S * M * 4);
+    wr(costs, (size_t)P * S * 4); wr(c64, (size_t)P * S * 8); wr(zero_stats, sizeof(double) * SGPMP_STAT_SHARDS * 4);
+    if (dense && dense->nnz) rd(dense->nnz, (size_t)P * 4);
     if (dense && dense->part && dense->nnz) {
-        rd(dense->nnz, (size_t)P * 4); wr(dense->part, (size_t)P * (S / 8) * (M + 4) * 4);
+        wr(dense->part, (size_t)P * ((S + 7) / 8) * (M + 4) * 4);
         if (armed) *armed = true;
     }
     if (picked) *picked = "stub_fused";
@@ -91,9 +97,15 @@ hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& p, const v
 }
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int cdt, const void* samples, void* means, double, double, void* weights,
                          void* grad, void* means_prev, double* stats, hipStream_t, hipEvent_t done, const PriorDev* ip, void* isw_next, bool* isw_written,
-                         void* means_copy, const float* part, unsigned* nnz, unsigned, unsigned* dense_flag) {
+                         void* means_copy, const float* part, unsigned* nnz, unsigned, const RegenHost* regen) {
     const size_t M = (size_t)T * 2 * n, w = esz(dtype);
-    rd(costs, (size_t)P * S * esz(cdt)); rd(samples, (size_t)P * S * M * w);
+    rd(costs, (size_t)P * S * esz(cdt));
+    if (regen && regen->recipe) {                              // store-free step: tables instead of rows
+        rd(regen->coef, sizeof(float) * T * 8);
+        if (regen->recipe == 2) rd(regen->pre, sizeof(float) * T * 4);
+    } else {
+        rd(samples, (size_t)P * S * M * w);
+    }
     wr(means, (size_t)P * M * w); wr(weights, (size_t)P * S * w); wr(grad, (size_t)P * M * w); wr(means_prev, (size_t)P * M * w);
     wr(means_copy, (size_t)P * M * w);
     if (stats) for (int i = 0; i < SGPMP_STAT_SHARDS * 4; ++i) stats[i] += 1.;        // accumulates, as the kernel's atomics do
@@ -101,7 +113,6 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
     if (isw_written) *isw_written = ip != nullptr && P > 0;
     if (part) rd(part, (size_t)P * (S / 8) * (M + 4) * 4);
     if (nnz) { rd(nnz, (size_t)P * 4); wr(nnz, (size_t)P * 4, 1); }
-    if (dense_flag && env1("STUB_DENSE")) *dense_flag = 1u;          // (as if some particle's weights were spread)
     if (done) return hipEventRecord(done, nullptr);
     return hipSuccess;
 }

@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libsgpmp.so does not export {name}"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in stoch_gpmp_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.sgpmp_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.sgpmp_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_ctypes_structs_match_the_c_layout(tmp_path):
@@ -295,8 +295,7 @@ def test_hand_placed_loads_are_not_touched_before_their_wait():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    # 11 = fused_step_kernel x 3 field types x {on the 8 x 16 grid, masked} (an EXPERIMENTS=1 build: x {in-launch update, one-wave workgroups, in-wave pipeline} more) + cost_sweep_chunked_kernel x 3
-    # + fused_planar_kernel x 2 (n = 2, 3)   (an EXPERIMENTS=1 build adds three more with the in-launch update)
+    # 11 = fused_step_kernel x 3 field types x {on the 8 x 16 grid, masked} + cost_sweep_chunked_kernel x 3 + fused_planar_kernel x 2 (n = 2, 3)
     assert re.search(r"\b11 kernels audited, \d+ hand-placed loads, 0 offending", r.stdout), r.stdout
 
 
@@ -348,7 +347,7 @@ def test_host_bookkeeping_under_address_and_ub_sanitizers(tmp_path):
     base = {k: v for k, v in os.environ.items() if not k.startswith(("SGPMP_", "STUB_", "HOST_ASAN"))}
     base["ASAN_OPTIONS"] = "detect_leaks=1:abort_on_error=0"
     for extra in ({}, {"SGPMP_RCCL_LIB": fake}, {"SGPMP_RCCL_LIB": fake, "STUB_FUSED": "1", "STUB_EVENT_LAG": "1"},
-                  {"STUB_FUSED": "1", "SGPMP_NO_STEP_PIPELINE": "1"}, {"STUB_FUSED": "1", "STUB_DENSE": "1"}):
+                  {"STUB_FUSED": "1", "SGPMP_NO_STEP_PIPELINE": "1"}, {"STUB_FUSED": "1", "SGPMP_NO_DENSE_PARTIALS": "1"}):
         p = subprocess.run([exe], env=dict(base, **extra), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "HOST_ASAN_OK" in p.stdout, (extra, p.stdout[-1000:], p.stderr[-4000:])
         assert "Sanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]

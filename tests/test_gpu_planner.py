@@ -16,17 +16,6 @@ F32 = {"device": DEV, "dtype": torch.float32}
 
 
 
-def _experimental(pl, name, value=1):
-    """Switch on a launch that lives in `make EXPERIMENTS=1` builds only (measured slower, kept for the record); the
-    default library reports the option unknown and the test is skipped."""
-    try:
-        pl._engine.set_option(name, value)
-    except ValueError as e:
-        if "unknown option" in str(e):
-            pytest.skip(f"{name}: not in this build of libsgpmp.so (make EXPERIMENTS=1)")
-        raise
-
-
 def rel_err(a, b):
     a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
     b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
@@ -644,34 +633,6 @@ def test_config2_free_running_ten_iterations_against_the_dense_oracle(golden):
     assert rec["tracking_fraction_per_iteration"][0] == 1.0
 
 
-def test_fused_launch_variants_of_round_4_keep_the_arithmetic():
-    """`wave_groups` (one wave per workgroup, tables in dynamic LDS) re-cuts the fused launch without touching its arithmetic:
-    samples, costs and means equal the default launch's bit for bit over several iterations, rbf and sdf.  `fused_pipe` (the
-    next chunk's noise phase inside the current chunk's kinematics block, on all 64 lanes, the recurrence fully unrolled) runs
-    the same expressions, but hipcc contracts `c0 e + c3 p + c4 v` into a different multiply / fma pairing in the unrolled
-    form: its samples are within 2 ulp of the default launch's (measured: 1 ulp on 17 % of the elements), not identical --
-    one more reason it stayed an experiment (the default launch IS bit-identical to the two-launch path at full size)."""
-    for field_type in ("rbf", "sdf"):
-        sph = torch.as_tensor(SC.panda_spheres(num=5)).to(**F32)
-        pls = {}
-        for name in ("default", "wave_groups", "fused_pipe"):
-            pl = hip_panda_planner(SC.PANDA, 64, 40, 32, F32, seed=27, field_type=field_type)
-            if name != "default":
-                _experimental(pl, name, 1)               # (`make EXPERIMENTS=1` builds only)
-            pls[name] = pl
-        for it in range(3):
-            for pl in pls.values():
-                pl.optimize(opt_iters=1, obstacle_spheres=sph)
-                assert pl._engine.last_cost_kernel() == "fused_step_kernel"
-            a, b = pls["default"], pls["wave_groups"]
-            assert torch.equal(a.state_samples, b.state_samples), it
-            assert torch.equal(a._costs, b._costs) and torch.equal(a.particle_means, b.particle_means), it
-            c = pls["fused_pipe"]
-            assert float((a.state_samples - c.state_samples).abs().max()) <= 5e-6, it
-            assert torch.allclose(a._costs, c._costs, rtol=1e-4, atol=0), it
-            assert float((a.particle_means - c.particle_means).abs().max()) <= 5e-6, it
-
-
 def test_fused_launch_equals_the_two_launch_path_bitwise_at_every_shape():
     """Round 4 (`rng.h: scan_step`): every sampler kernel evaluates the scan recurrence in ONE explicit-fma order (the fused
     launch two-wide, `scan_step2`), so samples, costs and means of the fused launch equal the sampler + sweep pair's bit for
@@ -772,16 +733,184 @@ def test_dense_weight_update_adds_partials_of_the_fused_launch_instead_of_reread
         assert rel_err(ca, costs_o) < 5e-3
         assert float((a.particle_means.cpu().double() - ora.particle_means).abs().max()) < 1e-3 * scale, it
         used = max(used, a._engine.dense_particles())
-    # the partials are armed by a host-visible word the update kernel sets (no synchronisation, so it lags a step or two):
-    # the first iterations ran round 3's row-reading update, the later ones the partials -- both inside the 1e-6 above
-    armed = a._engine.dense_armed_steps()
-    print(f"\n[dense-weight regime] {armed} of 8 iterations ran with the fused launch's partials armed")
-    assert used >= nppg // 2 and armed >= 4 and b._engine.dense_particles() == -1
-    # one-hot weights (the reference's hyper-parameters): never armed -- the launch stays round 3's
+    # which particles get partials is decided on the device from the row count the particle's previous update left (round 5:
+    # a function of stream-ordered state -- round 4 armed the partials from a host word read without synchronisation, and
+    # the step at which a run switched from rows to partials depended on host timing): the first iteration gathers rows,
+    # every later one adds partials, in every run
+    assert used >= nppg // 2 and a._engine.dense_armed_steps() == 8 and b._engine.dense_armed_steps() == 0
+    assert b._engine.dense_particles() >= nppg // 2          # (the counts are kept either way; `b` just never uses partials)
+    # ... so two runs of the same problem are the same run, bit for bit -- and so is the run cut into optimize() calls
+    # of several iterations (store-free iterations inside: a spread particle's rows are written all the same)
+    r1 = hip_panda_planner(c, T, nppg, S, F32, seed=seed)
+    r2 = hip_panda_planner(c, T, nppg, S, F32, seed=seed)
+    r3 = hip_panda_planner(c, T, nppg, S, F32, seed=seed, store_free=False)
+    for _ in range(6):
+        r1.optimize(opt_iters=1, obstacle_spheres=sph.to(**F32))
+    r2.optimize(opt_iters=4, obstacle_spheres=sph.to(**F32))
+    r2.optimize(opt_iters=2, obstacle_spheres=sph.to(**F32))
+    r3.optimize(opt_iters=6, obstacle_spheres=sph.to(**F32))
+    for r in (r2, r3):
+        assert torch.equal(r1.particle_means, r.particle_means) and torch.equal(r1.state_samples, r.state_samples)
+        assert torch.equal(r1._weights_buf, r._weights_buf) and torch.equal(r1._grad, r._grad)
+    assert r2._engine.store_free_steps() == 4 and r3._engine.store_free_steps() == 0
+    # one-hot weights (the reference's hyper-parameters): no particle ever asks for partials
     h = hip_panda_planner(SC.PANDA, T, nppg, S, F32, seed=seed)
     for _ in range(6):
         h.optimize(opt_iters=1, obstacle_spheres=sph.to(**F32))
-    assert h._engine.dense_particles() == 0 and h._engine.dense_armed_steps() == 0
+    assert h._engine.dense_particles() == 0 and int(h._engine.row_counts().max()) == 1
+
+
+# --------------------------------------------------------------------------- store-free iterations (round 5)
+def _store_free_twins(build, calls, obs, expect_kernel, expect_store_free=True):
+    """The same planner twice: `a` lets the iterations inside optimize(opt_iters = K) skip their sample stores (all but the
+    call's last: SGPMP_STEP_NO_SAMPLES; update_kernel regenerates the rows that carry weight from their noise keys), `b`
+    stores every iteration as rounds 1-4 did.  Everything a caller can see must be BIT-IDENTICAL after every call: the
+    returned 6-tuple, particle_means, state_samples, weights, gradient, costs."""
+    a, b = build(store_free=True), build(store_free=False)
+    free = 0
+    for k in calls:
+        ra, rb = a.optimize(opt_iters=k, **obs), b.optimize(opt_iters=k, **obs)
+        assert a._engine.last_cost_kernel() == expect_kernel, a._engine.last_cost_kernel()
+        for i, (x, y) in enumerate(zip(ra, rb)):
+            assert torch.equal(x, y), (k, i)
+        assert torch.equal(a.particle_means, b.particle_means) and torch.equal(a.state_samples, b.state_samples), k
+        assert torch.equal(a._weights_buf, b._weights_buf) and torch.equal(a._grad, b._grad), k
+        assert torch.equal(a._costs, b._costs) and torch.equal(a._means_prev, b._means_prev), k
+        sa, sb = a.global_stats(), b.global_stats()
+        assert abs(sa[0] / sb[0] - 1) < 1e-12 and abs(sa[1] / sb[1] - 1) < 1e-12
+        free += k - 1
+    assert a._engine.store_free_steps() == (free if expect_store_free else 0) and b._engine.store_free_steps() == 0
+    return a, b
+
+
+@pytest.mark.parametrize("kind", ["config3", "config3_one_chain", "config5_share", "off_grid", "two_goals_sdf", "small"])
+def test_store_free_iterations_equal_storing_iterations_bitwise_panda(kind):
+    """Verdict round 4, item 1: K iterations in one optimize() call, store-free against storing -- final particle_means,
+    the returned 6-tuple and state_samples bit-identical -- at BASELINE configs[2] (two particle-half chains, and as one
+    chain), config 5's share (T = 128: two regenerated Philox blocks per thread), a shape off the launch's 8 x 16 grid (the
+    masked instantiation), two goals with the sdf field, and a problem too small for two chains."""
+    sph = torch.as_tensor(SC.panda_spheres(num=5)).to(**F32)
+    obs = {"obstacle_spheres": sph}
+    calls = (10, 1, 3)
+    if kind == "config3":
+        build = lambda **kw: hip_panda_planner(SC.PANDA, 64, 1024, 128, F32, seed=61, **kw)                     # noqa: E731
+    elif kind == "config3_one_chain":
+        build = lambda **kw: hip_panda_planner(SC.PANDA, 64, 1024, 128, F32, seed=62, pipeline_steps=False, **kw)   # noqa: E731
+        calls = (6, 2)
+    elif kind == "config5_share":
+        goals = [SC.PANDA["goal_q"] + [0.] * 7, [0.3, 0.1, 0.2, -1.2, 0.0, 1.8, 0.2] + [0.] * 7,
+                 [-0.2, 0.4, 0.1, -1.8, 0.2, 2.2, 0.5] + [0.] * 7, [0.1, -0.1, 0.4, -2.0, -0.1, 1.6, 0.0] + [0.] * 7]
+        build = lambda **kw: hip_panda_planner(SC.PANDA, 128, 1024, 256, F32, seed=63, goals=goals, rank=3, world_size=8, **kw)   # noqa: E731
+        calls = (5, 2)
+    elif kind == "off_grid":
+        build = lambda **kw: hip_panda_planner(SC.PANDA, 50, 256, 100, F32, seed=64, **kw)                      # noqa: E731
+    elif kind == "two_goals_sdf":
+        goals = [SC.PANDA["goal_q"] + [0.] * 7, [0.3, 0.1, 0.2, -1.2, 0.0, 1.8, 0.2] + [0.] * 7]
+        build = lambda **kw: hip_panda_planner(SC.PANDA, 32, 96, 64, F32, seed=65, goals=goals, field_type="sdf", **kw)   # noqa: E731
+    else:
+        build = lambda **kw: hip_panda_planner(SC.PANDA, 16, 3, 8, F32, seed=66, **kw)                           # noqa: E731
+    a, _ = _store_free_twins(build, calls, obs, "fused_step_kernel")
+    assert int(a._engine.row_counts().max()) <= 2          # (the reference's hyper-parameters: one-hot weights, at most a near-tie)
+
+
+@pytest.mark.parametrize("nppg,G,S,T,n", [(64, 4, 64, 128, 2), (3, 2, 64, 64, 2), (5, 1, 64, 256, 2), (2, 2, 192, 16, 2), (3, 1, 64, 96, 3)])
+def test_store_free_iterations_equal_storing_iterations_bitwise_planar(golden, nppg, G, S, T, n):
+    """The same at BASELINE configs[1] (256 x 64 x 128: fused_planar_seg_kernel, whose rows update_kernel regenerates segment by
+    segment -- zero-start recurrences, the chain over the segments' end states, the fix-up: rng.h seg_chain / seg_fixup) and at
+    the launch's other shapes: segments of 16 waypoints (T = 256), several 64-sample blocks per particle, n = 3."""
+    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]][:G]
+    c = SC.PLANAR
+    if n == 3:
+        c = dict(SC.PLANAR, n_dof=3, start=[-9., -9., 0.5, 0., 0., 0.])
+        goals = [g[:2] + [0.3 * (i + 1), 0., 0., 0.] for i, g in enumerate(goals)]
+    om = planar_map(golden, F32)
+    def build(**kw):
+        pl = hip_planar_planner(c, T, goals, nppg, S, om, F32, seed=67, **kw)
+        pl._engine.set_option("planar_store_free", 1)    # (opt-in: measured slower than storing at config 2, DESIGN.md 4)
+        return pl
+    _store_free_twins(build, (7, 1, 4), {}, "fused_planar_seg_kernel")
+    # the default: this launch stores every iteration
+    _store_free_twins(lambda **kw: hip_planar_planner(c, T, goals, nppg, S, om, F32, seed=67, **kw), (3,), {},
+                      "fused_planar_seg_kernel", expect_store_free=False)
+
+
+def test_store_free_permission_is_ignored_where_the_step_has_no_store_free_form(golden):
+    """SGPMP_STEP_NO_SAMPLES is a permission: the tile launch of odd planar shapes, the two-launch paths, a program with an
+    end-effector goal (ee_goal_kernel reads the rows) and fp64 contexts store as always -- and give what they always gave."""
+    om = planar_map(golden, F32)
+    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.]]
+    _store_free_twins(lambda **kw: hip_planar_planner(SC.PLANAR, 48, goals, 3, 24, om, F32, seed=68, **kw), (4, 2), {},
+                      "fused_planar_kernel", expect_store_free=False)
+    sph = torch.as_tensor(SC.panda_spheres(num=5)).to(**F64)
+    _store_free_twins(lambda **kw: hip_panda_planner(SC.PANDA, 16, 4, 8, F64, seed=69, **kw), (3,), {"obstacle_spheres": sph},
+                      "cost_sweep_kernel<f64, generated chain>", expect_store_free=False)
+
+
+@pytest.mark.parametrize("temperature,extra", [(1e11, True), (1e14, True), (1e17, True), (1e13, False)])
+def test_store_free_iterations_with_soft_weights(temperature, extra):
+    """planner.py:263-275 is a softmax: at temperatures where several samples carry weight the update of a store-free
+    iteration regenerates several rows (rounds of four), and particles whose previous update spread its weight over more than
+    four rows have their rows WRITTEN as in a storing iteration (and, above S / 4, get the launch's softmax partials): whatever
+    mix of the three a run takes, it is the mix the storing run takes -- every buffer bit-identical."""
+    soft = dict(sigma_start_sample=1.0, sigma_goal_sample=1.0, sigma_gp_sample=30.0) if extra else {}
+    c = dict(SC.PANDA, temperature=temperature, **soft)
+    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=23)).to(**F32)
+    build = lambda **kw: hip_panda_planner(c, 32, 48, 64, F32, seed=71, **kw)                                 # noqa: E731
+    a, _ = _store_free_twins(build, (6, 1, 5), {"obstacle_spheres": sph}, "fused_step_kernel")
+    rc = a._engine.row_counts()
+    print(f"\n[store-free, soft weights] temperature {temperature:g}: rows with weight per particle min {rc.min()} median "
+          f"{int(np.median(rc))} max {rc.max()}")
+
+
+def test_store_free_update_regenerates_any_number_of_rows():
+    """The regeneration on its own, away from the thresholds: both planners get their row counts CLEARED before every step, so
+    the store-free one never has a row in memory and regenerates every row that carries weight -- up to all S, in rounds of
+    four with the sums carried through LDS -- while the storing one gathers them.  Same sums, bit for bit, for a Panda shape
+    and a planar one (the segment recipe)."""
+    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=23)).to(**F32)
+    c = dict(SC.PANDA, temperature=1e14, sigma_start_sample=1.0, sigma_goal_sample=1.0, sigma_gp_sample=30.0)
+    a = hip_panda_planner(c, 32, 24, 64, F32, seed=73)
+    b = hip_panda_planner(c, 32, 24, 64, F32, seed=73, store_free=False)
+    most = 0
+    for it in range(5):
+        for pl in (a, b):
+            pl._engine.set_row_counts(None)
+        a.step(_samples_unread=True, obstacle_spheres=sph)
+        b.step(obstacle_spheres=sph)
+        assert torch.equal(a.particle_means, b.particle_means) and torch.equal(a._grad, b._grad), it
+        assert torch.equal(a._weights_buf, b._weights_buf) and torch.equal(a._costs, b._costs), it
+        most = max(most, int(a._engine.row_counts().max()))
+    assert a._engine.store_free_steps() == 5 and most > 16, most
+
+
+def test_store_free_row_counts_travel_with_the_state():
+    """The per-particle row counts steer the next step (partials / stored rows / regenerated rows): state_dict carries them,
+    reset() clears them -- a resumed soft-weight run continues bit for bit, also when it resumes in the middle of what would
+    have been one optimize() call."""
+    c = dict(SC.PANDA, temperature=1e14, sigma_start_sample=1.0, sigma_goal_sample=1.0, sigma_gp_sample=30.0)
+    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=23)).to(**F32)
+    mk = lambda: hip_panda_planner(c, 32, 24, 64, F32, seed=75)                                              # noqa: E731
+    straight = mk()
+    straight.optimize(opt_iters=3, obstacle_spheres=sph)
+    straight.optimize(opt_iters=4, obstacle_spheres=sph)
+    a = mk()
+    a.optimize(opt_iters=3, obstacle_spheres=sph)
+    sd = a.state_dict()
+    assert int(sd['row_counts'].max()) > 16
+    b = mk()
+    assert int(b._engine.row_counts().max()) == 0
+    b.load_state_dict(sd)
+    b.optimize(opt_iters=4, obstacle_spheres=sph)
+    assert torch.equal(b.particle_means, straight.particle_means) and torch.equal(b.state_samples, straight.state_samples)
+    # without the counts the continuation differs in the last bits (rows gathered where the straight run added partials)
+    sd2 = dict(sd)
+    sd2.pop('row_counts')
+    d = mk()
+    d.load_state_dict(sd2)
+    d.optimize(opt_iters=4, obstacle_spheres=sph)
+    assert float((d.particle_means - straight.particle_means).abs().max()) <= 1e-5 * float(straight.particle_means.abs().max())
+    b.reset()
+    assert int(b._engine.row_counts().max()) == 0
 
 
 # --------------------------------------------------------------------------- any serial chain on the fast launches
@@ -1112,165 +1241,6 @@ def test_fused_step_random_shapes_match_the_two_launch_path():
             b.particle_means.copy_(a.particle_means)
 
 
-# --------------------------------------------------------------------------- small problems: one launch per iteration
-@pytest.mark.parametrize("ta,nppg,G,S,T,n", [
-    (F64, 2, 2, 16, 64, 2),                   # BASELINE config 1
-    (F32, 2, 2, 16, 64, 2),
-    (F32, 3, 4, 24, 128, 2),                  # two 64-waypoint passes per sample in the cost phase
-    (F64, 1, 1, 5, 31, 2),                    # odd S and T, one particle
-    (F32, 5, 1, 7, 48, 3),                    # n = 3
-    (F32, 4, 2, 100, 16, 2),                  # more samples than a workgroup has waves x passes, short trajectories
-])
-def test_small_problem_iteration_in_one_launch_equals_the_separate_launches(golden, ta, nppg, G, S, T, n):
-    """small_step_kernel (csrc/small_step.inc): sampler, cost sweep, update and the next step's importance-sampling
-    weights of a small no-FK problem as ONE launch, a workgroup per particle with its samples in LDS.  Noise, cost terms
-    scan and update are the separate kernels' code on the same data in the same order.  Against the multi-launch step
-    (sampler + generic sweep + update_kernel): the compiler may contract the scan's multiply-adds differently in the two
-    samplers (as it already does between sample_iso_kernel and sample_iso_small_kernel in fp32), so samples and means
-    agree to a few ulp, costs to rounding, with the same arg-min and the same statistics.  (Opt-in: "small_step".)"""
-    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]][:G]
-    c = SC.PLANAR
-    if n == 3:
-        c = dict(SC.PLANAR, n_dof=3, start=[-9., -9., 0.5, 0., 0., 0.])
-        goals = [g[:2] + [0.3 * (i + 1), 0., 0., 0.] for i, g in enumerate(goals)]
-    om = planar_map(golden, ta)
-    a = hip_planar_planner(c, T, goals, nppg, S, om, ta, seed=61)
-    b = hip_planar_planner(c, T, goals, nppg, S, om, ta, seed=61)
-    _experimental(a, "small_step", 1)
-    b._engine.set_option("no_fused_step", 1)
-    eps = 2.3e-16 if ta is F64 else 1.2e-7
-    sequential = False
-    for it in range(4):
-        ra = a.optimize()
-        rb = b.optimize()
-        assert a._engine.last_cost_kernel() == "small_step_kernel" and a._engine.last_step_launches() == (2 if it == 0 else 1)
-        assert b._engine.last_cost_kernel().startswith("cost_sweep_kernel")
-        sa, sb = a.global_stats(), b.global_stats()
-        scale = float(b.state_samples.abs().max())
-        if sequential and ta is F64:
-            assert torch.equal(a.state_samples, b.state_samples) and torch.equal(a._costs, b._costs), it
-            assert torch.equal(a._weights_buf, b._weights_buf) and torch.equal(a._grad, b._grad), it
-            assert torch.equal(a.particle_means, b.particle_means), it
-            for x, y in zip(ra, rb):
-                assert torch.equal(x, y)
-        assert float((a.state_samples - b.state_samples).abs().max()) <= 8 * eps * scale
-        assert rel_err(a._costs, b._costs) < (1e-9 if ta is F64 else 2e-5)
-        assert torch.equal(a._costs.argmin(1), b._costs.argmin(1)) and torch.equal(a._means_prev, b._means_prev)
-        assert float((a.particle_means - b.particle_means).abs().max()) <= 8 * eps * scale
-        assert abs(sa[0] / sb[0] - 1) < (1e-9 if ta is F64 else 1e-5) and abs(sa[1] / sb[1] - 1) < (1e-9 if ta is F64 else 1e-5)
-        b.particle_means.copy_(a.particle_means)          # (keep both on one trajectory: later iterations stay comparable)
-    a.optimize(opt_iters=5)                               # several iterations per call
-    assert a._engine.last_step_launches() == 1 and torch.isfinite(a.particle_means).all()
-
-
-# --------------------------------------------------------------------------- the update inside the fused launch
-def _one_vs_two_launches(build, iters, obs, soft=None, expect_one=True):
-    """The same planner twice: `a` lets the fused launch update the particles itself (csrc/fused_tail.inc, the last
-    wave of every particle; the opt-in "tail_update" switch), `b` runs update_kernel as a second launch (the default).  Same noise keys, same
-    arithmetic, same summation order: every buffer must come out bit-identical, statistics to rounding (their
-    atomics commute only up to the order of the additions)."""
-    a, b = build(), build()
-    _experimental(a, "tail_update", 1)
-    b._engine.set_option("no_dense_partials", 1)          # (spread weights: the row-reading update is the in-launch update's twin, bit for bit)
-    if soft is not None:                                  # a temperature at which many samples carry weight:
-        probe = build()                                   # a sixth of the typical cost spread over a particle's samples
-        probe.optimize(**obs)
-        cp = probe._costs.double()
-        a.temperature = b.temperature = float((cp.max(1)[0] - cp.min(1)[0]).median()) / 6.0
-    for it in range(iters):
-        ra = a.optimize(**obs)
-        rb = b.optimize(**obs)
-        k5 = 1 if it == 0 else 0                          # (the first step after reset() computes its IS weights itself)
-        assert a._engine.last_step_launches() == (1 if expect_one else 2) + k5, (it, a._engine.last_step_launches())
-        assert b._engine.last_step_launches() == 2 + k5, b._engine.last_step_launches()
-        assert torch.equal(a._costs, b._costs) and torch.equal(a.state_samples, b.state_samples), it
-        assert torch.equal(a._weights_buf, b._weights_buf), it
-        assert torch.equal(a._grad, b._grad) and torch.equal(a._means_prev, b._means_prev), it
-        assert torch.equal(a.particle_means, b.particle_means), it
-        for x, y in zip(ra, rb):
-            assert torch.equal(x, y)
-        sa, sb = a.global_stats(), b.global_stats()
-        assert abs(sa[0] / sb[0] - 1) < 1e-12 and abs(sa[1] / sb[1] - 1) < 1e-12, (sa, sb)
-    return a, b
-
-
-@pytest.mark.parametrize("nppg,G,S,T,field_type,soft", [
-    (3, 1, 8, 16, "rbf", None),               # one wave per particle: every wave is its particle's last
-    (5, 2, 24, 48, "sdf", None),              # three waves per particle (not a power of two), two goals
-    (7, 1, 128, 64, "rbf", None),             # config 3's S x T: 16 waves per particle, one 64-waypoint block
-    (3, 2, 256, 128, "rbf", None),            # config 5's S x T: 32 waves per particle, two blocks
-    (4, 1, 128, 64, "rbf", True),             # soft weights: dozens of rows carry weight (pairs + an odd one out)
-    (3, 1, 256, 16, "occupancy", True),       # the largest S the in-launch update takes
-    (2, 1, 64, 128, "rbf", True),             # two 64-waypoint blocks with several rows each
-])
-def test_update_inside_the_fused_launch_equals_the_update_kernel_bitwise(nppg, G, S, T, field_type, soft):
-    c, n = SC.PANDA, 7
-    goals = None if G == 1 else [c["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n][:G]
-    if soft is not None:
-        # The importance-sampling term temperature * x Sigma^-1 mu (planner.py:233-236) scales WITH the temperature and
-        # its spread over the samples is ~ |mu_0| / sigma_start: with the Panda start state the weights are one-hot at
-        # any temperature.  Start and goal at the origin make it small, and the weights follow the other costs.
-        c = dict(c, start_q=[0.] * n, goal_q=[0.02] * n)
-    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=3)).to(**F32)
-    a, _ = _one_vs_two_launches(lambda: hip_panda_planner(c, T, nppg, S, F32, field_type=field_type, seed=23, goals=goals),
-                                4, {"obstacle_spheres": sph}, soft=soft)
-    if soft is not None:                                  # the case is only a test if the weights really are soft
-        nnz = (a._weights_buf != 0).sum(1)
-        assert int(nnz.max()) >= 3, nnz
-
-
-def test_update_inside_the_fused_launch_falls_back_where_it_does_not_fit():
-    """S = 264 is more than the 256 costs a wave holds in registers; T = 144 is more than two 64-waypoint blocks; a
-    CostGoal term adds to the costs after the launch: update_kernel follows in all three."""
-    from stoch_gpmp_amd.costs.cost_functions import CostGoal
-    from stoch_gpmp_amd.costs.fields import EESE3DistanceField
-    c = SC.PANDA
-    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=3)).to(**F32)
-    for S, T in ((264, 16), (8, 144)):
-        pl = hip_panda_planner(c, T, 2, S, F32, seed=5)
-        _experimental(pl, "tail_update", 1)
-        pl.optimize(obstacle_spheres=sph)
-        assert pl._engine.last_cost_kernel() == "fused_step_kernel" and pl._engine.last_step_launches() == 3   # K5 + 2
-        pl.optimize(obstacle_spheres=sph)
-        assert pl._engine.last_step_launches() == 2
-    pl = hip_panda_planner(c, 32, 2, 16, F32, seed=5)
-    _experimental(pl, "tail_update", 1)
-    pl.cost.cost_list.append(CostGoal(7, 32, field=EESE3DistanceField(torch.eye(4, **F32), tensor_args=F32), sigma_goal=1.,
-                                      tensor_args=F32))
-    pl.cost.touch()
-    pl.optimize(obstacle_spheres=sph)
-    pl.optimize(obstacle_spheres=sph)
-    assert pl._engine.last_cost_kernel() == "fused_step_kernel" and pl._engine.last_step_launches() == 3   # + ee_goal_kernel
-
-
-def test_full_size_one_launch_iterations_equal_two_launch_iterations_bitwise():
-    """BASELINE configs[2] (Panda 1024 x 128 x 64): 30 iterations as ONE launch each against fused launch +
-    update_kernel; every buffer bit-identical after every iteration.  The chip is full (4096 workgroups, four per
-    CU) and the particles' last waves finish all over the launch: the hand-off of rows and costs between waves on
-    different CUs (sc1 stores, arrival counter, sc1 loads) is exercised 30 720 times under load -- a single stale
-    word would move a particle."""
-    sph = torch.as_tensor(SC.panda_spheres(num=5)).to(**F32)
-    a, b = _one_vs_two_launches(lambda: hip_panda_planner(SC.PANDA, 64, 1024, 128, F32, seed=77), 30,
-                                {"obstacle_spheres": sph})
-    # ... and with soft weights (every particle reads dozens of rows written by other waves)
-    soft_c = dict(SC.PANDA, start_q=[0.] * 7, goal_q=[0.02] * 7)
-    s1, _ = _one_vs_two_launches(lambda: hip_panda_planner(soft_c, 64, 1024, 128, F32, seed=78), 6, {"obstacle_spheres": sph},
-                                 soft=True)
-    assert int((s1._weights_buf != 0).sum(1).max()) >= 3
-    # ... and inside optimize(opt_iters=K): two particle-half chains, each one launch per iteration
-    x = hip_panda_planner(SC.PANDA, 64, 1024, 128, F32, seed=79)
-    _experimental(x, "tail_update", 1)
-    y = hip_panda_planner(SC.PANDA, 64, 1024, 128, F32, seed=79, pipeline_steps=False)
-    for k in (7, 1, 12):
-        x.optimize(opt_iters=k, obstacle_spheres=sph)
-        y.optimize(opt_iters=k, obstacle_spheres=sph)
-        assert torch.equal(x.particle_means, y.particle_means) and torch.equal(x._costs, y._costs)
-        assert torch.equal(x._grad, y._grad) and torch.equal(x._weights_buf, y._weights_buf)
-        sx, sy = x.global_stats(), y.global_stats()
-        assert abs(sx[0] / sy[0] - 1) < 1e-12 and abs(sx[1] / sy[1] - 1) < 1e-12
-    assert x._engine.pipeline_split_steps() == 19 and x._engine.last_step_launches() == 1
-
-
 @pytest.mark.parametrize("nppg,G,S,T,fused", [
     (2, 2, 8, 16, True), (3, 2, 24, 48, True), (5, 1, 16, 128, True), (1, 4, 8, 32, True),
     (2, 2, 12, 32, False),                    # S not a multiple of 8
@@ -1290,30 +1260,6 @@ def test_planar_fused_corners_match_the_two_launch_path(golden, nppg, G, S, T, f
         assert b._engine.last_cost_kernel() == "cost_sweep_kernel<f32, no FK>"
         scale = float(b.state_samples.abs().max())
         assert float((a.state_samples - b.state_samples).abs().max()) <= 4e-7 * scale
-        assert rel_err(a._costs, b._costs) < 2e-5
-        assert torch.equal(a._costs.argmin(1), b._costs.argmin(1))
-        b.particle_means.copy_(a.particle_means)
-
-
-@pytest.mark.parametrize("slabs,nppg,G,S,T", [(4, 3, 2, 16, 64), (4, 2, 4, 8, 128), (2, 3, 2, 16, 32), (2, 1, 4, 24, 128),
-                                               (4, 5, 1, 8, 256), (4, 2, 2, 8, 48)])
-def test_planar_time_slab_launch_matches_the_sequential_launch(golden, slabs, nppg, G, S, T):
-    """fused_planar_slab.inc (opt-in `planar_slabs`): the trajectory cut into 2 or 4 time slabs, one wave each -- zero-start
-    scans, 2 x 2 affine hand-off of the slab end states, fix-up with the host's fp64 prefix products -- against
-    fused_planar_kernel's sequential walk: same noise keys, samples to the last bit or two, costs to fp32 rounding, same
-    arg-min.  The last shape (T = 48) does not divide into 4 slabs of whole chunks and falls back."""
-    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]][:G]
-    om = planar_map(golden, F32)
-    a = hip_planar_planner(SC.PLANAR, T, goals, nppg, S, om, F32, seed=53)
-    b = hip_planar_planner(SC.PLANAR, T, goals, nppg, S, om, F32, seed=53)
-    _experimental(a, "planar_slabs", slabs)
-    for it in range(3):
-        a.optimize()
-        b.optimize()
-        want = "fused_planar_kernel" if T == 48 else f"fused_planar_slab_kernel<{slabs} slabs>"
-        assert a._engine.last_cost_kernel() == want and b._engine.last_cost_kernel() == "fused_planar_kernel"
-        scale = float(b.state_samples.abs().max())
-        assert float((a.state_samples - b.state_samples).abs().max()) <= 1e-6 * scale
         assert rel_err(a._costs, b._costs) < 2e-5
         assert torch.equal(a._costs.argmin(1), b._costs.argmin(1))
         b.particle_means.copy_(a.particle_means)

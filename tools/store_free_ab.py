@@ -1,0 +1,67 @@
+"""Store-free iterations against storing ones on one box, interleaved (round 5, verdict item 1).
+usage: store_free_ab.py [cfg3|cfg2|cfg5|cfg3_sdf|cfg3_64sph ...]   (default: all)"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+import bench  # noqa: E402
+
+SPECS = {
+    "cfg3": dict(workload="panda", P_local=1024, S=128, T=64, dtype=torch.float32),
+    "cfg3_sdf": dict(workload="panda", P_local=1024, S=128, T=64, dtype=torch.float32, field="sdf"),
+    "cfg3_64sph": dict(workload="panda", P_local=1024, S=128, T=64, dtype=torch.float32, spheres=64),
+    "cfg2": dict(workload="planar", P_local=256, S=64, T=128, dtype=torch.float32, goals=4),
+    "cfg5": dict(workload="panda", P_local=512, S=256, T=128, dtype=torch.float32, goals=4, shard_of=(3, 8)),
+}
+
+
+def event_pass(pl, obs, steps, unread):
+    pl._engine.profile_enable(True)
+    for _ in range(steps):
+        pl.step(_samples_unread=unread, **obs)
+    torch.cuda.synchronize()
+    kms, n = pl._engine.profile_read()
+    pl._engine.profile_enable(False)
+    return {k: round(1e3 * v / n, 2) for k, v in kms.items()}
+
+
+def main():
+    dev = torch.device("cuda:0")
+    names = sys.argv[1:] or list(SPECS)
+    out = {}
+    for name in names:
+        spec = SPECS[name]
+        steps = 300 if name == "cfg2" else 100 if name != "cfg5" else 60
+        pls = {}
+        for mode in ("storing", "store_free"):
+            pl, obs, _ = bench.build_planner(torch, dev=dev, store_free=(mode == "store_free"), **spec)
+            if spec["workload"] == "planar":
+                pl._engine.set_option("planar_store_free", 1)
+            if os.environ.get("AB_K3_BLOCKS") and mode == "store_free":
+                pl._engine.set_option("k3_blocks", int(os.environ["AB_K3_BLOCKS"]))
+            bench.time_loop(torch, pl, obs, 150, 0)
+            pls[mode] = (pl, obs)
+        rates = {m: [] for m in pls}
+        for rnd in range(4):                                  # alternate: clocks drift together
+            for m, (pl, obs) in pls.items():
+                el = bench.time_loop(torch, pl, obs, steps, 10)
+                rates[m].append(steps / el)
+        row = {m: {"it_per_s": [round(r, 1) for r in rates[m]], "best_ms_per_step": round(1e3 / max(rates[m]), 4)} for m in pls}
+        pl, obs = pls["store_free"]
+        row["kernel_us_event_timed"] = {"storing": event_pass(pl, obs, 60, False), "store_free": event_pass(pl, obs, 60, True)}
+        row["kernel"] = pl._engine.last_cost_kernel()
+        row["store_free_steps"] = pl._engine.store_free_steps()
+        row["same_means"] = bool(torch.equal(pls["storing"][0].particle_means, pls["store_free"][0].particle_means))
+        out[name] = row
+        print(name, json.dumps(row), flush=True)
+        del pls, pl
+        torch.cuda.empty_cache()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
