@@ -15,10 +15,14 @@ With N > 1 and no WORLD_SIZE in the environment the script starts its own N rank
 (`python -m torch.distributed.run --nproc-per-node N bench.py ...`) BEFORE anything touches the GPU
 and relays rank 0's JSON line and the exit code; under a launcher (WORLD_SIZE set) it is a rank.
 
-Prints one JSON line (rank 0).  `roofline` prices the dominant kernel against the HBM peak using its
-algorithmic bytes over the TIMED pass's ms_per_step (a lower bound: the step also holds the
-update kernel); its own average duration measured with HIP events on the launch stream and the VALU ceiling
-are in `roofline_detail`; `parity` is a free-running K = 10 comparison with the fp64 CPU oracle made by this run; `cpu_baseline` times the reference-equivalent PyTorch-CPU
+Prints one JSON line (rank 0).  `value` / `roofline` are the STORING mode -- every iteration writes its samples,
+the mode SURVEY.md 8(d)'s algorithmic bytes are defined on: `roofline.frac` prices the dominant kernel against
+the HBM peak using those bytes over the TIMED pass's ms_per_step (a lower bound: the step also holds the update
+kernel), `roofline.bound` says what really bounds the launch (the vector ALU: `valu_frac` = its instruction-issue
+floor / the launch's duration; `moved_frac` = bytes the counters saw / time / HBM peak); the launch's own
+average duration measured with HIP events on the launch stream is in `roofline_detail`.  `store_free` reports the
+product's default inside optimize(opt_iters=K) since round 5 -- iterations 1 .. K - 1 do not write their samples,
+bit-identical results -- beside it, never instead of it; `parity` is a free-running K = 10 comparison with the fp64 CPU oracle made by this run; `cpu_baseline` times the reference-equivalent PyTorch-CPU
 oracle on a bounded sample of the same workload on this box's host cores, `cpu_fair` the banded fp64
 restatement (what a careful CPU implementation of the same mathematics costs).
 """
@@ -36,7 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0       # same guide: 6.29 TB/s measured float4 copy (79 % of spec)
-PROFILE_ROUNDS = ("r04", "r03")   # committed rocprofv3 --pmc sets (traffic / VALU figures quoted beside the live timings): newest first
+PROFILE_ROUNDS = ("r05", "r04", "r03")   # committed rocprofv3 --pmc sets (traffic / VALU figures quoted beside the live timings): newest first
 GOALS4_PLANAR = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
 
 
@@ -56,13 +60,18 @@ def parse():
     ap.add_argument("--shard-of", default=None, metavar="R,W",
                     help="N=1 only: build shard R of W of a (particles x W)-particle problem without a process group "
                          "(config 5's per-GPU share: --goals 4 --particles 512 --samples 256 --traj-len 128 --shard-of 3,8)")
+    ap.add_argument("--store-free", action="store_true",
+                    help="the MAIN planner runs optimize(opt_iters=K) store-free (the product's default) and the event pass "
+                         "times store-free launches: for rocprofv3 runs of that mode (tools/profile_config.sh); the line's "
+                         "`mode` says so.  Without it value / roofline are the storing mode and `store_free` reports the other.")
     ap.add_argument("--single-iteration-calls", action="store_true",
                     help="time K calls of optimize(opt_iters=1) instead of one optimize(opt_iters=K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-store-free", action="store_true", help="skip the store-free leg (a second planner of the same workload)")
     ap.add_argument("--no-parity", action="store_true", help="skip the free-running K = 10 parity leg (fp64 CPU oracle, ~10 s)")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=4)
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=2)
     return ap.parse_args()
 
 
@@ -156,7 +165,7 @@ def profiled(config_key, kernel):
     return None, None
 
 
-def roofline_of(kernel, kernel_ms, N_elems, w, costs_bytes, fused, config_key, copy_gbs, step_ms=None, step_mode=""):
+def roofline_of(kernel, kernel_ms, N_elems, w, costs_bytes, fused, config_key, copy_gbs, step_ms=None, step_mode="", field=None):
     """`roofline` object of one configuration.  Algorithmic bytes per launch = SURVEY.md 8(d): N w (sampler write) + N w
     (sweep read) + P S 8 for the fused launch, N w + P S 8 for the sweep alone.
     `achieved` / `frac` divide them by the TIMED pass's ms_per_step (the whole iteration: this launch, the update kernel
@@ -169,8 +178,18 @@ def roofline_of(kernel, kernel_ms, N_elems, w, costs_bytes, fused, config_key, c
     achieved = alg / (t_ms * 1e-3) / 1e9
     ev = alg / (kernel_ms * 1e-3) / 1e9
     k, src = profiled(config_key, kernel)
-    r = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": achieved / HBM_PEAK_GBS, "traffic": k.get("bytes") if k else None,
+    # what bounds the launch (round-4 verdict): the vector ALU when the committed counters of this configuration show it busy
+    # > 70 % of the launch while the bytes they saw are < 60 % of the algorithmic ones -- the 8(d) fraction `frac` stays (it is
+    # what north_star's 40 % clause is about), `valu_frac` = instruction-issue floor / this run's launch duration and
+    # `moved_frac` = counter bytes / this run's launch duration / HBM peak say where the launch really stands
+    moved = k.get("bytes") if k else None
+    valu_busy = k.get("valu_busy_frac_under_profiler") if k else None
+    bound = "valu" if (valu_busy is not None and moved is not None and valu_busy > 0.7 and moved / alg < 0.6) else "hbm"
+    r = {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": moved,
+         "valu_frac": (k["valu_floor_ms"] / kernel_ms) if (k and "valu_floor_ms" in k) else None,
+         "moved_frac": (moved / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if moved else None,
+         "valu_busy_under_profiler": valu_busy, "field": field, "launch_ms": kernel_ms,
          "timed_by": ("ms_per_step of the timed pass (" + step_mode + ")") if step_ms else "HIP events around the launch"}
     detail = {"algorithmic_bytes_per_launch": alg, "divided_by_ms": t_ms,
               "event_pass": {"avg_launch_ms": kernel_ms, "achieved_GBs": ev, "frac": ev / HBM_PEAK_GBS,
@@ -188,12 +207,16 @@ def roofline_of(kernel, kernel_ms, N_elems, w, costs_bytes, fused, config_key, c
     return r, detail
 
 
-def kernel_profile(torch, pl, obs, steps):
+def kernel_profile(torch, pl, obs, steps, unread=False):
     """Per-kernel device time with HIP events on the launch stream (a separate pass: the events sit
-    between the kernels, so this pass is never the one whose wall time is reported)."""
+    between the kernels, so this pass is never the one whose wall time is reported).  unread: the steps run store-free
+    (what iterations 1 .. K - 1 of an optimize(opt_iters=K) call do)."""
     pl._engine.profile_enable(True)
     for _ in range(steps):
-        pl.optimize(opt_iters=1, **obs)
+        if unread:
+            pl.step(_samples_unread=True, **obs)
+        else:
+            pl.optimize(opt_iters=1, **obs)
     torch.cuda.synchronize()
     kms, launches = pl._engine.profile_read()
     pl._engine.profile_enable(False)
@@ -223,6 +246,39 @@ def time_loop(torch, pl, obs, steps, warmup, barrier=None, one_call=True):
     return time.perf_counter() - t0
 
 
+def store_free_leg(torch, spec_kwargs, obs_builder, config_key, steps, N_elems, w, costs_bytes, storing_ms, dev):
+    """The product's default inside optimize(opt_iters = K) since round 5, reported BESIDE the storing headline (round-4
+    verdict, item 1c): iterations 1 .. K - 1 do not write their samples (SGPMP_STEP_NO_SAMPLES; update_kernel regenerates the
+    rows that carry weight from their noise keys -- every returned tensor bit-identical to the storing mode's,
+    tests/test_gpu_planner.py::test_store_free_*).  SURVEY 8(d)'s algorithmic bytes are defined on the storing mode (sampler
+    write + sweep read), so no HBM fraction is quoted for this launch: it is bound by the vector ALU (`valu_frac`), and what
+    it moves is what the committed counters of this mode saw."""
+    pl, obs, _ = obs_builder(store_free=True, **spec_kwargs)
+    time_loop(torch, pl, obs, 150, 0)
+    els = [time_loop(torch, pl, obs, steps, 10), time_loop(torch, pl, obs, steps, 0)]
+    el = min(els)
+    kms = kernel_profile(torch, pl, obs, min(steps, 60), unread=True)
+    kernel = pl._engine.last_cost_kernel()
+    ran = pl._engine.store_free_steps()
+    k, src = profiled(config_key + "_store_free", kernel)
+    launch_ms = kms["cost_sweep"]
+    out = {"mode": "optimize(opt_iters=K): iterations 1 .. K-1 without the sample stores (the default), the K-th storing",
+           "bound": "valu" if ran else None, "kernel": kernel, "iterations_per_s": steps / el, "ms_per_step": 1e3 * el / steps,
+           "ms_per_step_of_each_pass": [1e3 * e / steps for e in els], "steps": steps,
+           "vs_storing": (storing_ms / (1e3 * el / steps)) if storing_ms else None,
+           "launch_ms": launch_ms, "update_ms": kms["update"],
+           "valu_frac": (k["valu_floor_ms"] / launch_ms) if (k and "valu_floor_ms" in k) else None,
+           "moved_bytes_per_launch": k.get("bytes") if k else None,
+           "moved_frac_of_hbm_peak": (k["bytes"] / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (k and k.get("bytes")) else None,
+           "valu_wave_insts_per_launch": k.get("valu_insts") if k else None,
+           "counters": src, "store_free_steps_run": ran,
+           "bytes_not_written_per_launch": N_elems * w if ran else 0,
+           "results": "bit-identical to the storing mode (means, returned 6-tuple, state_samples): tests/test_gpu_planner.py::test_store_free_*"}
+    del pl
+    torch.cuda.empty_cache()
+    return out
+
+
 def other_configs(torch, dev, copy_gbs=None):
     """The other single-GPU configurations of BASELINE.json, each timed for a few hundred iterations
     (they cost milliseconds): configs[0] in fp64, configs[1], configs[2] with the sdf field, and the
@@ -239,7 +295,8 @@ def other_configs(torch, dev, copy_gbs=None):
     ]
     out = []
     for label, key, spec, steps in specs:
-        pl, obs, name = build_planner(torch, dev=dev, **spec)
+        # (value / roofline: the storing mode, as for the headline; the store-free figure of the Panda launches beside it)
+        pl, obs, name = build_planner(torch, dev=dev, store_free=False, **spec)
         time_loop(torch, pl, obs, 150, 0)                        # (clock and chain-stream warm-up, see main())
         # (two passes, the faster one reported and both kept: these runs last 7-40 ms, and one host hiccup inside a pass --
         # round 4 saw a 29 ms stall once -- would otherwise be read as a 5 x slower kernel.  The headline is one pass of K.)
@@ -253,8 +310,14 @@ def other_configs(torch, dev, copy_gbs=None):
         roof, roof_detail = roofline_of(kernel + (" (K2+K3 in one launch)" if fused else " (K3)"), kms["cost_sweep"],
                                         spec["P_local"] * spec["S"] * spec["T"] * pl.d_state_opt, w,
                                         spec["P_local"] * spec["S"] * 8, fused, key, copy_gbs,
-                                        step_ms=1e3 * el / steps, step_mode="optimize(opt_iters=K)")
-        out.append({"config": label, "workload": name, "iterations_per_s": steps / el,
+                                        step_ms=1e3 * el / steps, step_mode="optimize(opt_iters=K)",
+                                        field=spec.get("field", "rbf") if spec["workload"] == "panda" else "occupancy grid")
+        sf = None
+        if kernel == "fused_step_kernel":
+            sf = store_free_leg(torch, spec, lambda **kw: build_planner(torch, dev=dev, **kw), key, steps,
+                                spec["P_local"] * spec["S"] * spec["T"] * pl.d_state_opt, w, spec["P_local"] * spec["S"] * 8,
+                                1e3 * el / steps, dev)
+        out.append({"config": label, "workload": name, "iterations_per_s": steps / el, "store_free": sf,
                     "ms_per_step": 1e3 * el / steps, "steps": steps, "ms_per_step_of_each_pass": [1e3 * e / steps for e in els],
                     "iterations_per_s_single_iteration_calls": steps / el1, "kernel_ms_per_step": kms,
                     "cost_kernel": kernel, "roofline": roof, "roofline_detail": roof_detail,
@@ -300,45 +363,71 @@ def cpu_baseline(args, torch, S, T, P_full):
         obs = {}
     # The dense algorithm is dominated by batched small-matrix LAPACK / bmm calls that do not scale
     # with threads (256 threads is ~30x SLOWER than 16 on this workload), so a few thread counts are
-    # tried and the best one is reported: the baseline is the reference algorithm at its best.
+    # tried and the best one is reported: the baseline is the reference algorithm at its best -- and the
+    # all-host-cores figure BASELINE.md section 3 asks for is measured beside it.
+    def timed(o, iters, warm=True):
+        if warm:
+            o.step(**obs)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            o.step(**obs)
+        return (time.perf_counter() - t0) / iters
+
     best = None
+    by_threads = {}
     leg0 = time.perf_counter()
     for threads in sorted({min(cores, 16), min(cores, 32)}):   # (16 has been the best count on every box so far)
         torch.set_num_threads(threads)
-        ora.step(**obs)                                 # warm-up
-        t0 = time.perf_counter()
-        for _ in range(args.cpu_iters):
-            ora.step(**obs)
-        dt = (time.perf_counter() - t0) / args.cpu_iters
+        dt = timed(ora, args.cpu_iters)
+        by_threads[threads] = 1.0 / dt
         if best is None or dt < best[0]:
             best = (dt, threads)
-        if time.perf_counter() - leg0 > 10.0:           # keep the whole baseline leg bounded
+        if time.perf_counter() - leg0 > 8.0:            # keep the whole baseline leg bounded
             break
     dt, threads = best
-    its = 1.0 / dt
-    # a second measured point at twice the particles (same thread count), to show that the per-particle
-    # extrapolation is linear ("report measured points"); skipped if it would take too long
-    points = [{"particles": Pc, "it_per_s": its}]
-    if args.workload == "panda" and dt * 2 * (args.cpu_iters + 1) < 8.0:
+    # all host cores (one iteration, no warm-up beyond the runs above: it is the slow point)
+    all_cores = None
+    if cores not in by_threads and time.perf_counter() - leg0 < 10.0:
+        torch.set_num_threads(cores)
+        dta = timed(ora, 1, warm=False)
+        all_cores = {"threads": cores, "it_per_s_at_sample": 1.0 / dta, "value_extrapolated_per_particle": (1.0 / dta) * Pc / P_full}
+        by_threads[cores] = 1.0 / dta
+    # measured points at 2 x and 4 x the particles (best thread count) while the leg stays inside ~25 s: the value is
+    # extrapolated from the TWO LARGEST measured P (time is affine in P: a fixed part + a per-particle part), not from the
+    # smallest sample alone (round-4 verdict: the P = 8 point lay 11 % off the line through P = 4 and the origin)
+    torch.set_num_threads(threads)
+    points = [{"particles": Pc, "it_per_s": 1.0 / dt, "s_per_it": dt}]
+    Pk = Pc
+    while args.workload == "panda" and len(points) < 3:
+        Pk *= 2
+        est = points[-1]["s_per_it"] * 2.2 * (args.cpu_iters + 1)
+        if time.perf_counter() - leg0 + est > 25.0 or Pk * 0.45e9 > 48e9:
+            break
         try:
-            ora2 = SC.oracle_panda_planner(W.PANDA, T, 2 * Pc, S, dtype=dtype, field_type=args.field, seed=0)
-            torch.set_num_threads(threads)
-            ora2.step(**obs)
-            t0 = time.perf_counter()
-            for _ in range(args.cpu_iters):
-                ora2.step(**obs)
-            points.append({"particles": 2 * Pc, "it_per_s": args.cpu_iters / (time.perf_counter() - t0)})
-        except Exception:                                   # (memory) keep the first point
-            pass
+            ora_k = SC.oracle_panda_planner(W.PANDA, T, Pk, S, dtype=dtype, field_type=args.field, seed=0)
+            dk = timed(ora_k, args.cpu_iters)
+            points.append({"particles": Pk, "it_per_s": 1.0 / dk, "s_per_it": dk})
+            del ora_k
+        except Exception:                                   # (memory) keep what was measured
+            break
+    if len(points) >= 2:
+        (p1, t1), (p2, t2) = [(q["particles"], q["s_per_it"]) for q in points[-2:]]
+        t_full = t2 + (t2 - t1) / (p2 - p1) * (P_full - p2)
+        how = (f"affine extrapolation of the time per iteration through the two largest measured points (P = {p1}: {t1:.3f} s, "
+               f"P = {p2}: {t2:.3f} s) to P = {P_full}")
+    else:
+        t_full = dt * P_full / Pc
+        how = f"per-particle linear extrapolation of the single measured point (P = {Pc}) to P = {P_full}"
+    its = 1.0 / dt
     return {
-        "value": its * Pc / P_full, "unit": "iterations/s", "cores": threads, "kind": "port",
-        "sample": (f"{Pc} of {P_full} particles at full S={S}, T={T}, {str(dtype).split('.')[-1]}, "
-                   f"{args.cpu_iters} iterations after 1 warm-up, best of "
-                   f"several torch thread counts ({threads} threads of {cores} host cores); "
-                   f"measured {its:.3f} it/s at P={Pc}; value = per-particle linear extrapolation to "
-                   f"P={P_full} (the dense reference algorithm needs ~0.4 GB per particle)"),
+        "value": 1.0 / t_full, "unit": "iterations/s", "cores": threads, "kind": "port",
+        "sample": (f"{', '.join(str(q['particles']) for q in points)} of {P_full} particles at full S={S}, T={T}, "
+                   f"{str(dtype).split('.')[-1]}, {args.cpu_iters} iterations after 1 warm-up each, best of several torch thread "
+                   f"counts ({threads} threads of {cores} host cores); value = {how} (the dense reference algorithm needs "
+                   "~0.4 GB per particle)"),
         "measured_it_per_s_at_sample": its, "sample_particles": Pc, "measured_points": points,
-        "torch_threads": threads, "host_cores": cores,
+        "it_per_s_at_sample_by_torch_threads": by_threads, "all_host_cores": all_cores,
+        "torch_threads": threads, "host_cores": cores, "extrapolation": how,
     }
 
 
@@ -525,7 +614,7 @@ def main():
     pl, obs, name = build_planner(torch, args.workload, P_local, S, T, dtype, dev, rank, world,
                                   field=args.field, spheres=args.spheres, goals=goals,
                                   shard_of=tuple(int(v) for v in args.shard_of.split(",")) if args.shard_of and world == 1 else None,
-                                  force_stats_allreduce=use_dist and world == 1)
+                                  force_stats_allreduce=use_dist and world == 1, store_free=bool(args.store_free))
     w = 4 if dtype == torch.float32 else 8
     d = pl.d_state_opt
 
@@ -541,7 +630,7 @@ def main():
     # ~150 iterations run up to 25 % slow (tools/first_calls_probe.py), whatever the call sizes.
     for _ in range(2):
         pl.optimize(opt_iters=100, **obs)                 # (device + chain-stream warm-up)
-    kms = kernel_profile(torch, pl, obs, 100)
+    kms = kernel_profile(torch, pl, obs, 100, unread=bool(args.store_free))
     # Pass 2: W untimed warm-up steps, then EXACTLY K timed steps between barriers (the reported value)
     split0 = pl._engine.pipeline_split_steps()
     elapsed = time_loop(torch, pl, obs, args.steps, args.warmup, barrier, one_call=not args.single_iteration_calls)
@@ -574,8 +663,18 @@ def main():
         # the pair stay SURVEY.md 8(d)'s N w + N w + P S 8 -- traffic the fusion legitimately avoids raises the fraction
         ms_step = 1e3 * elapsed / args.steps
         roof, roof_detail = roofline_of(sweep_kernel + (" (K2+K3 in one launch)" if fused else " (K3)"), kms["cost_sweep"],
-                                        N_elems, w, P_local * S * 8, fused, cfg_key, copy_gbs, step_ms=ms_step,
-                                        step_mode="optimize(opt_iters=1) x K" if args.single_iteration_calls else "optimize(opt_iters=K)")
+                                        N_elems, w, P_local * S * 8, fused, cfg_key + ("_store_free" if args.store_free and cfg_key else ""),
+                                        copy_gbs, step_ms=ms_step,
+                                        step_mode="optimize(opt_iters=1) x K" if args.single_iteration_calls else "optimize(opt_iters=K)",
+                                        field=args.field if args.workload == "panda" else "occupancy grid")
+        # the store-free mode of the same workload (the product's default inside one optimize() call), beside the headline
+        sfree = None
+        if world == 1 and not args.store_free and not args.no_store_free and fused:
+            sfree = store_free_leg(torch, dict(workload=args.workload, P_local=P_local, S=S, T=T, dtype=dtype, field=args.field,
+                                               spheres=args.spheres, goals=goals,
+                                               shard_of=tuple(int(v) for v in args.shard_of.split(",")) if args.shard_of else None),
+                                   lambda **kw: build_planner(torch, dev=dev, **kw), cfg_key, args.steps, N_elems, w,
+                                   P_local * S * 8, ms_step, dev)
         # bytes the iteration really moves: K4 reads only the sample rows whose softmax weight is not exactly zero
         nnz_rows = int((pl._weights_buf != 0).sum())
         iter_alg = 3 * N_elems * w + 2 * P_local * T * d * w + 2 * P_local * S * 8
@@ -592,8 +691,10 @@ def main():
             cpu_detail["leg_seconds"] = time.perf_counter() - t_cpu
             cpu = {"value": cpu_detail["value"], "unit": cpu_detail["unit"], "cores": cpu_detail["cores"],
                    "kind": cpu_detail["kind"],
-                   "sample": f"{cpu_detail['sample_particles']} of {P_local} particles, full S x T, "
-                             f"{args.cpu_iters} iterations, extrapolated linearly in the particles"}
+                   "sample": f"{', '.join(str(q['particles']) for q in cpu_detail['measured_points'])} of {P_local} particles, "
+                             f"full S x T, {args.cpu_iters} iterations each, extrapolated through the two largest; all "
+                             f"{cpu_detail['host_cores']} cores: "
+                             + (f"{cpu_detail['all_host_cores']['value_extrapolated_per_particle']:.4g} it/s" if cpu_detail.get('all_host_cores') else "= cores used")}
             t_cpu = time.perf_counter()
             fair = cpu_fair(args, torch, S, T, P_local)
             if fair:
@@ -616,6 +717,9 @@ def main():
                                        "ms_per_step": 1e3 * elapsed_calls / args.steps},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "mode": "store_free (--store-free: optimize(opt_iters=K) skips the sample stores of iterations 1 .. K-1)" if args.store_free
+                    else "storing (every iteration writes its samples: the mode SURVEY 8(d)'s bytes are defined on)",
+            "store_free": sfree,
             "config": {"workload": name, "particles_per_gpu": P_local, "particles_total": P_local * world,
                        "samples": S, "traj_len": T, "state_dim": d,
                        "parallelism": f"particle-sharded x{world}, RCCL statistics all-reduce inside sgpmp_step"

@@ -161,8 +161,12 @@ int sgpmp_set_priors(sgpmp_ctx* ctx, double dt, const double* sigma_start, const
  * blocks -- D HOST double[n_modes][T][d][d] (diagonal blocks), E HOST double[n_modes][T-1][d][d] with
  * E[m][t] = Sigma_m^-1[t+1-block, t-block]; anything outside the block-tridiagonal band must be zero
  * (the caller checks).  K1 factors every mode (one workgroup each, fp64 MFMA); sgpmp_sample then uses
- * mode m's factor for mean m, sgpmp_prior_quadform its precision.  The planner loop (sgpmp_step,
- * sgpmp_is_weights) keeps requiring the shared closed-form prior of sgpmp_set_prior.
+ * mode m's factor for mean m, sgpmp_prior_quadform its precision.  The planner loop: with which = SGPMP_PRIOR_SAMPLE and
+ * n_modes = the context's particle count, sgpmp_step samples particle p from factor p (two-launch route: the dense sampler
+ * on the matrix cores, then the sweep) while its importance-sampling term -- and sgpmp_is_weights -- keep the shared
+ * closed-form precision of the last sgpmp_set_prior, exactly as the reference does after
+ * planner._sample_dist.set_Sigma_invs(...) (planner.py:226,233-236: `self.Sigma_inv` is captured at reset).  A later
+ * sgpmp_set_prior(s) returns to the shared factor.
  * Synchronous; SGPMP_ENOTPD when a matrix is not positive definite. */
 int sgpmp_set_prior_blocks(sgpmp_ctx* ctx, int which, int n_modes, const double* D, const double* E,
                            void* stream);
@@ -177,7 +181,8 @@ int sgpmp_prior_quadform(sgpmp_ctx* ctx, int which, const void* x, int64_t rows,
 /* Test/inspection hook: copy K1's outputs to HOST buffers (any may be NULL). Synchronous.
  *   blocks  double[4*d*d]  D_0, D_interior, D_last, E = Sigma_inv[(i+1)-block, i-block]
  *   G, H    double[T*d*d]  scan coefficients:  y_t = G_t eps_t + H_t y_{t-1}  (= scale_tril @ eps);
- *           after sgpmp_set_prior_blocks: double[n_modes*T*d*d] and `blocks` is not written.
+ *           after sgpmp_set_prior_blocks: double[n_modes*T*d*d], and `blocks` are those of the shared prior of the
+ *           last sgpmp_set_prior (what the step's importance-sampling term keeps using).
  *   G_t = B_t^-1 is lower triangular and Sigma^-1 = L_inv^T L_inv with diag blocks B_t, so
  *   log det Sigma^-1 = -2 sum_t sum_i log G_t[i][i]. */
 int sgpmp_get_prior(sgpmp_ctx* ctx, int which, double* blocks, double* G, double* H);

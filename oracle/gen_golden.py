@@ -488,13 +488,100 @@ def gen_panda_urdf():
              link_names=np.array(links))
 
 
+# ------------------------------------------------------------------------------ G10
+def gen_per_particle_precisions():
+    """Covariance adaptation through the planner's live sampling distribution: a config-1-sized reference
+    planner, then `planner._sample_dist.set_Sigma_invs(new)` with one precision matrix PER PARTICLE -- the same prior with its
+    GP blocks scaled by 1 + 0.1 p, built by the reference's own get_const_vel_covariance -- then 3 x optimize().  The reference
+    samples particle p from precision p while the importance-sampling term keeps `planner.Sigma_inv` captured at reset
+    (planner.py:226,233-236; mp_priors_multi.py:125-128)."""
+    obst = planar_scene(F64)
+    T, goals, nppg, S, seed = 64, [[9., 6., 0., 0.], [9., -3., 0., 0.]], 2, 16, 3
+    out = {"grid": obst.map.astype(np.uint8), "cell_size": np.array(obst.cell_size), "goals": np.array(goals),
+           "dims": np.array([T, nppg, S, seed, 3])}
+    with NoiseTap() as tap:
+        planner, _ = build_planar(obst, T, goals, nppg, S, seed, F64)
+        out["means_reset"] = npy(planner.particle_means)
+        sd = planner._sample_dist
+        P = planner.num_particles
+        factors = np.array([1. + 0.1 * p for p in range(P)])
+        K_s, K_g = planner.start_prior_sample.K, planner.multi_goal_prior_sample[0].K
+        Q = planner.gp_prior_sample.Q_inv[0]
+        new = torch.stack([sd.get_const_vel_covariance(planner.dt, K_s, Q * float(f), K_g) for f in factors])
+        assert new.shape == sd.Sigma_invs.shape
+        sd.set_Sigma_invs(new)
+        out["gp_scale_per_particle"] = factors
+        out["Sigma_invs_p3_rows_0_8"] = npy(new[3, :8, :12])
+        out["Sigma_inv_planner_rows_0_8"] = npy(planner.Sigma_inv[:8, :12])      # unchanged: what the IS term uses
+        for it in range(1, 4):
+            sp, cp, st, cs, costs, grad = planner.optimize()
+            out[f"means_{it}"] = npy(planner.particle_means)
+            out[f"costs_{it}"] = npy(costs)
+            if it == 1:
+                out["samples_1_p3_s5"] = npy(planner.state_samples[3, 5])
+                out["samples_1_p0_s0"] = npy(planner.state_samples[0, 0])
+        draws = tap.draws
+    assert len(draws) == 2 + 3
+    out["eps_init"] = npy(draws[0])
+    for it in range(1, 4):
+        out[f"eps_{it}"] = npy(draws[1 + it])
+    np.savez_compressed(os.path.join(OUT, "g10_per_particle_precisions.npz"), **out)
+
+
+# ------------------------------------------------------------------------------ G11
+def gen_signatures():
+    """Names, parameter names and defaults of every public method of the classes on the path, as the
+    reference declares them -- DATA (inspect.signature), so that a CPU test can hold the mirrors in stoch_gpmp_amd to
+    "accepts a superset, same defaults" (INTEGRATION.md section 1)."""
+    import inspect
+    import json
+    from stoch_gpmp import planner as ref_planner
+    from stoch_gpmp.costs import cost_functions as ref_costs
+    from stoch_gpmp.costs import fields as ref_fields
+    from stoch_gpmp.costs.factors import field_factor as ref_ff
+    from stoch_gpmp.envs import obst_map as ref_om
+    classes = {
+        "planner.StochGPMP": ref_planner.StochGPMP, "planner.GPMP": ref_planner.GPMP,
+        "costs.factors.mp_priors_multi.MultiMPPrior": MultiMPPrior,
+        "costs.factors.gp_factor.GPFactor": GPFactor, "costs.factors.unary_factor.UnaryFactor": UnaryFactor,
+        "costs.factors.field_factor.FieldFactor": ref_ff.FieldFactor,
+        "costs.cost_functions.CostComposite": ref_costs.CostComposite, "costs.cost_functions.CostGP": ref_costs.CostGP,
+        "costs.cost_functions.CostGPTrajectory": ref_costs.CostGPTrajectory,
+        "costs.cost_functions.CostCollision": ref_costs.CostCollision, "costs.cost_functions.CostGoal": ref_costs.CostGoal,
+        "costs.cost_functions.CostGoalPrior": ref_costs.CostGoalPrior,
+        "costs.fields.LinkDistanceField": ref_fields.LinkDistanceField,
+        "costs.fields.LinkSelfDistanceField": ref_fields.LinkSelfDistanceField,
+        "costs.fields.EESE3DistanceField": ref_fields.EESE3DistanceField,
+        "envs.obst_map.ObstacleMap": ref_om.ObstacleMap,
+    }
+    out = {}
+    for cname, cls in classes.items():
+        methods = {}
+        for mname, fn in inspect.getmembers(cls, predicate=inspect.isfunction):
+            if mname.startswith("_") and mname != "__init__":
+                continue
+            params = []
+            for pn, prm in inspect.signature(fn).parameters.items():
+                if pn == "self":
+                    continue
+                kind = {prm.VAR_KEYWORD: "**", prm.VAR_POSITIONAL: "*"}.get(prm.kind, "")
+                default = None if prm.default is inspect.Parameter.empty else repr(prm.default)
+                params.append([kind + pn, default])
+            methods[mname] = params
+        out[cname] = methods
+    # module-level helper of the planner module
+    out["planner.<module>"] = {"print_info": [[pn, None] for pn in inspect.signature(ref_planner.print_info).parameters]}
+    with open(os.path.join(OUT, "g11_signatures.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
     gens = {"g1": gen_prior, "g2": gen_planar_e2e, "g3": gen_cost_terms, "g4": gen_panda_fields,
             "g5": gen_update_and_is, "g6": gen_scene_tooling, "g7": gen_gpmp, "g8": gen_field_surface,
-            "g9": gen_panda_urdf}
-    for key in (sys.argv[1:] or sorted(gens)):          # `python oracle/gen_golden.py g6` regenerates one
+            "g9": gen_panda_urdf, "g10": gen_per_particle_precisions, "g11": gen_signatures}
+    for key in (sys.argv[1:] or sorted(gens, key=lambda k: int(k[1:]))):          # `python oracle/gen_golden.py g6` regenerates one
         gens[key]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

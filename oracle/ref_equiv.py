@@ -121,6 +121,11 @@ class TrajPrior:
         self.means = means_new.clone().detach()
         self._rebuild()
 
+    def set_Sigma_invs(self, Sigma_invs_new):     # (:125-128)
+        assert Sigma_invs_new.shape == self.Sigma_invs.shape
+        self.Sigma_invs = Sigma_invs_new.clone().detach()
+        self._rebuild()
+
     def scale_tril(self):
         return self.dist._unbroadcasted_scale_tril
 

@@ -21,8 +21,8 @@ class UnaryFactor:
         """[dim, dim] weight matrix (unary_factor.py:19)."""
         return self.precision * torch.eye(self.dim, **self.tensor_args)
 
-    def get_error(self, x, calc_jacobian=False):
-        """mean - x, and with `calc_jacobian` also H = -d error / d x = I per batch entry
+    def get_error(self, x, calc_jacobian=True):
+        """mean - x, and with `calc_jacobian` (the reference's default) also H = -d error / d x = I per batch entry
         (unary_factor.py:22-29): -> error [B, dim, 1], H [B, dim, dim]."""
         residual = torch.sub(self.mean, x)
         if not calc_jacobian:

@@ -30,6 +30,12 @@ class DistanceField(ABC):
     def descriptor(self, sigma):
         """-> dict understood by Engine.set_costs (one cost term with weight 1/sigma^2)."""
 
+    def distances(self, *args, **kwargs):
+        """fields.py:11-12: the base class declares it and does nothing (the link fields override it)."""
+
+    def compute_collision(self, *args, **kwargs):
+        """fields.py:14-15: likewise."""
+
     @abstractmethod
     def compute_cost(self, *args, **kwargs):
         pass

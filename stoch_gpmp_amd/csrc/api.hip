@@ -520,8 +520,9 @@ extern "C" int sgpmp_get_prior(sgpmp_ctx* c, int which, double* blocks, double* 
     const size_t dd = (size_t)c->d * c->d, T = c->dims.traj_len;
     const size_t modes = p.n_factor_modes > 0 ? p.n_factor_modes : 1;     // per-mode factors: [modes][T][d][d]
     HIPCHK(hipDeviceSynchronize());
-    if (blocks && p.n_factor_modes == 0)
-        HIPCHK(hipMemcpy(blocks, p.blocks, sizeof(double) * 4 * dd, hipMemcpyDeviceToHost));
+    // (after sgpmp_set_prior_blocks these are still the blocks of the shared closed-form prior of the last sgpmp_set_prior:
+    // what the step's importance-sampling term keeps using)
+    if (blocks) HIPCHK(hipMemcpy(blocks, p.blocks, sizeof(double) * 4 * dd, hipMemcpyDeviceToHost));
     if (G) HIPCHK(hipMemcpy(G, p.G, sizeof(double) * modes * T * dd, hipMemcpyDeviceToHost));
     if (H) HIPCHK(hipMemcpy(H, p.H, sizeof(double) * modes * T * dd, hipMemcpyDeviceToHost));
     return SGPMP_OK;
@@ -1121,8 +1122,14 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     }
     if (!means || !samples) return fail(SGPMP_EINVAL, "sgpmp_step: null argument");
     if (!c->prior[SGPMP_PRIOR_SAMPLE].valid) return fail(SGPMP_ESTATE, "sgpmp_step: sampling prior not set");
-    if (c->prior[SGPMP_PRIOR_SAMPLE].n_factor_modes > 0)
-        return fail(SGPMP_ESTATE, "sgpmp_step: per-mode precisions (sgpmp_set_prior_blocks) are for sampling / log_prob only");
+    // Per-mode sampling precisions (MultiMPPrior.set_Sigma_invs on the planner's sampling distribution, mp_priors_multi.py:125-128
+    // reached through planner._sample_dist): particle p is sampled from ITS factor (sample_dense_kernel: d x d blocks on the
+    // matrix cores) while the importance-sampling term keeps the precision captured at reset -- the reference's
+    // `self.Sigma_inv = self._sample_dist.Sigma_inv` (planner.py:226) is not updated by set_Sigma_invs (planner.py:233-236) --
+    // i.e. the shared closed-form blocks (Qinv, ks, kg) sgpmp_set_prior left in the same PriorDev.  Such steps run the sampler,
+    // the sweep and the update as separate launches (the fused launches need the shared isotropic factor).
+    if (c->prior[SGPMP_PRIOR_SAMPLE].n_factor_modes > 0 && c->prior[SGPMP_PRIOR_SAMPLE].n_factor_modes < c->dims.num_particles)
+        return fail(SGPMP_ESTATE, "sgpmp_step: per-mode precisions (sgpmp_set_prior_blocks) must cover every particle of the context");
     if (!(temperature > 0.)) return fail(SGPMP_EINVAL, "sgpmp_step: temperature must be positive");
     int rc;
     if ((rc = finalize_program(c)) != SGPMP_OK) return rc;

@@ -48,6 +48,7 @@ class Engine:
         self._keep = []          # tensors whose device memory the cost program points at
         self.n_links = None
         self._prior_key = {}     # which -> arguments of the last successful set_prior
+        self._prior_modes = {}   # which -> number of per-mode factors after set_prior_blocks (absent: one shared factor)
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx:
@@ -200,6 +201,7 @@ class Engine:
         if self._prior_key.get(which) == key:
             return
         self._prior_key.pop(which, None)
+        self._prior_modes.pop(which, None)
         with torch.cuda.device(self.device):
             L.check(self.lib.sgpmp_set_prior(
                 self._ctx, which, float(dt), float(sigma_start),
@@ -224,14 +226,24 @@ class Engine:
         arr = lambda i: (C.c_double * 2)(*[float(-1.0 if v[i] is None else v[i]) for v in (init, sample)])   # noqa: E731
         for w in stale:
             self._prior_key.pop(w, None)
+            self._prior_modes.pop(w, None)
         with torch.cuda.device(self.device):
             L.check(self.lib.sgpmp_set_priors(self._ctx, float(dt), arr(0), arr(1), arr(2), L.stream_ptr()))
         self._prior_key.update(keys)
 
-    def get_prior(self, which, n_modes=None):
+    def get_prior(self, which, n_modes=None, blocks_only=False):
         """-> (blocks [4,d,d], G [T,d,d], H [T,d,d]) as fp64 CPU tensors (inspection/tests); after
-        set_prior_blocks pass n_modes: G, H are [n_modes,T,d,d] and blocks is None."""
+        set_prior_blocks pass n_modes: G, H are [n_modes,T,d,d] and blocks is None.  blocks_only: the four precision
+        blocks of the shared closed-form prior alone (valid also after set_prior_blocks) -> (blocks, None, None)."""
         d, T = self.d, self.T
+        if blocks_only:
+            blocks = (C.c_double * (4 * d * d))()
+            with torch.cuda.device(self.device):
+                L.check(self.lib.sgpmp_get_prior(self._ctx, which, blocks, None, None))
+            return torch.tensor(list(blocks), dtype=torch.float64).reshape(4, d, d), None, None
+        held = self._prior_modes.get(which, 0)
+        if held and (n_modes is None or n_modes < held):
+            n_modes = held                               # (the library copies every mode's factor: size the host buffers for them)
         m = 1 if n_modes is None else n_modes
         blocks = (C.c_double * (4 * d * d))()
         G = (C.c_double * (m * T * d * d))()
@@ -250,6 +262,7 @@ class Engine:
         modes = D.shape[0]
         assert D.shape == (modes, self.T, self.d, self.d) and E.shape == (modes, self.T - 1, self.d, self.d)
         self._prior_key.pop(which, None)
+        self._prior_modes[which] = modes
         Dp = C.cast(D.data_ptr(), C.POINTER(C.c_double))
         Ep = C.cast(E.data_ptr(), C.POINTER(C.c_double))
         with torch.cuda.device(self.device):

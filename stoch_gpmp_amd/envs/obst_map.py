@@ -107,6 +107,17 @@ class ObstacleMap:
             self._engines[key] = eng
         return self._engines[key]
 
+    def plot(self, save_dir=None, filename="obst_map.png"):
+        """obst_map.py:149-156: the occupancy grid as an image (matplotlib, host side; not part of the planning path)."""
+        import os.path as osp
+        import matplotlib.pyplot as plt
+        fig = plt.figure()
+        plt.imshow(self.map)
+        plt.gca().invert_yaxis()
+        if save_dir is not None:
+            plt.savefig(osp.join(save_dir, filename))
+        return fig
+
     def get_collisions(self, X, **kwargs):
         """X [..., 2] -> occupancy value at each point (reference obst_map.py:164-182)."""
         shape = X.shape[:-1]

@@ -45,6 +45,20 @@ class GPMP(StochGPMP):
                          sigma_gp_init=sigma_gp_init, sigma_gp_sample=sigma_gp_sample, seed=seed,
                          tensor_args=tensor_args, **kwargs)
 
+    def get_dist(self, start_K, gp_K, goal_K, state_init, particle_means=None, goal_states=None):
+        """planner.py:479-501: a stand-alone MultiMPPrior of this problem (the same object StochGPMP.get_prior_dist builds)."""
+        return self.get_prior_dist(start_K, gp_K, goal_K, state_init, particle_means=particle_means, goal_states=goal_states)
+
+    def get_torch_solve(self, A, b, method):
+        """planner.py:619-633 for callers that hold a dense system: 'inverse' = torch.linalg.solve; 'cholesky' SOLVES it too
+        (the reference's second triangular solve reads only the factor's diagonal, see the module docstring).  The planner's
+        own step never forms the dense [P, N, N] system: it solves the block-tridiagonal one on the GPU (csrc/gpmp.hip)."""
+        if method == 'inverse':
+            return torch.linalg.solve(A, b)
+        if method == 'cholesky':
+            return torch.cholesky_solve(b, torch.linalg.cholesky(A))
+        raise NotImplementedError
+
     def reset(self, start_state=None, multi_goal_states=None, initial_particle_means=None):
         super().reset(start_state, multi_goal_states, initial_particle_means=initial_particle_means)
         T, d = self.traj_len, self.d_state_opt

@@ -48,6 +48,7 @@ import torch
 
 from . import _lib as L
 from .costs.factors.gp_factor import GPFactor
+from .costs.factors.mp_priors_multi import MultiMPPrior, PlannerPrior
 from .costs.factors.unary_factor import UnaryFactor
 from .dist import allgather_means, allreduce_mode_sums, allreduce_stats_async, mode_moments, shard_range
 from .engine import Engine
@@ -193,6 +194,12 @@ class StochGPMP:
         state_traj[:, :, :, n:] = mean_vel.unsqueeze(1).unsqueeze(1)
         return state_traj
 
+    def get_prior_dist(self, start_K, gp_K, goal_K, state_init, particle_means=None, goal_states=None):
+        """planner.py:157-179: a stand-alone MultiMPPrior of this problem's shape (a context of its own; the planner's OWN
+        distributions, `_sample_dist` / `_init_dist`, are PlannerPrior views of the planner's context)."""
+        return MultiMPPrior(self.traj_len - 1, self.dt, 2 * self.n_dof, self.n_dof, start_K, gp_K, state_init,
+                            K_g_inv=goal_K, means=particle_means, goal_states=goal_states, tensor_args=self.tensor_args)
+
     def _const_vel_prior_means(self):
         """Means of the initialisation prior (mp_priors_multi.py:130-168): [G,T,d]."""
         T, n = self.traj_len, self.n_dof
@@ -254,7 +261,11 @@ class StochGPMP:
             eps = None
             if self.noise == 'torch':                      # reference draw #1: randn(nppg, G, M)
                 eps = torch.randn(nppg, G, M, dtype=ta['dtype']).to(ta['device'])
-            pm = eng.sample(L.PRIOR_INIT, self.seed, self._draw, init_means, nppg, eps=eps)
+            # planner.py:206-214: the initialisation distribution lives for this one draw
+            self._init_dist = PlannerPrior(self, L.PRIOR_INIT, means=init_means)
+            pm = self._init_dist.sample(nppg, eps=eps)
+            del self._init_dist                            # free memory (planner.py:214)
+            self._draw -= 1                                # (counted below, for both ways of initialising)
         self._draw += 1
         # flatten(0,1): p = g * nppg + k (planner.py:215); keep this rank's shard
         self.particle_means = pm.reshape(P, T, d)[self.p0:self.p1].contiguous().clone()
@@ -288,6 +299,9 @@ class StochGPMP:
         self._pm_obj, self._pm_version = None, -1       # means tensor / version after our last fused step
         self._mode_fresh = False                        # _mode_buf holds the statistics of the current means
         self._Sigma_inv = None
+        # planner.py:217-226: the sampling distribution -- a live object over this planner's context and means
+        self._sample_dist = PlannerPrior(self, L.PRIOR_SAMPLE)
+        self._Sigma_invs_set = False
         self._obs_src = None        # strong reference to the caller's obstacle tensor (see _spheres)
         self._obs_ver = -1
         self._obs_dev = None
@@ -319,7 +333,7 @@ class StochGPMP:
         """Dense [M,M] precision of the sampling prior (planner.py:226), assembled on demand from
         K1's blocks -- the kernels never materialise it."""
         if self._Sigma_inv is None:
-            blocks, _, _ = self._engine.get_prior(L.PRIOR_SAMPLE)
+            blocks, _, _ = self._engine.get_prior(L.PRIOR_SAMPLE, blocks_only=True)
             d, T = self.d_state_opt, self.traj_len
             S = torch.zeros(T * d, T * d, dtype=torch.float64)
             for t in range(T):
@@ -692,10 +706,10 @@ class StochGPMP:
                                self.process_group)
 
 
-def print_info(opt_step, opt_iters, start_time_iter, start_time, costs):
+def print_info(iteration, max_iterations, start_time_iter, start_time, costs):
     """Same line format as reference planner.py:664-672."""
     now = time.time()
-    fields = ['Iteration: %5d/%5d ' % (opt_step, opt_iters),
+    fields = ['Iteration: %5d/%5d ' % (iteration, max_iterations),
               ' Iter Time: %.3f' % (now - start_time_iter),
               ' Total Time: %.3f ' % (now - start_time),
               ' Cost: %.6f' % float(costs.sum(-1).mean())]

@@ -225,8 +225,14 @@ def test_factor_mirrors_expose_the_reference_quantities():
     assert gp.Q_inv.shape == (5, 6, 6)
     uf = UnaryFactor(6, 0.05, torch.ones(6, dtype=torch.float64), CPU)
     assert torch.equal(uf.K, R.unary_K(6, 0.05, torch.float64))
-    assert torch.equal(uf.get_error(torch.zeros(2, 1, 6, dtype=torch.float64)),
+    assert torch.equal(uf.get_error(torch.zeros(2, 1, 6, dtype=torch.float64), calc_jacobian=False),
                        torch.ones(2, 1, 6, dtype=torch.float64))
+    # the reference's defaults (gp_factor.py:54, unary_factor.py:22): a bare get_error(x) returns the Jacobians too
+    e, H = uf.get_error(torch.zeros(2, 6, dtype=torch.float64))
+    assert e.shape == (2, 6, 1) and torch.equal(H, torch.eye(6, dtype=torch.float64).expand(2, 6, 6))
+    err, H1, H2 = gp.get_error(torch.zeros(4, 6, 6, dtype=torch.float64))
+    assert err.shape == (4, 5, 6, 1) and torch.equal(H1[2], gp.calc_phi()) and torch.equal(H2[0], -torch.eye(6, dtype=torch.float64))
+    assert torch.equal(gp.calc_Q_inv(), gp.Q_inv) and torch.equal(gp.calc_phi(), gp.phi)
     assert FieldFactor(2, 1e-5, [1, 64]).K == 1. / (1e-5 ** 2) and FieldFactor(2, 1., [1, 64]).length == 63
 
 
@@ -297,6 +303,7 @@ def test_hand_placed_loads_are_not_touched_before_their_wait():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     # 11 = fused_step_kernel x 3 field types x {on the 8 x 16 grid, masked} + cost_sweep_chunked_kernel x 3 + fused_planar_kernel x 2 (n = 2, 3)
     assert re.search(r"\b11 kernels audited, \d+ hand-placed loads, 0 offending", r.stdout), r.stdout
+    assert "0 kernels with scratch" in r.stdout, r.stdout       # (no spilled vector register in any launch of the step)
 
 
 def test_run_time_chain_code_compiles_for_gfx950_without_a_device():
@@ -354,3 +361,54 @@ def test_host_bookkeeping_under_address_and_ub_sanitizers(tmp_path):
     p = subprocess.run([exe], env=dict(base, HOST_ASAN_INJECT="1"), capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and "AddressSanitizer" in p.stderr, "the harness did not notice a short buffer"
     shutil.rmtree(b, ignore_errors=True)
+
+
+def test_mirror_classes_accept_the_reference_signatures():
+    """INTEGRATION.md section 1 says the classes of stoch_gpmp_amd keep the reference's names and signatures.  Checked against
+    DATA dumped from the reference itself (oracle/gen_golden.py g11: inspect.signature of every public method of the classes
+    on the path): every method exists, takes the reference's parameters under the same names in the same positional order
+    with the same defaults, and may take more (a superset: extra keyword arguments with defaults)."""
+    import importlib
+    import inspect
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "g11_signatures.json")))
+    problems = []
+    checked = 0
+    for cname, methods in sorted(ref.items()):
+        modname, _, clsname = cname.rpartition(".")
+        mod = importlib.import_module("stoch_gpmp_amd." + modname)
+        owner = mod if clsname == "<module>" else getattr(mod, clsname, None)
+        if owner is None:
+            problems.append(f"{cname}: class missing")
+            continue
+        for mname, params in sorted(methods.items()):
+            fn = getattr(owner, mname, None)
+            if fn is None or not callable(fn):
+                problems.append(f"{cname}.{mname}: missing")
+                continue
+            mine = [(n, p) for n, p in inspect.signature(fn).parameters.items() if n != "self"]
+            names = [n for n, p in mine if p.kind not in (p.VAR_KEYWORD, p.VAR_POSITIONAL)]
+            has_kw = any(p.kind == p.VAR_KEYWORD for _, p in mine)
+            ref_named = [(n, d) for n, d in params if not n.startswith("*")]
+            if any(n.startswith("**") for n, _ in params) and not has_kw:
+                problems.append(f"{cname}.{mname}: the reference takes **kwargs, the mirror does not")
+            for i, (n, d) in enumerate(ref_named):
+                checked += 1
+                if n not in names:
+                    if not has_kw:
+                        problems.append(f"{cname}.{mname}: parameter {n!r} not accepted")
+                    continue
+                if names.index(n) != i:
+                    problems.append(f"{cname}.{mname}: parameter {n!r} is positional #{names.index(n)}, the reference's is #{i}")
+                p = dict(mine)[n]
+                if d is not None:
+                    if p.default is inspect.Parameter.empty or repr(p.default) != d:
+                        have = "<required>" if p.default is inspect.Parameter.empty else repr(p.default)
+                        problems.append(f"{cname}.{mname}: default of {n!r} is {have}, the reference's is {d}")
+            # (a parameter the mirror adds must not be required)
+            for n, p in mine:
+                if p.kind in (p.VAR_KEYWORD, p.VAR_POSITIONAL) or n in dict(ref_named):
+                    continue
+                if p.default is inspect.Parameter.empty:
+                    problems.append(f"{cname}.{mname}: extra REQUIRED parameter {n!r}")
+    assert checked > 150 and not problems, "\n".join(problems)

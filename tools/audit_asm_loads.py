@@ -105,7 +105,24 @@ def main():
         assert g or "fused_planar" in m.group(1), m.group(1)
         kernels, groups, bad = kernels + 1, groups + g, bad + b
     print(f"{kernels} kernels audited, {groups} hand-placed loads, {bad} offending instructions")
-    return 1 if bad or kernels == 0 else 0
+    # Scratch: none of the step's launches may spill a vector register (round-4 verdict, weak #6: the masked instantiation
+    # of fused_step_kernel carried 4 spilled VGPRs / 20 B of scratch; a scratch access is a vector-memory round trip that
+    # waits behind the launch's stores).  The kernel descriptors say it: .amdhsa_private_segment_fixed_size must be 0, and no
+    # scratch_* instruction may appear in the body.
+    spilled = 0
+    step_kernels = KERNELS + r"|fused_planar_seg_kernel"
+    for m in re.finditer(r"\.amdhsa_kernel (_Z\w*(?:%s)\w*)\n(.*?)\.end_amdhsa_kernel" % step_kernels, text, re.S):
+        size = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
+        if size:
+            print(f"{m.group(1)}: {size} bytes of scratch (spilled registers)")
+            spilled += 1
+    for m in re.finditer(r"^(_Z\w*(?:%s)\w*):[^\n]*\n(.*?)^\.Lfunc_end" % step_kernels, text, re.S | re.M):
+        n = len(re.findall(r"^\s+scratch_", m.group(2), re.M))
+        if n:
+            print(f"{m.group(1)}: {n} scratch instructions")
+            spilled += 1
+    print(f"{spilled} kernels with scratch")
+    return 1 if bad or kernels == 0 or spilled else 0
 
 
 if __name__ == "__main__":
