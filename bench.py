@@ -636,14 +636,15 @@ def main():
     elapsed = time_loop(torch, pl, obs, args.steps, args.warmup, barrier, one_call=not args.single_iteration_calls)
     split_steps = pl._engine.pipeline_split_steps() - split0
     # Pass 3 (reported beside it): the same K iterations as K optimize(opt_iters=1) calls
-    elapsed_calls = time_loop(torch, pl, obs, args.steps, args.warmup, barrier, one_call=False)
+    # (--store-free: skipped -- single-iteration calls always store, and a profile of the store-free launches must not mix them in)
+    elapsed_calls = time_loop(torch, pl, obs, args.steps, args.warmup, barrier, one_call=False) if not args.store_free else None
     rank_rates = None
     if use_dist:
-        mine = torch.tensor([elapsed, elapsed_calls], device="cpu" if shared_gpu else dev, dtype=torch.float64)
+        mine = torch.tensor([elapsed, elapsed_calls or 0.0], device="cpu" if shared_gpu else dev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         rank_rates = [args.steps / float(e[0]) for e in every]           # each rank's own clock, before the max
-        elapsed, elapsed_calls = max(float(e[0]) for e in every), max(float(e[1]) for e in every)
+        elapsed, elapsed_calls = max(float(e[0]) for e in every), (max(float(e[1]) for e in every) if elapsed_calls else None)
     mean_cost, mean_min_cost = pl.global_stats()
     # what the communicator behind the C ABI itself reports (ncclCommCount / ncclCommUserRank / ncclGetVersion):
     # proof that RCCL saw `world` ranks, not a number this script made up
@@ -712,9 +713,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
             "field": args.field if args.workload == "panda" else "occupancy grid",
-            "single_call_iterations_per_s": world * args.steps / elapsed_calls,   # K x optimize(opt_iters=1), the reference examples' loop
+            "single_call_iterations_per_s": (world * args.steps / elapsed_calls) if elapsed_calls else None,   # K x optimize(opt_iters=1), the reference examples' loop
             "single_iteration_calls": {"iterations_per_s": world * args.steps / elapsed_calls,
-                                       "ms_per_step": 1e3 * elapsed_calls / args.steps},
+                                       "ms_per_step": 1e3 * elapsed_calls / args.steps} if elapsed_calls else None,
             "roofline": roof,
             "cpu_baseline": cpu,
             "mode": "store_free (--store-free: optimize(opt_iters=K) skips the sample stores of iterations 1 .. K-1)" if args.store_free

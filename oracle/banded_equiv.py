@@ -116,3 +116,23 @@ def panda_chunk_cost(c, T, S, goals, field_type='rbf', dtype=torch.float64):
             xt, lambda f: R.field_spheres(f, obs["obstacle_spheres"], field_type=field_type), c["sigma_coll"])
         return out
     return cost
+
+
+def planar_chunk_cost(c, T, S, goals, grid, cell_size, c_offset, dtype=torch.float64):
+    """The planar twin: cost(x [p,S,T,d] of goal g, g) -> [p*S] with the oracle's CostGP, CostGoalPrior (goal g) and
+    occupancy-grid terms (cost_functions.py:128-146, 376-388, 247-261 + obst_map.py:164-182)."""
+    import numpy as np
+    n = c["n_dof"]
+    start = torch.tensor(c["start"], dtype=dtype)
+    goals = torch.as_tensor(goals, dtype=dtype)
+    grid_t = torch.as_tensor(np.asarray(grid, dtype=np.float64)).to(dtype)
+    off = torch.as_tensor(c_offset, dtype=dtype)
+
+    def cost(x, g, **obs):
+        p = x.shape[0]
+        trajs = x.reshape(-1, T, 2 * n)
+        out = R.cost_gp(trajs, start, n, c["dt"], c["cost_sigma_start"], c["cost_sigma_gp"])
+        out = out + R.cost_goal_prior(trajs, goals[g:g + 1], p, S, n, c["sigma_goal_prior"])
+        out = out + R.cost_collision_grid(trajs, n, grid_t, cell_size, off, c["sigma_coll"])
+        return out
+    return cost

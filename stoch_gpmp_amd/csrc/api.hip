@@ -769,11 +769,9 @@ extern "C" int sgpmp_set_fk_codegen(sgpmp_ctx* c, const char* struct_src) {
     int ft = SGPMP_FIELD_RBF;
     for (int i = 0; i < c->h_prog.n_terms; ++i)
         if (c->h_prog.terms[i].kind == SGPMP_COST_SPHERES) ft = c->h_prog.terms[i].flags & 15;
-    if (const char* e = rtc_verify(rc, c->h_chain, ft)) {
-        const std::string msg = e;
-        const bool mismatch = msg.find("does not") != std::string::npos || msg.find("outside the chain") != std::string::npos;
-        return fail(mismatch ? SGPMP_EINVAL : SGPMP_ESTATE, "sgpmp_set_fk_codegen: " + msg);
-    }
+    int mismatch = 0;
+    if (const char* e = rtc_verify(rc, c->h_chain, ft, &mismatch))
+        return fail(mismatch ? SGPMP_EINVAL : SGPMP_ESTATE, std::string("sgpmp_set_fk_codegen: ") + e);
     c->h_chain.plan.codegen_id = 2;
     c->h_chain.rtc = rc;
     HIPCHK(hipMemcpy(c->d_chain, &c->h_chain, sizeof(c->h_chain), hipMemcpyHostToDevice));

@@ -31,6 +31,12 @@
 #ifndef SGPMP_CSRC_DEFAULT
 #define SGPMP_CSRC_DEFAULT ""
 #endif
+#ifndef SGPMP_BUILD_EXTRA
+#define SGPMP_BUILD_EXTRA ""                 // the EXTRA compile flags of this build (Makefile): the run-time compiler gets the same -D's
+#endif
+#if __has_include("rtc_sources_hash.h")
+#include "rtc_sources_hash.h"                // SGPMP_RTC_SOURCES_HASH: FNV-1a of the kernel sources this library was built from (Makefile)
+#endif
 
 namespace {
 
@@ -44,6 +50,7 @@ struct HiprtcApi {
     hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
     hiprtcResult (*GetCode)(hiprtcProgram, char*) = nullptr;
     hiprtcResult (*DestroyProgram)(hiprtcProgram*) = nullptr;
+    hiprtcResult (*Version)(int*, int*) = nullptr;       // optional
 };
 HiprtcApi g_rtc;
 std::mutex g_mu;
@@ -69,6 +76,7 @@ const char* load_hiprtc() {
     SYM(GetCode, "hiprtcGetCode")
     SYM(DestroyProgram, "hiprtcDestroyProgram")
 #undef SYM
+    g_rtc.Version = (decltype(g_rtc.Version))dlsym(h, "hiprtcVersion");
     g_rtc.handle = h;
     return nullptr;
 }
@@ -98,6 +106,10 @@ uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
     return h;
 }
 
+// The directory code objects are cached in, or "" (no cache).  Whatever is found there is LOADED INTO THE GPU, so the
+// directory must be this user's own and closed to everybody else: owner = getuid(), a real directory (not a symlink), no
+// group / other permission bits -- otherwise another user of the machine could pre-seed a code object (round-4 advisor
+// finding: the /tmp fallback was used unchecked).  A directory that fails the check is not used at all.
 std::string cache_dir() {
     std::string d;
     if (const char* e = getenv("SGPMP_RTC_CACHE")) d = e;
@@ -109,7 +121,45 @@ std::string cache_dir() {
     const size_t k = d.rfind('/');
     if (k != std::string::npos && k > 0) mkdir(d.substr(0, k).c_str(), 0700);
     mkdir(d.c_str(), 0700);
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & (S_IRWXG | S_IRWXO)) != 0) return "";
     return d;
+}
+
+// FNV-1a over the contents of the kernel sources in `dir`, in kSources order (what gen/rtc_hash.py computed at build time)
+bool sources_hash(const std::string& dir, uint64_t* out, std::string* missing) {
+    uint64_t h = 14695981039346656037ull;
+    for (const char* f : kSources) {
+        std::ifstream in(dir + "/" + f, std::ios::binary);
+        if (!in) { if (missing) *missing = f; return false; }
+        std::vector<char> buf((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        h = fnv1a(h, buf.data(), buf.size());
+    }
+    *out = h;
+    return true;
+}
+
+// The kernel sources on disk must be the ones this library was built from: the host side passes CostArgs / FlatProg /
+// FusedArgs BY VALUE in layouts fixed at build time, and a kernel compiled from edited sources (or for a library loaded
+// through SGPMP_LIB_PATH from another tree) would read them with another layout -- silent memory corruption (round-4
+// advisor finding).  Returns nullptr when they match (or the development override SGPMP_RTC_ALLOW_EDITED_SOURCES=1 is set).
+const char* check_sources(const std::string& dir, uint64_t* hash_out) {
+    static thread_local std::string msg;
+    std::string missing;
+    uint64_t h = 0;
+    if (!sources_hash(dir, &h, &missing)) { msg = "kernel source missing: " + missing; return msg.c_str(); }
+    *hash_out = h;
+#ifdef SGPMP_RTC_SOURCES_HASH
+    if (h != SGPMP_RTC_SOURCES_HASH) {
+        const char* ov = getenv("SGPMP_RTC_ALLOW_EDITED_SOURCES");
+        if (!(ov && *ov == '1')) {
+            msg = "the kernel sources in " + dir + " are not the ones this libsgpmp.so was built from (content hash differs): "
+                  "rebuild the library, or point SGPMP_CSRC_DIR at its own csrc/";
+            return msg.c_str();
+        }
+    }
+#endif
+    return nullptr;
 }
 
 }  // namespace
@@ -138,7 +188,10 @@ static std::string translation_unit(const RtcChain& c) {
           "#include \"sgpmp_internal.h\"\n#include \"rng.h\"\n#include \"update_common.h\"\n"
           "#pragma clang diagnostic ignored \"-Wunused-variable\"\n"
        << c.struct_src
-       << "\nusing ChainCode_panda = ChainCode_rt;       // (the generic kernels' ChainOf<> default; never instantiated here)\n"
+       << "\nstatic_assert(ChainCode_rt::NREP >= 1 && ChainCode_rt::NREP <= SGPMP_MAX_LINKS && ChainCode_rt::NJ <= SGPMP_MAX_JOINTS && "
+          "ChainCode_rt::N >= 1 && ChainCode_rt::N <= 7 && ChainCode_rt::NPAIR >= 0 && ChainCode_rt::NPAIR <= SGPMP_MAX_LINKS * SGPMP_MAX_LINKS / 2, "
+          "\"chain code outside the library's link / joint / pair tables\");\n"
+       << "using ChainCode_panda = ChainCode_rt;       // (the generic kernels' ChainOf<> default; never instantiated here)\n"
           "#include \"cost_device.h\"\n#include \"cost_sweep_kernel.inc\"\n#include \"cost_sweep_dual.inc\"\n"
           "#include \"fused_step.inc\"\n"
           "extern \"C\" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGPMP_FUSED_WAVES, SGPMP_FUSED_WAVES)))\n"
@@ -180,10 +233,13 @@ static bool compile_tu(const std::string& tu, const std::string& dir, int ft, st
     }
     const std::string inc = "-I" + dir, ftd = "-DSGPMP_RTC_FT=" + std::to_string(ft),
                       rounds = "-DSGPMP_PHILOX_ROUNDS=" + std::to_string(SGPMP_PHILOX_ROUNDS);
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str(), ftd.c_str(), rounds.c_str()};
+    std::vector<std::string> extra;                          // the library's own EXTRA -D flags: kernels and host agree on every build parameter
+    { std::istringstream es(SGPMP_BUILD_EXTRA); for (std::string tok; es >> tok;) if (tok.rfind("-D", 0) == 0 && tok.find("SGPMP_PHILOX_ROUNDS") == std::string::npos) extra.push_back(tok); }
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str(), ftd.c_str(), rounds.c_str()};
+    for (const std::string& e : extra) opts.push_back(e.c_str());
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    const hiprtcResult r = g_rtc.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+    const hiprtcResult r = g_rtc.CompileProgram(prog, (int)opts.size(), opts.data());
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (secs) *secs += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     if (r != HIPRTC_SUCCESS) {
@@ -209,6 +265,8 @@ long long rtc_compile_check(const char* struct_src, int ft, std::string& err) {
     std::lock_guard<std::mutex> lk(g_mu);
     const std::string dir = csrc_dir();
     if (dir.empty() || !file_exists(dir + "/fused_step.inc")) { err = "kernel sources not found (csrc/ next to libsgpmp.so; SGPMP_CSRC_DIR)"; return -1; }
+    uint64_t srch = 0;
+    if (const char* e = check_sources(dir, &srch)) { err = e; return -1; }
     RtcChain tmp;
     tmp.struct_src = struct_src;
     std::vector<char> code;
@@ -219,24 +277,26 @@ long long rtc_compile_check(const char* struct_src, int ft, std::string& err) {
 // Compile (or fetch from the disk cache) the code object of chain `c` for sphere-field type `ft`; load it as a module.
 static bool build_module(RtcChain& c, int ft) {
     if (c.mod[ft]) return true;
+    // (only a COMPILER verdict is final for the process: missing sources, an unusable cache directory or a failed module
+    // load may be repaired -- SGPMP_CSRC_DIR, a rebuilt library -- and are retried on the next call)
     if (c.tried[ft]) return false;
-    c.tried[ft] = true;
     const std::string dir = csrc_dir();
     if (dir.empty() || !file_exists(dir + "/fused_step.inc")) {
         c.err = "kernel sources not found (looked for csrc/fused_step.inc next to libsgpmp.so; set SGPMP_CSRC_DIR)";
         return false;
     }
+    uint64_t srch = 0;
+    if (const char* e = check_sources(dir, &srch)) { c.err = e; return false; }
     const std::string tu = translation_unit(c);
-    // cache key: the translation unit, the field type, the build parameters and the state of every included file
+    // cache key: the translation unit, the field type, the build parameters (incl. the EXTRA flags), the run-time compiler's
+    // version and the CONTENT of every included file
     uint64_t key = fnv1a(14695981039346656037ull, tu.data(), tu.size());
-    const int params[3] = {ft, SGPMP_PHILOX_ROUNDS, SGPMP_ABI_VERSION};
+    int rv[2] = {0, 0};
+    if (!load_hiprtc() && g_rtc.Version) g_rtc.Version(&rv[0], &rv[1]);
+    const int params[5] = {ft, SGPMP_PHILOX_ROUNDS, SGPMP_ABI_VERSION, rv[0], rv[1]};
     key = fnv1a(key, params, sizeof(params));
-    for (const char* f : kSources) {
-        struct stat st;
-        if (stat((dir + "/" + f).c_str(), &st) != 0) { c.err = std::string("kernel source missing: ") + f; return false; }
-        const long long sig[2] = {(long long)st.st_size, (long long)st.st_mtime};
-        key = fnv1a(key, sig, sizeof(sig));
-    }
+    key = fnv1a(key, SGPMP_BUILD_EXTRA, sizeof(SGPMP_BUILD_EXTRA));
+    key = fnv1a(key, &srch, sizeof(srch));
     char name[64];
     std::snprintf(name, sizeof(name), "chain-%016llx-ft%d.hsaco", (unsigned long long)key, ft);
     const std::string cdir = cache_dir();
@@ -247,7 +307,7 @@ static bool build_module(RtcChain& c, int ft) {
         if (f) { code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>()); if (!code.empty()) c.from_cache += 1; }
     }
     if (code.empty()) {
-        if (!compile_tu(tu, dir, ft, code, c.err, &c.compile_s)) return false;
+        if (!compile_tu(tu, dir, ft, code, c.err, &c.compile_s)) { c.tried[ft] = c.err.rfind("hiprtc: compilation", 0) == 0; return false; }
         c.compiled += 1;
         if (!cpath.empty()) {                     // write-then-rename: concurrent processes never see half a file
             const std::string tmp = cpath + "." + std::to_string((long)getpid());
@@ -308,7 +368,10 @@ hipError_t rtc_launch(hipFunction_t f, unsigned blocks, unsigned dyn_lds, hipStr
 
 // Does the generated code describe THIS chain?  Link positions of the distinct links at pseudo-random joint vectors against
 // the host's double-precision FK of the chain given to sgpmp_set_fk, and the link / pair tables against the host analysis.
-const char* rtc_verify(RtcChain* c, const ChainDev& ch, int ft_hint) {
+// *mismatch (may be null): 1 when the failure is "this code is not this chain's" (the caller's SGPMP_EINVAL), 0 when the chain
+// kernels are merely unavailable (no compiler, no sources, a failed launch: SGPMP_ESTATE).
+const char* rtc_verify(RtcChain* c, const ChainDev& ch, int ft_hint, int* mismatch) {
+    if (mismatch) *mismatch = 0;
     if (!rtc_kernel(c, ft_hint, false)) return c->err.c_str();
     const int K = 16, N = c->n_dof, ML = SGPMP_MAX_LINKS;
     std::vector<float> q((size_t)K * N);
@@ -337,6 +400,7 @@ const char* rtc_verify(RtcChain* c, const ChainDev& ch, int ft_hint) {
     static thread_local std::string msg;
     if ((int)tab[0] != N || (int)tab[1] != ch.n_joints || nrep != pl.n_rep || (int)tab[3] != npair ||
         std::fabs(tab[4] - msum) > 1e-3 || std::fabs(tab[5] - wsum) > 1e-3) {
+        if (mismatch) *mismatch = 1;
         msg = "generated chain code does not match the chain of sgpmp_set_fk (tables: N " + std::to_string((int)tab[0]) + "/" + std::to_string(N) +
               ", joints " + std::to_string((int)tab[1]) + "/" + std::to_string(ch.n_joints) + ", distinct links " + std::to_string(nrep) + "/" +
               std::to_string(pl.n_rep) + ", q-dependent pairs " + std::to_string((int)tab[3]) + "/" + std::to_string(npair) + ")";
@@ -361,9 +425,10 @@ const char* rtc_verify(RtcChain* c, const ChainDev& ch, int ft_hint) {
         }
         for (int l = 0; l < nrep; ++l) {
             const int link = (int)tab[8 + l];
-            if (link < 0 || link > ch.n_joints) return "generated chain code names a link outside the chain";
+            if (link < 0 || link > ch.n_joints) { if (mismatch) *mismatch = 1; return "generated chain code names a link outside the chain"; }
             for (int x = 0; x < 3; ++x)
                 if (std::fabs((double)pos[((size_t)k * nrep + l) * 3 + x] - hp[link][x]) > 2e-4) {    // (v_sin / v_cos: ~1e-6 per joint)
+                    if (mismatch) *mismatch = 1;
                     msg = "generated chain code does not reproduce the forward kinematics of the chain of sgpmp_set_fk (link " + std::to_string(link) + ")";
                     return msg.c_str();
                 }

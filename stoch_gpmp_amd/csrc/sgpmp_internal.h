@@ -151,7 +151,7 @@ struct RtcChain;
 const char* rtc_chain_get(const char* struct_src, int n_dof, RtcChain** out);       // null on success, else the reason
 hipFunction_t rtc_kernel(RtcChain* c, int field_type, bool sweep, bool rag = false); // compiled on first use; null: unavailable (rag: the fused launch for S, T off its 8 x 16 grid)
 hipError_t rtc_launch(hipFunction_t f, unsigned blocks, unsigned dyn_lds, hipStream_t stream, void** args, hipEvent_t done);
-const char* rtc_verify(RtcChain* c, const ChainDev& chain, int field_type_hint);     // generated code == this chain?
+const char* rtc_verify(RtcChain* c, const ChainDev& chain, int field_type_hint, int* mismatch = nullptr);   // generated code == this chain?  (*mismatch: 1 = no, 0 = kernels unavailable)
 const char* rtc_error(const RtcChain* c);
 void rtc_stats(const RtcChain* c, double* compile_s, int* compiled, int* from_cache);
 long long rtc_compile_check_c(const char* struct_src, int field_type, char* err, size_t err_len);   // compile only: bytes, or -1

@@ -158,7 +158,7 @@ hipError_t launch_field_eval(int dtype, const CostTerm&, const void* frames, lon
 const char* rtc_chain_get(const char*, int, RtcChain**) { return "no run-time compiler in the sanitizer harness"; }
 hipFunction_t rtc_kernel(RtcChain*, int, bool) { return nullptr; }
 hipError_t rtc_launch(hipFunction_t, unsigned, hipStream_t, void**, hipEvent_t) { return hipErrorNotSupported; }
-const char* rtc_verify(RtcChain*, const ChainDev&, int) { return "no run-time compiler in the sanitizer harness"; }
+const char* rtc_verify(RtcChain*, const ChainDev&, int, int* mismatch) { if (mismatch) *mismatch = 0; return "no run-time compiler in the sanitizer harness"; }
 const char* rtc_error(const RtcChain*) { return ""; }
 void rtc_stats(const RtcChain*, double* s, int* c, int* f) { if (s) *s = 0.; if (c) *c = 0; if (f) *f = 0; }
 long long rtc_compile_check_c(const char*, int, char* err, size_t n) { if (err && n) err[0] = 0; return -1; }

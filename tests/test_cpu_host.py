@@ -334,6 +334,41 @@ def test_run_time_chain_code_compiles_for_gfx950_without_a_device():
     assert rc == _lib.ESTATE and "hiprtc" in _lib.last_error()
 
 
+def test_run_time_chain_compiler_refuses_kernel_sources_it_was_not_built_from(tmp_path):
+    """The library passes CostArgs / FlatProg / FusedArgs by value in layouts fixed when IT was built; chain kernels compiled
+    from other sources (an edited tree, a library loaded from elsewhere through SGPMP_LIB_PATH) would read them with another
+    layout.  The content hash of the kernel sources is baked into the library (csrc/gen/rtc_hash.py): a csrc directory whose
+    files differ by one byte is refused (SGPMP_ESTATE), SGPMP_RTC_ALLOW_EDITED_SOURCES=1 is the development override.
+    (Own process: SGPMP_CSRC_DIR is read when the compiler looks for its sources.)"""
+    import shutil
+    import subprocess
+    import sys
+    src = os.path.join(ROOT, "stoch_gpmp_amd", "csrc")
+    inc = os.path.join(ROOT, "include")
+    edited = tmp_path / "tree" / "stoch_gpmp_amd" / "csrc"
+    shutil.copytree(src, edited, ignore=shutil.ignore_patterns("build*", "*.o"))
+    shutil.copytree(inc, tmp_path / "tree" / "include")
+    with open(edited / "fused_step.inc", "a") as f:
+        f.write("// one more line\n")
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from stoch_gpmp_amd import _lib\n"
+        "from stoch_gpmp_amd.engine import _chain_struct_source\n"
+        "from stoch_gpmp_amd.robots.panda_chain import PANDA_CHAIN\n"
+        "lib = _lib.load()\n"
+        "chain = [(nm, kind, rpy, (xyz[0] + (0.01 if i == 3 else 0.0), xyz[1], xyz[2])) for i, (nm, kind, rpy, xyz) in enumerate(PANDA_CHAIN)]\n"
+        "rc = lib.sgpmp_fk_codegen_compile(_chain_struct_source(chain).encode(), 0, None)\n"
+        "print('RC', rc, _lib.last_error()[:300].replace(chr(10), ' '))\n" % ROOT)
+    env = dict(os.environ, SGPMP_CSRC_DIR=str(edited))
+    env.pop("SGPMP_RTC_ALLOW_EDITED_SOURCES", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "RC -4" in r.stdout and "not the ones this libsgpmp.so was built from" in r.stdout, r.stdout + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, SGPMP_RTC_ALLOW_EDITED_SOURCES="1"), capture_output=True,
+                       text=True, timeout=600)
+    assert "RC 0" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
 def test_host_bookkeeping_under_address_and_ub_sanitizers(tmp_path):
     """tests/host_asan: api.hip and comm.hip compiled host-only with -fsanitize=address,undefined over a stub HIP runtime
     (malloc-backed device memory, streams that execute at enqueue), stub launchers that touch the kernels' byte ranges and

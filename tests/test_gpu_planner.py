@@ -828,6 +828,186 @@ def test_dense_weight_update_adds_partials_of_the_fused_launch_instead_of_reread
     assert h._engine.dense_particles() == 0 and int(h._engine.row_counts().max()) == 1
 
 
+# --------------------------------------------------------------------------- whole-population parity at full size (round 5)
+# Round-4 verdict, weak #1 / next #2: the full-size fp32 parity above follows 3-8 particles per configuration; here EVERY
+# particle of the configuration is followed by the fp64 banded oracle (oracle/banded_equiv.py: the dense oracle's mathematics
+# with the prior factored once -- pinned to the dense oracle, which is pinned to reference runs, at 1e-9) on the restated
+# noise of its own global index: 2 re-synchronised iterations (the oracle is handed the HIP means before the step: every
+# particle-iteration an independent trial) + 5 free-running ones (both sides on their own).  The population is cut into
+# chunks of particles that worker threads step side by side (particles are independent: planner.py:263-275).
+def _population_parity(tag, pl, make_band, n, obs_hip, obs_ora, expect_kernel, sync_iters=2, free_iters=5, pchunk=32, workers=32,
+                       cost_quantum=None):
+    """cost_quantum (planar problems): the weight 1 / sigma_coll^2 of one occupancy-grid count.  The grid lookup is a step
+    function of the position (obst_map.py:173-174: floor(X / cell + offset)); a sample whose fp32 position lies within
+    rounding of a cell boundary reads the neighbouring cell, and its cost differs from the fp64 oracle's by a whole number
+    of quanta (1e10 at configs[1]) -- counted and reported as `grid_boundary_samples`, not as cost error."""
+    import json
+    import os
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.native_noise import native_eps
+    t_start = time.perf_counter()
+    P, S, T = pl.num_particles_local, pl.num_samples, pl.traj_len
+    chunks = [(lo, min(P, lo + pchunk)) for lo in range(0, P, pchunk)]
+    bands = [make_band(lo, hi, pl.particle_means[lo:hi].cpu().double()) for lo, hi in chunks]
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // workers)))
+    tracking = np.ones(P, dtype=bool)
+    per_iter, flips_log, unexplained = [], [], []
+    worst_cost = worst_samples = 0.0
+    boundary = 0
+    scale = float(pl.particle_means.abs().max())
+    try:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            for it in range(sync_iters + free_iters):
+                sync = it < sync_iters
+                draw = pl._draw
+                mu_before = pl.particle_means.cpu().double()
+                costs = pl.optimize(opt_iters=1, **obs_hip)[4].cpu().double()
+                assert pl._engine.last_cost_kernel().startswith(expect_kernel), pl._engine.last_cost_kernel()
+                x_hip = pl.state_samples.cpu()
+                mu_after = pl.particle_means.cpu().double()
+
+                def one(ci):
+                    lo, hi = chunks[ci]
+                    band = bands[ci]
+                    if sync:
+                        band.particle_means = mu_before[lo:hi].clone()
+                    eps = torch.from_numpy(native_eps(pl.seed, draw, range(pl.p0 + lo, pl.p0 + hi), S, T, n, "float32")).double()
+                    c_o, _ = band.step(eps, **obs_ora)
+                    x_o = band.state_samples
+                    xs = float((x_hip[lo:hi].double() - x_o).abs().max() / x_o.abs().max())
+                    diff = costs[lo:hi] - c_o
+                    rel = diff.abs() / c_o.abs()
+                    on_boundary = 0
+                    if cost_quantum is not None:
+                        q = diff / cost_quantum
+                        stepped = (rel > 1e-3) & (q.round() != 0) & ((q - q.round()).abs() < 0.02)
+                        on_boundary = int(stepped.sum())
+                        rel = torch.where(stepped, torch.zeros_like(rel), rel)
+                    cr = rel.amax(dim=1)
+                    d = (mu_after[lo:hi] - band.particle_means).abs().amax(dim=(1, 2)) / scale
+                    a = costs[lo:hi].argmin(dim=1)
+                    b = c_o.argmin(dim=1)
+                    gap = ((c_o.gather(1, a[:, None]) - c_o.gather(1, b[:, None])).abs() / c_o.gather(1, b[:, None]).abs())[:, 0]
+                    return lo, hi, xs, cr.numpy(), d.numpy(), (a != b).numpy(), gap.numpy(), on_boundary
+                within = flips = 0
+                for lo, hi, xs, cr, d, differ, gap, nb_ in pool.map(one, range(len(chunks))):
+                    boundary += nb_
+                    for j in range(hi - lo):
+                        p = lo + j
+                        if not (sync or tracking[p]):
+                            continue                         # (left its twin through a documented near-tie: no longer comparable)
+                        worst_cost = max(worst_cost, float(cr[j]))
+                        if d[j] < 1e-3:
+                            within += 1
+                            continue
+                        rec = {"iteration": it + 1, "particle": int(pl.p0 + p), "means_rel": float(d[j]), "near_tie_gap": float(gap[j]),
+                               "resynchronised": sync}
+                        if differ[j] and gap[j] < 2e-5:
+                            flips += 1
+                            flips_log.append(rec)
+                        else:
+                            unexplained.append(rec)
+                        if not sync:
+                            tracking[p] = False
+                    if sync or tracking[lo:hi].all():
+                        worst_samples = max(worst_samples, xs)
+                compared = P if sync else int(tracking.sum()) + flips
+                per_iter.append({"iteration": it + 1, "resynchronised": sync, "particles_compared": compared,
+                                 "within_1e-3": within / max(compared, 1), "near_tie_flips": flips})
+    finally:
+        torch.set_num_threads(threads_before)
+    rec = {"configuration": tag, "kernel": expect_kernel, "particles": P, "global_range": [int(pl.p0), int(pl.p1)],
+           "samples": S, "traj_len": T, "oracle": "oracle/banded_equiv.py (fp64; pinned to the dense oracle at 1e-9)",
+           "iterations": per_iter, "near_tie_flips": flips_log, "flip_rate_per_particle_iteration":
+           len(flips_log) / float(P * (sync_iters + free_iters)), "unexplained_departures": unexplained,
+           "largest_unexplained_gap": max([u["near_tie_gap"] for u in unexplained], default=None),
+           "cost_rel_err_max": worst_cost, "samples_rel_err_max": worst_samples,
+           "grid_boundary_samples": boundary if cost_quantum is not None else None,
+           "sample_costs_compared": P * S * (sync_iters + free_iters),
+           "still_tracking_after_free_run": int(tracking.sum()), "seconds": time.perf_counter() - t_start}
+    print(f"\n[whole-population parity] {tag}: " + json.dumps({k: v for k, v in rec.items() if k not in ('near_tie_flips',)}))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        path = os.path.join(out, "parity_population.json")
+        old = json.load(open(path)) if os.path.exists(path) else {}
+        old[tag] = rec
+        json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+    assert not unexplained, unexplained[:5]
+    assert worst_cost < 5e-3 and worst_samples < 2e-5, (worst_cost, worst_samples)
+    assert all(r["within_1e-3"] + r["near_tie_flips"] / max(r["particles_compared"], 1) == 1.0 for r in per_iter)
+    return rec
+
+
+def test_whole_population_parity_config3():
+    """BASELINE configs[2]: all 1024 particles x 128 samples x 64 waypoints of the fused launch against the banded oracle."""
+    from oracle import banded_equiv as B
+    c, n = SC.PANDA, 7
+    T, S, P, seed = 64, 128, 1024, 83
+    sph = torch.as_tensor(SC.panda_spheres(num=5))
+    goal = torch.tensor([c["goal_q"] + [0.] * n], dtype=torch.float64)
+    start = torch.tensor(c["start_q"] + [0.] * n, dtype=torch.float64)
+    pl = hip_panda_planner(c, T, P, S, F32, seed=seed)
+    cost = B.panda_chunk_cost(c, T, S, goal, "rbf")
+
+    def make_band(lo, hi, mu):
+        return B.BandedPlanner(hi - lo, S, T, c["dt"], n, start, goal, cost, c["step_size"], c["temperature"],
+                               c["sigma_start_sample"], c["sigma_goal_sample"], c["sigma_gp_sample"], mu, chunk=8)
+    rec = _population_parity("config 3: Panda 1024 x 128 x 64 fp32 (fused launch)", pl, make_band, n,
+                             {"obstacle_spheres": sph.to(**F32)}, {"obstacle_spheres": sph}, "fused_step_kernel")
+    assert rec["still_tracking_after_free_run"] >= 0.99 * P
+
+
+def test_whole_population_parity_config2(golden):
+    """BASELINE configs[1]: all 256 particles (4 goals x 64) x 64 samples x 128 waypoints of fused_planar_seg_kernel."""
+    from oracle import banded_equiv as B
+    z = golden("g2_planar_e2e.npz")
+    c, n = SC.PLANAR, 2
+    T, nppg, S, seed = 128, 64, 64, 85
+    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
+    goals_t = torch.tensor(goals, dtype=torch.float64)
+    start = torch.tensor(c["start"], dtype=torch.float64)
+    pl = hip_planar_planner(c, T, goals, nppg, S, planar_map(golden, F32), F32, seed=seed)
+
+    def make_band(lo, hi, mu):
+        g = lo // nppg
+        assert (hi - 1) // nppg == g
+        cost = B.planar_chunk_cost(c, T, S, goals_t[g:g + 1], z["grid"], float(z["cell_size"]), z["c_offset"])
+        return B.BandedPlanner(hi - lo, S, T, c["dt"], n, start, goals_t[g:g + 1], cost, c["step_size"], c["temperature"],
+                               c["sigma_start_sample"], c["sigma_goal_sample"], c["sigma_gp_sample"], mu, chunk=32)
+    rec = _population_parity("config 2: planar 256 x 64 x 128 fp32 (fused_planar_seg_kernel)", pl, make_band, n, {}, {},
+                             "fused_planar_seg", pchunk=32, workers=8, cost_quantum=1. / c["sigma_coll"] ** 2)
+    assert rec["grid_boundary_samples"] <= 1e-3 * rec["sample_costs_compared"]
+    assert rec["still_tracking_after_free_run"] >= 0.98 * 256
+
+
+def test_whole_population_parity_config5_share():
+    """BASELINE configs[4]'s per-GPU share: all 512 particles of shard 3 of 8 (4 goals x 1024 x 256 samples x 128 waypoints;
+    global particles 1536..2047, goal 1) -- 1 re-synchronised + 3 free-running iterations (each costs the host four
+    config-3 iterations)."""
+    from oracle import banded_equiv as B
+    c, n = SC.PANDA, 7
+    T, S, nppg, seed = 128, 256, 1024, 87
+    goals = torch.tensor([g + [0.] * n for g in [c["goal_q"], [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5],
+                                                 [0.9, -0.2, 0.4, -1.1, -0.3, 1.9, 0.8],
+                                                 [-0.8, 0.1, 0.6, -2.4, 0.4, 2.6, -0.2]]], dtype=torch.float64)
+    sph = torch.as_tensor(SC.panda_spheres(num=5))
+    start = torch.tensor(c["start_q"] + [0.] * n, dtype=torch.float64)
+    pl = hip_panda_planner(c, T, nppg, S, F32, seed=seed, goals=goals.tolist(), rank=3, world_size=8)
+    assert (pl.p0, pl.p1) == (1536, 2048)
+    g = pl.p0 // nppg
+    cost = B.panda_chunk_cost(c, T, S, goals[g:g + 1], "rbf")
+
+    def make_band(lo, hi, mu):
+        return B.BandedPlanner(hi - lo, S, T, c["dt"], n, start, goals[g:g + 1], cost, c["step_size"], c["temperature"],
+                               c["sigma_start_sample"], c["sigma_goal_sample"], c["sigma_gp_sample"], mu, chunk=2)
+    rec = _population_parity("config 5 share: shard 3 of 8 of Panda 4 goals x 1024 x 256 x 128 fp32 (fused launch)", pl,
+                             make_band, n, {"obstacle_spheres": sph.to(**F32)}, {"obstacle_spheres": sph}, "fused_step_kernel",
+                             sync_iters=1, free_iters=3, pchunk=16, workers=32)
+    assert rec["still_tracking_after_free_run"] >= 0.99 * 512
+
+
 # --------------------------------------------------------------------------- store-free iterations (round 5)
 def _store_free_twins(build, calls, obs, expect_kernel, expect_store_free=True):
     """The same planner twice: `a` lets the iterations inside optimize(opt_iters = K) skip their sample stores (all but the
