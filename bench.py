@@ -292,6 +292,9 @@ def other_configs(torch, dev, copy_gbs=None):
          dict(workload="panda", P_local=1024, S=128, T=64, dtype=f32, spheres=64), 40),
         ("config 5 share: Panda 4 goals, 512 of 4096 particles x 256 x 128, fp32 (shard 3 of 8)", "cfg5",
          dict(workload="panda", P_local=512, S=256, T=128, dtype=f32, goals=4, shard_of=(3, 8)), 60),
+        # north_star's fp64 clause (means within 1e-5) at configs[2]'s shape: the fp64 context runs sampler, generic sweep and
+        # update as three launches (parity: tests/test_gpu_planner.py::test_config3_shape_fp64_free_running_*)
+        ("config 3's shape in fp64 (Panda 1024 x 128 x 64)", "cfg3_f64", dict(workload="panda", P_local=1024, S=128, T=64, dtype=f64), 20),
     ]
     out = []
     for label, key, spec, steps in specs:

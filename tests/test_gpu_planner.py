@@ -676,6 +676,36 @@ def test_config5_share_free_running_ten_iterations_against_the_banded_oracle():
     assert rec["tracking_fraction_per_iteration"][0] == 1.0
 
 
+def test_config3_shape_fp64_free_running_against_the_dense_oracle():
+    """north_star's fp64 clause -- trajectory means within 1e-5 relative -- AT configs[2]'s shape (Panda 1024 x 128 x 64; rounds
+    1-4 measured it at config 1's 4 particles only): the fp64 context (sampler + generic sweep on the generated chain + update:
+    three launches) against the dense fp64 oracle on the restated fp64 noise stream, four particles, five free iterations."""
+    from oracle.native_noise import native_eps
+    c, n = SC.PANDA, 7
+    T, S, P, seed = 64, 128, 1024, 91
+    sph = torch.as_tensor(SC.panda_spheres(num=5))
+    pl = hip_panda_planner(c, T, P, S, F64, seed=seed)
+    sub = [0, 3, 512, 1023]
+    idx = torch.as_tensor(sub, device=DEV)
+    ora = SC.oracle_panda_planner(c, T, len(sub), S, seed=seed, eps_init=torch.zeros(len(sub), 1, T * 2 * n, dtype=torch.float64))
+    ora.particle_means.copy_(pl.particle_means[idx].cpu())
+    ora.prior.set_mean(ora.particle_means.view(len(sub), -1))
+    scale = float(ora.particle_means.abs().max())
+    worst = worst_cost = 0.0
+    for it in range(5):
+        eps = torch.from_numpy(native_eps(seed, pl._draw, sub, S, T, n, "float64")).double()
+        costs_o, _ = ora.step(eps=eps, obstacle_spheres=sph)
+        costs = pl.optimize(opt_iters=1, obstacle_spheres=sph.to(**F64))[4]
+        assert pl._engine.last_cost_kernel() == "cost_sweep_kernel<f64, generated chain>"
+        worst_cost = max(worst_cost, rel_err(costs[idx], costs_o))
+        worst = max(worst, float((pl.particle_means[idx].cpu() - ora.particle_means).abs().max()) / scale)
+    rec = {"particles": sub, "iterations": 5, "means_rel_err_max": worst, "cost_rel_err_max": worst_cost,
+           "kernel": "cost_sweep_kernel<f64, generated chain>", "tolerance": 1e-5}
+    print(f"\n[full-size parity, fp64] config 3 shape: {rec}")
+    _record_parity("config 3 shape in fp64: Panda 1024 x 128 x 64 (sampler + generic sweep + update)", rec)
+    assert worst < 1e-5 and worst_cost < 1e-7, rec
+
+
 def test_config2_free_running_ten_iterations_against_the_dense_oracle(golden):
     """BASELINE configs[1] at full size (planar 256 x 64 x 128, fp32, fused_planar_seg_kernel), two particles of every goal,
     ten free iterations against the dense fp64 oracle."""
