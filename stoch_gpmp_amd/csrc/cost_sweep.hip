@@ -267,14 +267,6 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     // S, T off the launch's grid of 8 rows x 16 waypoints: the instantiation with the masks (fused_step.inc: RAG)
 #define FUSED_LAUNCH(FT_, RAG_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, RAG_>), dim3((unsigned)blocks), dim3(256), (unsigned)dyn + SGPMP_FUSED_EXTRA_LDS, stream, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0u, a, F, fs)
     const bool rag = S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0;
-    // sixteen spheres or more (rbf, shapes on the grid): the exponent arguments of the sphere field on the matrix cores (fused_step.inc: SPHM)
-    if (ft == SGPMP_FIELD_RBF && !rag && F.has_sph && n_spheres >= 16 && !tg.no_sphere_mfma) {
-        hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, SGPMP_FIELD_RBF, false, true>), dim3((unsigned)blocks), dim3(256),
-                              (unsigned)dyn + SGPMP_FUSED_EXTRA_LDS, stream, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0u, a, F, fs);
-        if (picked) *picked = "fused_step_kernel";
-        *launched = true;
-        return hipGetLastError();
-    }
     if (ft == SGPMP_FIELD_RBF) { if (rag) FUSED_LAUNCH(SGPMP_FIELD_RBF, true); else FUSED_LAUNCH(SGPMP_FIELD_RBF, false); }
     else if (ft == SGPMP_FIELD_SDF) { if (rag) FUSED_LAUNCH(SGPMP_FIELD_SDF, true); else FUSED_LAUNCH(SGPMP_FIELD_SDF, false); }
     else { if (rag) FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, true); else FUSED_LAUNCH(SGPMP_FIELD_OCCUPANCY, false); }

@@ -118,7 +118,6 @@ struct SgpmpToggles {
     int no_dense_partials;    // SGPMP_NO_DENSE_PARTIALS    update_kernel re-reads all rows with weight even when the weights are spread (round 3)
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
     int planar_store_free;    // SGPMP_PLANAR_STORE_FREE    store-free steps (SGPMP_STEP_NO_SAMPLES) also for fused_planar_seg_kernel: measured SLOWER at config 2 (the launch saves 3.8 us, the update's regeneration costs 5.2: 42.4 k -> 40.0 k it/s, profiles/r05), hence opt-in
-    int no_sphere_mfma;       // SGPMP_NO_SPHERE_MFMA       sixteen spheres or more: the sphere field's exponent arguments on the vector ALU (rounds 1-4) instead of the matrix cores (fused_step.inc: SPHM)
     int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
     long long pipe_split;     // SGPMP_PIPE_SPLIT           first chain's share of the particles in 16ths (0 = default 8)
     long long k3_blocks;      // SGPMP_K3_BLOCKS            workgroup cap of the dual sweep (0: default)
