@@ -77,6 +77,11 @@ struct sgpmp_ctx {
     double isw_temperature;
     const char* last_cost_kernel; // name of the cost-sweep kernel the dispatcher picked last
     StepPipe pipe;                // two-chain execution of consecutive steps (sgpmp_pipeline_begin / _end)
+    // the update inside fused_planar_seg_kernel (store-free steps, S = 64): per-launch finished-particle counters and
+    // statistics accumulators ([0]: whole range / first half, [1]: second half of a two-chain step); zero between
+    // launches by construction (the launch's last particle resets them)
+    unsigned* d_done = nullptr;      // [2]
+    double* d_tail_acc = nullptr;    // [2][SGPMP_STAT_SHARDS][4]
     // per-goal mean statistics once per iteration (sgpmp_set_step_mode_stats): the update kernel leaves a snapshot of
     // the new means, a side stream reduces it per goal and all-reduces the sums -- nothing on the steps' own stream
     double* ms_buf = nullptr;        // caller's [G][M+1][2] buffer, or null: off
@@ -104,7 +109,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"k3_no_one", &SgpmpToggles::k3_no_one}, {"k3_no_lds_prefetch", &SgpmpToggles::k3_no_lds_prefetch},
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
-    {"comm_packet_event", &SgpmpToggles::comm_packet_event}, {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"planar_store_free", &SgpmpToggles::planar_store_free},
+    {"comm_packet_event", &SgpmpToggles::comm_packet_event}, {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"planar_store_free", &SgpmpToggles::planar_store_free}, {"no_planar_tail", &SgpmpToggles::no_planar_tail},
     {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
 };
 
@@ -190,6 +195,10 @@ extern "C" int sgpmp_create(const sgpmp_dims* dims, sgpmp_ctx** out) {
     const size_t P = (size_t)(dims->num_particles > 0 ? dims->num_particles : 1);
     HIPCHK(hipMalloc(&c->d_isw, P * (dims->traj_len + 1) * c->d * c->esz));
     HIPCHK(hipMalloc(&c->d_costs64, P * dims->num_samples * sizeof(double)));
+    HIPCHK(hipMalloc(&c->d_done, 2 * sizeof(unsigned)));
+    HIPCHK(hipMalloc(&c->d_tail_acc, 2 * SGPMP_STAT_SHARDS * 4 * sizeof(double)));
+    HIPCHK(hipMemset(c->d_done, 0, 2 * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->d_tail_acc, 0, 2 * SGPMP_STAT_SHARDS * 4 * sizeof(double)));
     *out = c;
     return SGPMP_OK;
 }
@@ -336,7 +345,7 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     free_prior(c->prior[0]);
     free_prior(c->prior[1]);
     hipFree(c->d_qc); hipFree(c->d_prog); hipFree(c->d_chain); hipFree(c->d_isw);
-    hipFree(c->d_costs64);
+    hipFree(c->d_costs64); hipFree(c->d_done); hipFree(c->d_tail_acc);
     hipFree(c->d_part); hipFree(c->d_nnz);
     if (c->ms_side) { hipStreamSynchronize(c->ms_side); hipStreamDestroy(c->ms_side); }
     for (int i = 0; i < 2; ++i) { hipFree(c->ms_snap[i]); if (c->ms_read[i]) hipEventDestroy(c->ms_read[i]); }
@@ -1057,13 +1066,21 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
         FusedDenseHost dh = dense;
         if (dh.part) dh.part += off * (size_t)((S + 7) / 8) * (size_t)(c->M + 4);
         if (dh.nnz) dh.nnz += off;
-        bool armed = false;
+        dh.tail_done = c->d_done + h; dh.tail_acc = c->d_tail_acc + (size_t)h * SGPMP_STAT_SHARDS * 4; dh.stats_out = slot;
+        dh.weights = wh; dh.grad = gh; dh.means_prev = mph; dh.step_size = step_size;
+        bool armed = false, tail_ran = false;
         RegenHost rgh;
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, mu, Ph,
                                  D.particle_offset + (int)off, S, X, spheres, n_spheres, isw, slot, cs, c64, sh, c->tg,
-                                 &c->last_cost_kernel, &launched, &dh, &armed, &rgh));
+                                 &c->last_cost_kernel, &launched, &dh, &armed, &rgh, &tail_ran));
         if (!launched) return fail(SGPMP_ESTATE, "sgpmp_step: a half of a pipelined step did not qualify for the fused launch");
         c->last_step_launches = 1;
+        if (tail_ran) {                                          // the launch updated its particles itself (fused_planar_seg.inc: seg_update)
+            isw_next[h] = true;
+            if (h == 0) c->store_free_steps += 1;
+            if (k4_done[h]) HIPCHK(hipEventRecord(k4_done[h], sh));
+            continue;
+        }
         for (int i = 0; i < c->h_prog.n_terms; ++i)
             if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) {
                 HIPCHK(launch_ee_goal(D.dtype, D.n_dof, D.traj_len, c->h_prog.terms[i], c->d_chain, X,
@@ -1186,7 +1203,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     c->last_step_launches = prepared ? 0 : 1;
     FusedDenseHost dense;                                        // what the launch and the update share per particle (row counts, partials)
     std::memset(&dense, 0, sizeof(dense));
-    bool partials = false;
+    bool partials = false, tail_ran = false;                     // tail_ran: the launch also updated its particles (fused_planar_seg.inc: seg_update)
     RegenHost regen;                                             // store-free step: how the update regenerates rows
     std::memset(&regen, 0, sizeof(regen));
     if (fused) {
@@ -1194,10 +1211,14 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         if ((rc = dense_buffers(c, &dense, temperature, c->h_prog.needs_fk != 0)) != SGPMP_OK) return rc;
         // (per-goal mean statistics and the profiler read nothing of the samples either: they do not stand in the way)
         dense.nostore = (flags & SGPMP_STEP_NO_SAMPLES) ? 1 : 0;
+        if (!c->ms_buf) {                                        // (the per-step mean statistics want update_kernel's snapshot of the new means)
+            dense.tail_done = c->d_done; dense.tail_acc = c->d_tail_acc; dense.stats_out = acc_stats;
+            dense.weights = weights; dense.grad = grad; dense.means_prev = means_prev; dense.step_size = step_size;
+        }
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, means, P,
                                  D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, acc_stats, costs,
-                                 c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, &dense, &partials, &regen));
-        if (fused) { c->last_step_launches += 1; if (partials) c->dense_armed_steps += 1; if (regen.recipe != 0) c->store_free_steps += 1; }
+                                 c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, &dense, &partials, &regen, &tail_ran));
+        if (fused) { c->last_step_launches += 1; if (partials) c->dense_armed_steps += 1; if (regen.recipe != 0 || tail_ran) c->store_free_steps += 1; }
         for (int i = 0; fused && i < c->h_prog.n_terms; ++i)
             if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) {
                 HIPCHK(launch_ee_goal(D.dtype, D.n_dof, D.traj_len, c->h_prog.terms[i], c->d_chain, samples,
@@ -1217,8 +1238,10 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     if (se) HIPCHK(hipEventRecord(se->ev[3], st));
     // (the update also prepares the NEXT step's importance-sampling weights -- unless, as a kernel of its own, the new
     // means do not fit its LDS beside the weights: launch_update decides)
-    bool isw_written = false;
-    {
+    bool isw_written = tail_ran;
+    if (tail_ran) {
+        if (k4_done) HIPCHK(hipEventRecord(k4_done, st));
+    } else {
         // per-goal mean statistics (sgpmp_set_step_mode_stats): the update kernel also leaves a snapshot of the new
         // means for the side stream; a snapshot is reused two steps later -- by then its reduction has long finished
         // (host-side query; the stream wait is the never-taken fallback)
@@ -1239,7 +1262,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         }
     }
     c->isw_ready = isw_written; c->isw_means = means; c->isw_temperature = temperature;
-    if (se) { HIPCHK(hipEventRecord(se->ev[4], st)); se->has[3] = true; }
+    if (se) { HIPCHK(hipEventRecord(se->ev[4], st)); se->has[3] = !tail_ran; }
     // multi-GPU: sum the statistics over all ranks on the side stream (never gates the next step)
     if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats, false));
     return SGPMP_OK;

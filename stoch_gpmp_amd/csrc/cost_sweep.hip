@@ -171,8 +171,9 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                              int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
                              const void* isw, double* zero_stats, void* costs, double* costs64,
                              hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched,
-                             const FusedDenseHost* dense, bool* partials_armed, RegenHost* regen) {
+                             const FusedDenseHost* dense, bool* partials_armed, RegenHost* regen, bool* tail_ran) {
     *launched = false;
+    if (tail_ran) *tail_ran = false;
     if (partials_armed) *partials_armed = false;
     if (regen) std::memset(regen, 0, sizeof(*regen));
     using CCp = ChainCode_panda;
@@ -197,6 +198,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     fs.zero_stats = zero_stats;
     fs.part = nullptr; fs.nnz_prev = nullptr; fs.nnz_threshold = 0u; fs.inv_temperature = 0.f;
     fs.nostore = 0; fs.store_threshold = 0u;
+    std::memset(&fs.tail, 0, sizeof(fs.tail));
     if (dense && dense->nnz) fs.nnz_prev = dense->nnz;
     // softmax partials for the dense-weight regime of the update: chain-code launch whose costs are complete inside it
     if (kind == 1 && dense && dense->part && dense->nnz && h_prog.n_ee == 0 && !tg.no_dense_partials && (T * 2 * n) % 4 == 0) {
@@ -230,8 +232,25 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
             const int L = planar_seg_len(n, T, S, tg), G = L ? T / L : 0;
             const long long wgs = batch / 64;
             if (L && wgs <= (1LL << 20)) {
-                const size_t lds = (size_t)G * 64 * (16 * n + 8) + (size_t)G * 64 * 20 * sizeof(float) + (size_t)G * 16;
+                size_t lds = (size_t)G * 64 * (16 * n + 8) + (size_t)G * 64 * 20 * sizeof(float) + (size_t)G * 16;
                 fs.gpp = S / 64; fs.gpp_shift = log2_exact(fs.gpp);
+                // Store-free step of a problem whose particles have exactly one workgroup's 64 samples: the UPDATE runs inside the
+                // launch (seg_update) -- no sample store, no update_kernel, no regeneration: one launch per iteration
+                const bool upd = dense && dense->nostore && dense->tail_done && tail_ran && S == 64 && prior.isotropic && !tg.no_planar_tail &&
+                                 (size_t)T * 2 * n * sizeof(float) + lds <= 160 * 1024;
+                if (upd) {
+                    SegTail& t = fs.tail;
+                    t.done = dense->tail_done; t.acc = dense->tail_acc; t.stats_out = dense->stats_out;
+                    t.means = (float*)const_cast<void*>(means); t.weights = (float*)dense->weights; t.grad = (float*)dense->grad;
+                    t.means_prev = (float*)dense->means_prev; t.isw_next = (float*)const_cast<void*>(isw); t.nnz_out = dense->nnz;
+                    t.Qinv = prior.Qinv; t.ks = prior.ks; t.kg = prior.kg; t.dt = prior.dt;
+                    t.temperature = dense->temperature; t.step_size = dense->step_size; t.P = P;
+                    fs.nostore = 1; fs.store_threshold = 0xffffffffu;
+                    fs.zero_stats = nullptr;                      // (the launch's last particle writes the statistics)
+                    lds += (size_t)T * 2 * n * sizeof(float);
+                    if (regen) regen->recipe = 0;                 // (nothing left for update_kernel to regenerate: there is no update_kernel)
+                    *tail_ran = true;
+                }
                 const float* tab = prior.slabpre + (size_t)(L == 8 ? 3 : 4) * T * 4;
 #define SEG_LAUNCH(NN, LL) hipLaunchKernelGGL((fused_planar_seg_kernel<NN, LL>), dim3((unsigned)wgs), dim3(64 * G), (unsigned)lds, stream, a, F, fs, tab)
                 if (n == 2) { if (L == 8) SEG_LAUNCH(2, 8); else SEG_LAUNCH(2, 16); }

@@ -117,6 +117,7 @@ struct SgpmpToggles {
     int gpmp_cholesky;        // SGPMP_GPMP_CHOLESKY        GPMP solve by round 3's block Cholesky through LDS instead of the register-resident block-Thomas kernel
     int no_dense_partials;    // SGPMP_NO_DENSE_PARTIALS    update_kernel re-reads all rows with weight even when the weights are spread (round 3)
     int comm_packet_event;    // SGPMP_COMM_PACKET_EVENT    statistics all-reduce chained by the update kernel's own stop event (hipExtLaunchKernelGGL) instead of a plain event record behind it: +16 us instead of +9 us per iteration at one rank on this round's boxes (round 2's boxes had it the other way round)
+    int no_planar_tail;       // SGPMP_NO_PLANAR_TAIL       store-free steps of S = 64 planar problems: update_kernel (+ regeneration, if planar_store_free) instead of the update inside fused_planar_seg_kernel
     int planar_store_free;    // SGPMP_PLANAR_STORE_FREE    store-free steps (SGPMP_STEP_NO_SAMPLES) also for fused_planar_seg_kernel: measured SLOWER at config 2 (the launch saves 3.8 us, the update's regeneration costs 5.2: 42.4 k -> 40.0 k it/s, profiles/r05), hence opt-in
     int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
     long long pipe_split;     // SGPMP_PIPE_SPLIT           first chain's share of the particles in 16ths (0 = default 8)
@@ -188,6 +189,13 @@ struct FusedDenseHost {
     double temperature;
     int nostore;                  // the caller does not need this step's samples (SGPMP_STEP_NO_SAMPLES) and the update can regenerate rows
     unsigned store_threshold;     // ... rows are then stored for particles with nnz above it only
+    // the update INSIDE fused_planar_seg_kernel (store-free steps, S = 64; fused_planar_seg.inc: seg_update) -- what update_kernel
+    // would have been given; tail_done == null: not offered (per-step mean statistics, ...)
+    unsigned* tail_done;          // finished-particle counter of this launch (zero between launches)
+    double* tail_acc;             // [SGPMP_STAT_SHARDS][4] statistics accumulators (zero between launches)
+    double* stats_out;            // the step's statistics buffer or null
+    void* weights; void* grad; void* means_prev;   // K4's optional outputs (context dtype)
+    double step_size;
 };
 // How update_kernel regenerates the rows a store-free step did not write (update_common.h: RegenArgs)
 struct RegenHost {
@@ -206,7 +214,8 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                              int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
                              const void* isw, double* zero_stats, void* costs, double* costs64,
                              hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched,
-                             const FusedDenseHost* dense = nullptr, bool* partials_armed = nullptr, RegenHost* regen = nullptr);
+                             const FusedDenseHost* dense = nullptr, bool* partials_armed = nullptr, RegenHost* regen = nullptr,
+                             bool* tail_ran = nullptr);   // *tail_ran: the launch also updated its particles (no update_kernel behind it)
 // the recipe update_kernel would need to regenerate this step's rows (0: the step's launch cannot run store-free)
 int fused_step_regen_recipe(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
                             int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg, int* seg_len);

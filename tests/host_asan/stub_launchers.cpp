@@ -71,9 +71,10 @@ bool fused_step_eligible(int dtype, int, int T, const PriorDev&, const CostProgr
 hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& pr, const CostProgram& prog, const ChainDev& ch, uint64_t, uint64_t, const void* means,
                              int P, int off, int S, void* samples, const void* spheres, int ns, const void* isw, double* zero_stats, void* costs,
                              double* c64, hipStream_t, const SgpmpToggles& tg, const char** picked, bool* launched, const FusedDenseHost* dense,
-                             bool* armed, RegenHost* regen) {
+                             bool* armed, RegenHost* regen, bool* tail_ran) {
     *launched = fused_step_eligible(dtype, n, T, pr, prog, ch, P, off, S, ns, tg) && samples && isw;
     if (armed) *armed = false;
+    if (tail_ran) *tail_ran = false;
     if (regen) std::memset(regen, 0, sizeof(*regen));
     if (!*launched) return hipSuccess;
     const size_t M = (size_t)T * 2 * n;
@@ -86,6 +87,15 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& pr, const 
     if (dense && dense->part && dense->nnz) {
         wr(dense->part, (size_t)P * ((S + 7) / 8) * (M + 4) * 4);
         if (armed) *armed = true;
+    }
+    // STUB_TAIL=1: as if the launch updated its particles itself (fused_planar_seg.inc: seg_update) -- touches what update_kernel would
+    if (env1("STUB_TAIL") && nostore && dense->tail_done && tail_ran) {
+        regen->recipe = 0;
+        rd(dense->tail_done, 4); wr(dense->tail_done, 4); rd(dense->tail_acc, sizeof(double) * SGPMP_STAT_SHARDS * 4);
+        wr(dense->stats_out, sizeof(double) * SGPMP_STAT_SHARDS * 4);
+        wr(const_cast<void*>(means), (size_t)P * M * 4); wr(dense->weights, (size_t)P * S * 4); wr(dense->grad, (size_t)P * M * 4);
+        wr(dense->means_prev, (size_t)P * M * 4); wr(const_cast<void*>(isw), (size_t)P * (T + 1) * 2 * n * 4); wr(dense->nnz, (size_t)P * 4, 1);
+        *tail_ran = true;
     }
     if (picked) *picked = "stub_fused";
     return hipSuccess;
