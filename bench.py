@@ -263,7 +263,8 @@ def store_free_leg(torch, spec_kwargs, obs_builder, config_key, steps, N_elems, 
     k, src = profiled(config_key + "_store_free", kernel)
     launch_ms = kms["cost_sweep"]
     out = {"mode": "optimize(opt_iters=K): iterations 1 .. K-1 without the sample stores (the default), the K-th storing",
-           "bound": "valu" if ran else None, "kernel": kernel, "iterations_per_s": steps / el, "ms_per_step": 1e3 * el / steps,
+           "bound": ("valu" if kernel.startswith("fused_step") else "latency: one workgroup per CU in lockstep, three barriers, the update's dependent chain")
+           if ran else None, "kernel": kernel + (" with the update inside the launch" if ran and pl._engine.last_step_launches() == 2 and kernel.startswith("fused_planar_seg") else ""), "iterations_per_s": steps / el, "ms_per_step": 1e3 * el / steps,
            "ms_per_step_of_each_pass": [1e3 * e / steps for e in els], "steps": steps,
            "vs_storing": (storing_ms / (1e3 * el / steps)) if storing_ms else None,
            "launch_ms": launch_ms, "update_ms": kms["update"],
@@ -316,7 +317,7 @@ def other_configs(torch, dev, copy_gbs=None):
                                         step_ms=1e3 * el / steps, step_mode="optimize(opt_iters=K)",
                                         field=spec.get("field", "rbf") if spec["workload"] == "panda" else "occupancy grid")
         sf = None
-        if kernel == "fused_step_kernel":
+        if kernel == "fused_step_kernel" or (kernel == "fused_planar_seg_kernel" and spec["S"] == 64):
             sf = store_free_leg(torch, spec, lambda **kw: build_planner(torch, dev=dev, **kw), key, steps,
                                 spec["P_local"] * spec["S"] * spec["T"] * pl.d_state_opt, w, spec["P_local"] * spec["S"] * 8,
                                 1e3 * el / steps, dev)

@@ -1093,23 +1093,46 @@ def test_store_free_iterations_equal_storing_iterations_bitwise_panda(kind):
 
 @pytest.mark.parametrize("nppg,G,S,T,n", [(64, 4, 64, 128, 2), (3, 2, 64, 64, 2), (5, 1, 64, 256, 2), (2, 2, 192, 16, 2), (3, 1, 64, 96, 3)])
 def test_store_free_iterations_equal_storing_iterations_bitwise_planar(golden, nppg, G, S, T, n):
-    """The same at BASELINE configs[1] (256 x 64 x 128: fused_planar_seg_kernel, whose rows update_kernel regenerates segment by
-    segment -- zero-start recurrences, the chain over the segments' end states, the fix-up: rng.h seg_chain / seg_fixup) and at
-    the launch's other shapes: segments of 16 waypoints (T = 256), several 64-sample blocks per particle, n = 3."""
+    """The same at BASELINE configs[1] (256 x 64 x 128: fused_planar_seg_kernel) and at the launch's other shapes: segments of
+    16 waypoints (T = 256), several 64-sample blocks per particle, n = 3.  Two store-free forms:
+      * S = 64 (a particle's samples are ONE workgroup's): the update runs INSIDE the launch (seg_update) -- the default: one
+        launch per iteration, nothing stored, nothing regenerated;
+      * any S (opt-in `planar_store_free`, measured slower): update_kernel regenerates its rows segment by segment -- zero-start
+        recurrences, the chain over the segments' end states, the fix-up (rng.h seg_chain / seg_fixup)."""
     goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]][:G]
     c = SC.PLANAR
     if n == 3:
         c = dict(SC.PLANAR, n_dof=3, start=[-9., -9., 0.5, 0., 0., 0.])
         goals = [g[:2] + [0.3 * (i + 1), 0., 0., 0.] for i, g in enumerate(goals)]
     om = planar_map(golden, F32)
-    def build(**kw):
+
+    def regen(**kw):
         pl = hip_planar_planner(c, T, goals, nppg, S, om, F32, seed=67, **kw)
         pl._engine.set_option("planar_store_free", 1)    # (opt-in: measured slower than storing at config 2, DESIGN.md 4)
+        pl._engine.set_option("no_planar_tail", 1)
         return pl
-    _store_free_twins(build, (7, 1, 4), {}, "fused_planar_seg_kernel")
-    # the default: this launch stores every iteration
-    _store_free_twins(lambda **kw: hip_planar_planner(c, T, goals, nppg, S, om, F32, seed=67, **kw), (3,), {},
-                      "fused_planar_seg_kernel", expect_store_free=False)
+    _store_free_twins(regen, (7, 1, 4), {}, "fused_planar_seg_kernel")
+    # the default: S = 64 -> the update inside the launch; else this launch stores every iteration
+    a, _ = _store_free_twins(lambda **kw: hip_planar_planner(c, T, goals, nppg, S, om, F32, seed=67, **kw), (5, 1, 3), {},
+                             "fused_planar_seg_kernel", expect_store_free=(S == 64))
+    if S == 64:
+        a.optimize(opt_iters=3)
+        assert a._engine.last_step_launches() == 2           # (the call's last iteration: launch + update_kernel)
+        a.step(_samples_unread=True)
+        assert a._engine.last_step_launches() == 1           # a store-free step: ONE launch
+
+
+def test_store_free_planar_update_inside_the_launch_with_soft_weights(golden):
+    """seg_update with many samples carrying weight (a small workspace at temperature 20, the soft fixture's hyper-parameters):
+    the weighted mean over the rows in ascending order, row by row through the wave's LDS block -- bit-identical to update_kernel
+    -- and the per-particle row counts it leaves are update_kernel's."""
+    soft = dict(SC.PLANAR, start=[-2.9, -2.9, 0., 0.], dt=0.5, cost_sigma_start=0.5, cost_sigma_gp=8., sigma_coll=0.4,
+                sigma_goal_prior=2., sigma_start_sample=2., sigma_goal_sample=2., sigma_gp_sample=6.)
+    goals = [[2.9, 2.6, 0., 0.], [2.9, -1.3, 0., 0.], [-1.3, 2.9, 0., 0.]]
+    om = planar_map(golden, F32)
+    build = lambda **kw: hip_planar_planner(soft, 64, goals, 7, 64, om, F32, seed=69, temperature=20., **kw)   # noqa: E731
+    a, b = _store_free_twins(build, (6, 1, 4), {}, "fused_planar_seg_kernel")
+    assert int(a._engine.row_counts().max()) > 8 and (a._engine.row_counts() == b._engine.row_counts()).all()
 
 
 def test_store_free_permission_is_ignored_where_the_step_has_no_store_free_form(golden):
