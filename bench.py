@@ -389,13 +389,6 @@ def cpu_baseline(args, torch, S, T, P_full):
         if time.perf_counter() - leg0 > 8.0:            # keep the whole baseline leg bounded
             break
     dt, threads = best
-    # all host cores (one iteration, no warm-up beyond the runs above: it is the slow point)
-    all_cores = None
-    if cores not in by_threads and time.perf_counter() - leg0 < 10.0:
-        torch.set_num_threads(cores)
-        dta = timed(ora, 1, warm=False)
-        all_cores = {"threads": cores, "it_per_s_at_sample": 1.0 / dta, "value_extrapolated_per_particle": (1.0 / dta) * Pc / P_full}
-        by_threads[cores] = 1.0 / dta
     # measured points at 2 x and 4 x the particles (best thread count) while the leg stays inside ~25 s: the value is
     # extrapolated from the TWO LARGEST measured P (time is affine in P: a fixed part + a per-particle part), not from the
     # smallest sample alone (round-4 verdict: the P = 8 point lay 11 % off the line through P = 4 and the origin)
@@ -414,6 +407,15 @@ def cpu_baseline(args, torch, S, T, P_full):
             del ora_k
         except Exception:                                   # (memory) keep what was measured
             break
+    # all host cores (one iteration, no warm-up beyond the runs above: it is the slow point)
+    all_cores = None
+    # (LAST: at 256 threads one iteration of the dense algorithm takes ~15 s, which must not eat the budget of the measured points)
+    if cores not in by_threads and time.perf_counter() - leg0 < 30.0:
+        torch.set_num_threads(cores)
+        dta = timed(ora, 1, warm=False)
+        torch.set_num_threads(threads)
+        all_cores = {"threads": cores, "it_per_s_at_sample": 1.0 / dta, "value_extrapolated_per_particle": (1.0 / dta) * Pc / P_full}
+        by_threads[cores] = 1.0 / dta
     if len(points) >= 2:
         (p1, t1), (p2, t2) = [(q["particles"], q["s_per_it"]) for q in points[-2:]]
         t_full = t2 + (t2 - t1) / (p2 - p1) * (P_full - p2)
