@@ -252,7 +252,8 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                     *tail_ran = true;
                 }
                 const float* tab = prior.slabpre + (size_t)(L == 8 ? 3 : 4) * T * 4;
-#define SEG_LAUNCH(NN, LL) hipLaunchKernelGGL((fused_planar_seg_kernel<NN, LL>), dim3((unsigned)wgs), dim3(64 * G), (unsigned)lds, stream, a, F, fs, tab)
+#define SEG_LAUNCH(NN, LL) do { if (upd) hipLaunchKernelGGL((fused_planar_seg_kernel<NN, LL, true>), dim3((unsigned)wgs), dim3(64 * G), (unsigned)lds, stream, a, F, fs, tab); \
+                                 else hipLaunchKernelGGL((fused_planar_seg_kernel<NN, LL, false>), dim3((unsigned)wgs), dim3(64 * G), (unsigned)lds, stream, a, F, fs, tab); } while (0)
                 if (n == 2) { if (L == 8) SEG_LAUNCH(2, 8); else SEG_LAUNCH(2, 16); }
                 else SEG_LAUNCH(3, 8);
 #undef SEG_LAUNCH
