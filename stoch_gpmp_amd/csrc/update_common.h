@@ -201,9 +201,9 @@ static inline size_t regen_lds_bytes(int recipe, int T, int n, int R) {
 
 // The update of ONE particle by one 256-thread workgroup -- update_kernel's body.  `c`: the particle's S costs, `X`: its S
 // sample rows, `x_pitch` elements apart (global [S][M]), `lds_raw`: S * 12 (+ 16-byte round-up + M elements when nx.out)
-// bytes of workgroup scratch (+ regen_lds_bytes behind them when `rg`).  `stats` are ACCUMULATED into by atomics (shard p & 63).
+// bytes of workgroup scratch (+ regen_lds_bytes behind them when `regen`).  `stats` are ACCUMULATED into by atomics (shard p & 63).
 // VW = elements per thread and load (4 when M % 4 == 0, else 2; M = T * 2n is always even).
-// rg != null: the particle's rows are NOT in memory (store-free step) -- the rows that carry weight are regenerated.
+// regen: the particle's rows are NOT in memory (store-free step) -- the rows that carry weight are regenerated (rg says how).
 #define SGPMP_UPD_THREADS 256
 template <typename real, typename cost_t, int VW>
 __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_t* c, const real* X, size_t x_pitch,
@@ -212,7 +212,9 @@ __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_
                                                 double* __restrict__ stats, const IswNext<real>& nx, real* __restrict__ means_copy,
                                                 unsigned char* lds_raw, const real* mu_rd = nullptr,
                                                 const float* __restrict__ partials = nullptr, int gpp = 0, unsigned* __restrict__ nnz_out = nullptr,
-                                                const RegenArgs* rg = nullptr, unsigned char* regen_lds = nullptr) {
+                                                const RegenArgs& rg = RegenArgs{}, bool regen = false, unsigned char* regen_lds = nullptr) {
+    // (rg by reference and a separate flag: a POINTER to the kernel-argument struct made every thread copy the struct to scratch
+    // -- 72 bytes of private segment, 16 KB of scratch stores per workgroup: +2.6 us on update_kernel until it was found)
     typedef real vec __attribute__((ext_vector_type(VW)));
     double* w = reinterpret_cast<double*>(lds_raw);                  // [S] weights
     int* idx = reinterpret_cast<int*>(lds_raw + (size_t)S * 8);      // [S] samples with weight != 0
@@ -337,19 +339,19 @@ __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_
     };
     bool regenerated = false;
     if constexpr (sizeof(real) == 4) {
-        if (rg != nullptr && !use_part) {
+        if (regen && !use_part) {
             regenerated = true;
             // Store-free step: rounds of R rows with weight -- regenerated into LDS as perturbations y, x = mu + y formed as the
             // launch forms it (one fp32 add), then the row-gather's arithmetic in the row-gather's order (ascending sample index,
             // one fma per row): the same sums, bit for bit.  One round is the rule (one-hot weights: one row).
-            const int Tn = M / (2 * rg->N), R = rg->R;
+            const int Tn = M / (2 * rg.N), R = rg.R;
             float* ybuf = reinterpret_cast<float*>(regen_lds);
             float* tab = ybuf + (size_t)R * M;
             float* zl = tab + (size_t)Tn * 12;
-            double* accl = reinterpret_cast<double*>(zl + (rg->recipe == 2 ? (size_t)R * 16 * rg->N * 2 : 0));
+            double* accl = reinterpret_cast<double*>(zl + (rg.recipe == 2 ? (size_t)R * 16 * rg.N * 2 : 0));
             for (int b0 = 0; b0 < nnz; b0 += R) {
                 const int nb = nnz - b0 < R ? nnz - b0 : R;
-                regen_rows(*rg, Tn, (unsigned)(rg->mode_offset + p), idx + b0, nb, ybuf, tab, zl, tid, nthr, b0 == 0);
+                regen_rows(rg, Tn, (unsigned)(rg.mode_offset + p), idx + b0, nb, ybuf, tab, zl, tid, nthr, b0 == 0);
                 for (int m = tid < nthr ? tid * VW : M; m < M; m += nthr * VW) {
                     const vec mu_m = *reinterpret_cast<const vec*>((mu_rd ? mu_rd : mu) + m);
                     double acc[VW];
@@ -455,6 +457,6 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
     const bool regen = rg.recipe != 0 && !(prev > rg.store_threshold);
     update_particle<real, cost_t, VW>(p, M, S, costs + (size_t)p * S, samples + (size_t)p * S * M, (size_t)M, means, temperature,
                                       step_size, weights, grad, means_prev, stats, nx, means_copy, lds_raw, nullptr, part_p, gpp,
-                                      nnz ? nnz + p : nullptr, regen ? &rg : nullptr, lds_raw + regen_lds_offset);
+                                      nnz ? nnz + p : nullptr, rg, regen, lds_raw + regen_lds_offset);
 }
 

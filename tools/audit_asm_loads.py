@@ -18,11 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = r"fused_step_kernel|cost_sweep_chunked_kernel|fused_planar_kernel"
 
 
-def listing():
-    if len(sys.argv) > 1:
+def listing(name="cost_sweep"):
+    if len(sys.argv) > 1 and name == "cost_sweep":
         return open(sys.argv[1]).read()
-    out = os.path.join(tempfile.mkdtemp(), "cost_sweep.s")
-    src = os.path.join(ROOT, "stoch_gpmp_amd", "csrc", "cost_sweep.hip")
+    out = os.path.join(tempfile.mkdtemp(), name + ".s")
+    src = os.path.join(ROOT, "stoch_gpmp_amd", "csrc", name + ".hip")
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S",
                     "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
     return open(out).read()
@@ -110,7 +110,11 @@ def main():
     # waits behind the launch's stores).  The kernel descriptors say it: .amdhsa_private_segment_fixed_size must be 0, and no
     # scratch_* instruction may appear in the body.
     spilled = 0
-    step_kernels = KERNELS + r"|fused_planar_seg_kernel"
+    step_kernels = KERNELS + r"|fused_planar_seg_kernel|update_kernel|is_weights_kernel"
+    if len(sys.argv) <= 1:
+        # update.hip too: round 5's update_kernel once carried 72 bytes of private segment -- not a spilled register but a
+        # kernel-argument struct whose ADDRESS was taken (every thread copied it to scratch: 16 KB of stores per workgroup, +2.6 us)
+        text = text + "\n" + listing("update")
     for m in re.finditer(r"\.amdhsa_kernel (_Z\w*(?:%s)\w*)\n(.*?)\.end_amdhsa_kernel" % step_kernels, text, re.S):
         size = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
         if size:
