@@ -132,7 +132,9 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * k3_no_one, k3_no_lds_prefetch, no_small_sampler, no_fused_step, no_chunked_sweep, no_step_pipeline, comm_packet_event,
  * gpmp_cholesky (GPMP solve by round 3's LDS block-Cholesky kernel), no_dense_partials (dense-weight regime: update_kernel re-reads every row with weight, as in round 3),
  * no_planar_seg (planar one-launch step through the LDS tile, fused_planar_kernel, even where the lane-per-sample launch applies),
- * planar_store_free (store-free steps also for the lane-per-sample planar launch: bit-identical, measured slower at BASELINE configs[1]),
+ * planar_store_free (store-free planar steps of ANY sample count by regenerating rows in update_kernel: bit-identical, measured slower
+ * than storing at BASELINE configs[1]; problems with 64 samples per particle run store-free by default, with the update inside the launch),
+ * no_planar_tail (those steps with update_kernel behind the launch instead),
  * pipe_split (1..15) and k3_blocks (count).  (The launches that measured slower -- tail_update, small_step, planar_slabs,
  * wave_groups, fused_pipe -- were removed in round 5; DESIGN.md 8 keeps their numbers and the commit that last held them.)
  * No reference counterpart. */
@@ -283,7 +285,9 @@ int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, in
                                       configs[2] -- and update_kernel REGENERATES the rows that carry weight from their noise
                                       keys (one row per particle with the reference's one-hot weights), bit for bit what the
                                       launch would have stored: means, costs, weights, gradient come out identical to a
-                                      storing step's.  Rows of particles whose previous update spread its weight over more
+                                      storing step's.  (fused_planar_seg_kernel with 64 samples per particle: the workgroup
+                                      holds all samples of its particle in registers and runs the update itself -- one
+                                      launch per iteration, bit-identical to update_kernel.)  Rows of particles whose previous update spread its weight over more
                                       than 4 samples are still written (`samples` must be a valid buffer).  A permission,
                                       not a demand: steps on other paths store as always.  After such a step `samples`
                                       holds rows of earlier steps. */
@@ -302,7 +306,8 @@ int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, in
 int sgpmp_pipeline_begin(sgpmp_ctx* ctx, void* stream);
 int sgpmp_pipeline_end(sgpmp_ctx* ctx, void* stream);
 /* Kernels the last sgpmp_step enqueued for its particle range (per chain when it ran as two): 2 = fused sampler + sweep,
- * then update_kernel (the default); 3-4 = separate kernels. */
+ * then update_kernel (the default); 3-4 = separate kernels; 1 = a store-free planar step whose launch also updated its
+ * particles (fused_planar_seg.inc: seg_update). */
 int sgpmp_last_step_launches(sgpmp_ctx* ctx);
 /* how many steps of this context ran as two chains so far (tests and bench.py report it) */
 long long sgpmp_pipeline_split_steps(sgpmp_ctx* ctx);
