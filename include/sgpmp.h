@@ -135,6 +135,9 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * planar_store_free (store-free planar steps of ANY sample count by regenerating rows in update_kernel: bit-identical, measured slower
  * than storing at BASELINE configs[1]; problems with 64 samples per particle run store-free by default, with the update inside the launch),
  * no_planar_tail (those steps with update_kernel behind the launch instead),
+ * store_free_min_bytes (a store-free step that regenerates rows in update_kernel is taken when one waypoint of all the step's
+ * samples -- P S 2n floats -- has at least this many bytes; 0: the measured break-even of 2.8 MB, below which it ran 4 .. 20 %
+ * slower than a storing step; 1: always),
  * pipe_split (1..15) and k3_blocks (count).  (The launches that measured slower -- tail_update, small_step, planar_slabs,
  * wave_groups, fused_pipe -- were removed in round 5; DESIGN.md 8 keeps their numbers and the commit that last held them.)
  * No reference counterpart. */
@@ -289,8 +292,10 @@ int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, in
                                       holds all samples of its particle in registers and runs the update itself -- one
                                       launch per iteration, bit-identical to update_kernel.)  Rows of particles whose previous update spread its weight over more
                                       than 4 samples are still written (`samples` must be a valid buffer).  A permission,
-                                      not a demand: steps on other paths store as always.  After such a step `samples`
-                                      holds rows of earlier steps. */
+                                      not a demand: steps on other paths store as always, and so do steps too small for the
+                                      regeneration to pay (option store_free_min_bytes: below 2.8 MB of samples per waypoint a
+                                      regenerating step measured 4 .. 20 % slower than a storing one).  After such a step
+                                      `samples` holds rows of earlier steps. */
 
 /* The loop of planner.py:289-299 itself (`for opt_step in range(opt_iters)`), when its iterations follow each
  * other without the caller looking at the buffers in between: bracket the sgpmp_step calls of one optimize() with

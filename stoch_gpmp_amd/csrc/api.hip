@@ -123,6 +123,7 @@ static void toggles_from_env(SgpmpToggles& tg) {
     }
     if (const char* e = getenv("SGPMP_K3_BLOCKS")) tg.k3_blocks = atoll(e);
     if (const char* e = getenv("SGPMP_PIPE_SPLIT")) tg.pipe_split = atoll(e);
+    if (const char* e = getenv("SGPMP_STORE_FREE_MIN_BYTES")) tg.store_free_min_bytes = atoll(e);
 }
 
 extern "C" int sgpmp_abi_version(void) { return SGPMP_ABI_VERSION; }
@@ -207,6 +208,7 @@ extern "C" int sgpmp_set_option(sgpmp_ctx* c, const char* name, long long value)
     if (!c || !name) return fail(SGPMP_EINVAL, "sgpmp_set_option: null argument");
     if (std::strcmp(name, "k3_blocks") == 0) { c->tg.k3_blocks = value; return SGPMP_OK; }
     if (std::strcmp(name, "pipe_split") == 0) { c->tg.pipe_split = value; return SGPMP_OK; }
+    if (std::strcmp(name, "store_free_min_bytes") == 0) { c->tg.store_free_min_bytes = value; return SGPMP_OK; }
     for (const auto& t : kToggleNames)
         if (std::strcmp(name, t.name) == 0) { c->tg.*(t.flag) = value != 0; return SGPMP_OK; }
     return fail(SGPMP_EINVAL, std::string("sgpmp_set_option: unknown option ") + name);
@@ -911,6 +913,7 @@ static int dense_buffers(sgpmp_ctx* c, FusedDenseHost* d, double temperature, bo
     // rows of a store-free step: kept for particles that wanted more rows than update_kernel regenerates in one round --
     // and for every particle that gets partials (they re-read the rows): never above the partials' threshold
     d->store_threshold = d->threshold < 4u ? d->threshold : 4u;
+    d->particles_total = D.num_particles;
     if (D.dtype != SGPMP_F32 || D.num_particles < 1) return SGPMP_OK;
     if (!c->d_nnz) {
         const size_t P = (size_t)D.num_particles;

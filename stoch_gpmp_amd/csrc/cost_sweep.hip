@@ -210,7 +210,14 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     if (dense && dense->nostore && dense->nnz && regen) {
         int L = 0;
         const int recipe = fused_step_regen_recipe(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg, &L);
-        if (recipe != 0 && update_regen_rows(dtype, n, T, S, recipe) > 0) {
+        // ... and regenerating pays: update_kernel's regeneration is a dependent chain of ~6.5 us per particle (T = 64) that a small
+        // step cannot hide, while what the launch saves grows with the bytes it does not write.  Measured break-even on MI355X
+        // (tools/store_free_sizes.py, profiles/r05/store_free_sizes.txt: Panda, S = 64 .. 512, T = 32 and 64, P = 16 .. 2048):
+        // 176 MB of samples per step at T = 64, ~88 MB at T = 32 -- i.e. 2.75 MB per waypoint; below it a store-free step ran
+        // 4 .. 20 % SLOWER than a storing one, so the step stores (same results either way: the choice is a function of the shape).
+        const long long waypoint_bytes = (long long)dense->particles_total * S * 2 * n * (long long)sizeof(float);
+        const long long min_bytes = tg.store_free_min_bytes > 0 ? tg.store_free_min_bytes : SGPMP_STORE_FREE_BREAK_EVEN;
+        if (recipe != 0 && waypoint_bytes >= min_bytes && update_regen_rows(dtype, n, T, S, recipe) > 0) {
             fs.nostore = 1; fs.store_threshold = dense->store_threshold;
             regen->recipe = recipe; regen->L = L; regen->seed = seed; regen->draw = draw; regen->mode_offset = mode_offset;
             regen->coef = recipe == 1 ? prior.iso32p : prior.iso32;

@@ -120,6 +120,7 @@ struct SgpmpToggles {
     int no_planar_tail;       // SGPMP_NO_PLANAR_TAIL       store-free steps of S = 64 planar problems: update_kernel (+ regeneration, if planar_store_free) instead of the update inside fused_planar_seg_kernel
     int planar_store_free;    // SGPMP_PLANAR_STORE_FREE    store-free steps (SGPMP_STEP_NO_SAMPLES) also for fused_planar_seg_kernel: measured SLOWER at config 2 (the launch saves 3.8 us, the update's regeneration costs 5.2: 42.4 k -> 40.0 k it/s, profiles/r05), hence opt-in
     int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
+    long long store_free_min_bytes;   // SGPMP_STORE_FREE_MIN_BYTES  a store-free step that REGENERATES rows in update_kernel is taken when one waypoint of all the step's samples (P S 2n floats) has at least this many bytes (0: the measured break-even, SGPMP_STORE_FREE_BREAK_EVEN; 1: always)
     long long pipe_split;     // SGPMP_PIPE_SPLIT           first chain's share of the particles in 16ths (0 = default 8)
     long long k3_blocks;      // SGPMP_K3_BLOCKS            workgroup cap of the dual sweep (0: default)
 };
@@ -189,6 +190,7 @@ struct FusedDenseHost {
     double temperature;
     int nostore;                  // the caller does not need this step's samples (SGPMP_STEP_NO_SAMPLES) and the update can regenerate rows
     unsigned store_threshold;     // ... rows are then stored for particles with nnz above it only
+    int particles_total;          // particles of the whole step (a pipelined step launches halves): the size a regenerating store-free step is judged on
     // the update INSIDE fused_planar_seg_kernel (store-free steps, S = 64; fused_planar_seg.inc: seg_update) -- what update_kernel
     // would have been given; tail_done == null: not offered (per-step mean statistics, ...)
     unsigned* tail_done;          // finished-particle counter of this launch (zero between launches)
@@ -197,6 +199,9 @@ struct FusedDenseHost {
     void* weights; void* grad; void* means_prev;   // K4's optional outputs (context dtype)
     double step_size;
 };
+// bytes of one waypoint of all samples of a step above which a regenerating store-free step is faster than a storing one
+// (cost_sweep.hip: launch_fused_step has the measurement)
+#define SGPMP_STORE_FREE_BREAK_EVEN 2800000LL
 // How update_kernel regenerates the rows a store-free step did not write (update_common.h: RegenArgs)
 struct RegenHost {
     int recipe;                   // 0: all rows are in memory; 1: fused_step_kernel's rows; 2: fused_planar_seg_kernel's (segments of L)

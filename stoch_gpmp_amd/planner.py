@@ -39,7 +39,9 @@ Additions over the reference API (all optional keyword arguments):
                              the update regenerates the rows that carry weight from their noise keys, bit for bit
                              (include/sgpmp.h: SGPMP_STEP_NO_SAMPLES).  The last iteration of every call -- and so every
                              optimize(opt_iters=1) -- stores as always; all returned tensors, `particle_means` and
-                             `state_samples` are identical either way.  False: every iteration stores.
+                             `state_samples` are identical either way.  The library takes the permission where it
+                             pays (problems of >= 2.8 MB of samples per waypoint, or planar ones whose update runs
+                             inside the launch); smaller problems store.  False: every iteration stores.
 """
 import itertools
 import time

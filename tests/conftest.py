@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Store-free iterations that regenerate rows are taken above a measured size only (cost_sweep.hip: SGPMP_STORE_FREE_BREAK_EVEN);
+# the parity tests run small shapes and want the store-free form all the same.  Read once per context, at sgpmp_create;
+# test_store_free_steps_are_taken_where_they_pay puts the default back.
+os.environ.setdefault("SGPMP_STORE_FREE_MIN_BYTES", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -1184,6 +1184,29 @@ def test_store_free_update_regenerates_any_number_of_rows():
     assert a._engine.store_free_steps() == 5 and most > 16, most
 
 
+def test_store_free_steps_are_taken_where_they_pay(golden):
+    """The permission is not an order: a step that would REGENERATE rows in update_kernel runs store-free only when the bytes it
+    does not write outweigh the regeneration (2.8 MB per waypoint of all samples, measured: tools/store_free_sizes.py) -- a
+    small problem stores, config 3 does not, and the results are the same bits either way.  (tests/conftest.py lowers the bar
+    to 1 byte for every other test.)"""
+    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=23)).to(**F32)
+    small = [hip_panda_planner(SC.PANDA, 32, 16, 64, F32, seed=77) for _ in range(2)]
+    small[0]._engine.set_option("store_free_min_bytes", 0)            # the default
+    for pl in small:
+        pl.optimize(opt_iters=5, obstacle_spheres=sph)
+    assert small[0]._engine.store_free_steps() == 0 and small[1]._engine.store_free_steps() == 4
+    assert torch.equal(small[0].particle_means, small[1].particle_means) and torch.equal(small[0].state_samples, small[1].state_samples)
+    big = hip_panda_planner(SC.PANDA, 64, 1024, 128, F32, seed=78)    # BASELINE configs[2]: 7.3 MB per waypoint
+    big._engine.set_option("store_free_min_bytes", 0)
+    big.optimize(opt_iters=3, obstacle_spheres=sph)
+    assert big._engine.store_free_steps() == 2
+    # the planar problems whose update runs inside the launch have nothing to regenerate: store-free at any size
+    pl = hip_planar_planner(SC.PLANAR, 64, [[2.9, 2.6, 0., 0.]], 4, 64, planar_map(golden, F32), F32, seed=79)
+    pl._engine.set_option("store_free_min_bytes", 0)
+    pl.optimize(opt_iters=3)
+    assert pl._engine.store_free_steps() == 2
+
+
 def test_store_free_row_counts_travel_with_the_state():
     """The per-particle row counts steer the next step (partials / stored rows / regenerated rows): state_dict carries them,
     reset() clears them -- a resumed soft-weight run continues bit for bit, also when it resumes in the middle of what would
