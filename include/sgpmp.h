@@ -135,6 +135,10 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * planar_store_free (store-free planar steps of ANY sample count by regenerating rows in update_kernel: bit-identical, measured slower
  * than storing at BASELINE configs[1]; problems with 64 samples per particle run store-free by default, with the update inside the launch),
  * no_planar_tail (those steps with update_kernel behind the launch instead),
+ * no_small_step (steps of up to small_step_items items -- groups of 8 samples; default 256, one per CU -- go out as
+ * fused_step_small_kernel, one WORKGROUP per item with its four waves on the item's time chunks side by side, bit-identical to
+ * the one-wave-per-item launch and about twice as fast where every wave sits alone on its SIMD; 1: always fused_step_kernel),
+ * small_step_items (count),
  * store_free_min_bytes (a store-free step that regenerates rows in update_kernel is taken when one waypoint of all the step's
  * samples -- P S 2n floats -- has at least this many bytes; 0: the measured break-even of 2.8 MB, below which it ran 4 .. 20 %
  * slower than a storing step; 1: always),

@@ -110,7 +110,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
     {"comm_packet_event", &SgpmpToggles::comm_packet_event}, {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"planar_store_free", &SgpmpToggles::planar_store_free}, {"no_planar_tail", &SgpmpToggles::no_planar_tail},
-    {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
+    {"no_small_step", &SgpmpToggles::no_small_step}, {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {
@@ -124,6 +124,7 @@ static void toggles_from_env(SgpmpToggles& tg) {
     if (const char* e = getenv("SGPMP_K3_BLOCKS")) tg.k3_blocks = atoll(e);
     if (const char* e = getenv("SGPMP_PIPE_SPLIT")) tg.pipe_split = atoll(e);
     if (const char* e = getenv("SGPMP_STORE_FREE_MIN_BYTES")) tg.store_free_min_bytes = atoll(e);
+    if (const char* e = getenv("SGPMP_SMALL_STEP_ITEMS")) tg.small_step_items = atoll(e);
 }
 
 extern "C" int sgpmp_abi_version(void) { return SGPMP_ABI_VERSION; }
@@ -209,6 +210,7 @@ extern "C" int sgpmp_set_option(sgpmp_ctx* c, const char* name, long long value)
     if (std::strcmp(name, "k3_blocks") == 0) { c->tg.k3_blocks = value; return SGPMP_OK; }
     if (std::strcmp(name, "pipe_split") == 0) { c->tg.pipe_split = value; return SGPMP_OK; }
     if (std::strcmp(name, "store_free_min_bytes") == 0) { c->tg.store_free_min_bytes = value; return SGPMP_OK; }
+    if (std::strcmp(name, "small_step_items") == 0) { c->tg.small_step_items = value; return SGPMP_OK; }
     for (const auto& t : kToggleNames)
         if (std::strcmp(name, t.name) == 0) { c->tg.*(t.flag) = value != 0; return SGPMP_OK; }
     return fail(SGPMP_EINVAL, std::string("sgpmp_set_option: unknown option ") + name);

@@ -292,6 +292,21 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     // they stay under 2 KB
     const size_t dyn = fused_wave_dyn_lds(n_spheres, F.has_goal ? F.goal.dim0 : 0);
     // S, T off the launch's grid of 8 rows x 16 waypoints: the instantiation with the masks (fused_step.inc: RAG)
+    // a SMALL step -- fewer items than SIMDs: every wave of the launch above would sit alone on its SIMD for as long as one item
+    // takes one wave (~20 us) -- goes out with one WORKGROUP per item instead, its four waves on the item's chunks side by side
+    // (fused_step.inc: LAT; same samples and costs, bit for bit).  Up to one workgroup per CU: beyond, its 260 registers and 55 KB
+    // of LDS per workgroup make a second round of what the other launch does in one (tools/small_step_sizes.py).
+    const long long small_items = tg.small_step_items > 0 ? tg.small_step_items : 256;
+    if (!tg.no_small_step && fs.nitems <= small_items && (T + SGPMP_FUSED_TC - 1) / SGPMP_FUSED_TC <= 16) {
+#define SMALL_LAUNCH(FT_) hipLaunchKernelGGL((fused_step_small_kernel<CCp::N, CCp, FT_>), dim3((unsigned)fs.nitems), dim3(256), (unsigned)dyn, stream, a, F, fs)
+        if (ft == SGPMP_FIELD_RBF) SMALL_LAUNCH(SGPMP_FIELD_RBF);
+        else if (ft == SGPMP_FIELD_SDF) SMALL_LAUNCH(SGPMP_FIELD_SDF);
+        else SMALL_LAUNCH(SGPMP_FIELD_OCCUPANCY);
+#undef SMALL_LAUNCH
+        if (picked) *picked = "fused_step_small_kernel";
+        *launched = true;
+        return hipGetLastError();
+    }
 #define FUSED_LAUNCH(FT_, RAG_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, RAG_>), dim3((unsigned)blocks), dim3(256), (unsigned)dyn + SGPMP_FUSED_EXTRA_LDS, stream, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0u, a, F, fs)
     const bool rag = S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0;
     if (ft == SGPMP_FIELD_RBF) { if (rag) FUSED_LAUNCH(SGPMP_FIELD_RBF, true); else FUSED_LAUNCH(SGPMP_FIELD_RBF, false); }

@@ -110,13 +110,23 @@ __device__ __forceinline__ void scan_step(CP c, real e_pos, real e_vel, real& p,
 // broadcast operand selected by op_sel) instead of the seven the compiler made of the scalar form.  c: row of PriorDev::iso32p =
 // [g11 g21 | h11 h21 | h12 h22 | g22 0] -- the pairs a packed instruction takes as ONE aligned scalar-register pair.
 typedef float sg_f2 __attribute__((ext_vector_type(2)));
+// (in two halves: the noise term does not depend on the state -- fused_step_small_kernel forms it for a whole chunk BEFORE the
+// state arrives from the wave that has the previous chunk, and only the two dependent fmas per waypoint wait for it)
 template <typename CP>
-__device__ __forceinline__ void scan_step2(CP c, float e_pos, float e_vel, sg_f2& pv) {
-    const sg_f2 g = {c[0], c[1]}, h1 = {c[2], c[3]}, h2 = {c[4], c[5]};
+__device__ __forceinline__ sg_f2 scan_step2_noise(CP c, float e_pos, float e_vel) {
+    const sg_f2 g = {c[0], c[1]};
     sg_f2 t = g * (sg_f2){e_pos, e_pos};
     t.y = __builtin_fmaf(c[6], e_vel, t.y);
+    return t;
+}
+__device__ __forceinline__ void scan_step2_state(sg_f2 h1, sg_f2 h2, sg_f2 t, sg_f2& pv) {
     t = __builtin_elementwise_fma(h1, (sg_f2){pv.x, pv.x}, t);
     pv = __builtin_elementwise_fma(h2, (sg_f2){pv.y, pv.y}, t);
+}
+template <typename CP>
+__device__ __forceinline__ void scan_step2(CP c, float e_pos, float e_vel, sg_f2& pv) {
+    const sg_f2 h1 = {c[2], c[3]}, h2 = {c[4], c[5]};
+    scan_step2_state(h1, h2, scan_step2_noise(c, e_pos, e_vel), pv);
 }
 
 // ... with the two coefficient rows of a Philox block (waypoints t, t + 1) already in 16 scalar registers (one s_load_dwordx16)

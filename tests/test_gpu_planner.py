@@ -1184,6 +1184,55 @@ def test_store_free_update_regenerates_any_number_of_rows():
     assert a._engine.store_free_steps() == 5 and most > 16, most
 
 
+@pytest.mark.parametrize("shape", ["example", "one_particle", "ragged", "long", "two_goals_sdf", "occupancy", "soft_weights",
+                                   "store_free"])
+def test_small_step_launch_equals_the_one_wave_per_item_launch_bitwise(shape):
+    """A step of few items (the reference's own example: 5 particles x 32 samples x 64 waypoints, panda_environment.py:29-32) goes
+    out as fused_step_small_kernel -- one WORKGROUP per item, its four waves on the item's chunks side by side, the recurrence's
+    state handed from wave to wave -- instead of one wave per item (fused_step.inc: LAT).  Same counters, expressions and order
+    of sums: samples, costs, means, weights, gradient bit-identical, for shapes on and off the 8 x 16 grid, T beyond one round of
+    four chunks, several goals, every field type, spread weights (softmax partials re-read rows other waves stored) and
+    store-free iterations (rows regenerated by update_kernel)."""
+    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=23)).to(**F32)
+    kw, calls, cfg, args = {}, (1, 3, 1), SC.PANDA, (64, 5, 32)
+    if shape == "one_particle":
+        args = (16, 1, 8)
+    elif shape == "ragged":
+        args = (50, 7, 27)
+    elif shape == "long":
+        args = (176, 3, 40)                              # 11 chunks: three rounds, the last one short
+    elif shape == "two_goals_sdf":
+        kw = dict(goals=[SC.PANDA["goal_q"] + [0.] * 7, [0.3, 0.1, 0.2, -1.2, 0.0, 1.8, 0.2] + [0.] * 7], field_type="sdf")
+        args = (32, 6, 16)
+    elif shape == "occupancy":
+        kw = dict(field_type="occupancy")
+        args = (48, 4, 24)
+    elif shape == "soft_weights":
+        cfg = dict(SC.PANDA, temperature=1e14, sigma_start_sample=1.0, sigma_goal_sample=1.0, sigma_gp_sample=30.0)
+        args, calls = (32, 6, 64), (1, 1, 4, 2)
+    elif shape == "store_free":
+        calls = (5, 1, 4)
+    T, nppg, S = args
+    a = hip_panda_planner(cfg, T, nppg, S, F32, seed=81, **kw)
+    b = hip_panda_planner(cfg, T, nppg, S, F32, seed=81, **kw)
+    a._engine.set_option("no_small_step", 0)             # (tests/conftest.py switches the small launch off for every other test)
+    for k in calls:
+        ra, rb = a.optimize(opt_iters=k, obstacle_spheres=sph), b.optimize(opt_iters=k, obstacle_spheres=sph)
+        assert a._engine.last_cost_kernel() == "fused_step_small_kernel" and b._engine.last_cost_kernel() == "fused_step_kernel"
+        for i, (x, y) in enumerate(zip(ra, rb)):
+            assert torch.equal(x, y), (k, i)
+        assert torch.equal(a.particle_means, b.particle_means) and torch.equal(a.state_samples, b.state_samples), k
+        assert torch.equal(a._weights_buf, b._weights_buf) and torch.equal(a._grad, b._grad) and torch.equal(a._costs, b._costs), k
+    if shape == "soft_weights":
+        assert a._engine.dense_armed_steps() > 0 and int(a._engine.row_counts().max()) > 16
+    if shape == "store_free":
+        assert a._engine.store_free_steps() == 7 and b._engine.store_free_steps() == 7
+    # above the size bar the step is the one-wave-per-item launch again (256 items by default; here: 3)
+    a._engine.set_option("small_step_items", 3)
+    a.optimize(opt_iters=1, obstacle_spheres=sph)
+    assert a._engine.last_cost_kernel() == ("fused_step_small_kernel" if shape == "one_particle" else "fused_step_kernel")
+
+
 def test_store_free_steps_are_taken_where_they_pay(golden):
     """The permission is not an order: a step that would REGENERATE rows in update_kernel runs store-free only when the bytes it
     does not write outweigh the regeneration (2.8 MB per waypoint of all samples, measured: tools/store_free_sizes.py) -- a

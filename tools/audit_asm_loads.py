@@ -15,7 +15,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = r"fused_step_kernel|cost_sweep_chunked_kernel|fused_planar_kernel"
+KERNELS = r"fused_step_kernel|fused_step_small_kernel|cost_sweep_chunked_kernel|fused_planar_kernel"
 
 
 def listing(name="cost_sweep"):

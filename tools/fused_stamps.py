@@ -14,7 +14,8 @@ pl._engine.set_option("no_step_pipeline", 1)
 for _ in range(30):
     pl.optimize(opt_iters=1, obstacle_spheres=sph)
 torch.cuda.synchronize()
-assert pl._engine.last_cost_kernel() == "fused_step_kernel"
+assert pl._engine.last_cost_kernel() in ("fused_step_kernel", "fused_step_small_kernel")
+print("kernel:", pl._engine.last_cost_kernel())
 c = pl._costs.reshape(-1, 8).double().cpu()          # [item = wave][slot]
 PRO = os.environ.get("FUSED_STAMPS_PROLOGUE") == "1"          # library built with -DFUSED_STAMPS=2: slots 0..2 = cycles from kernel entry
 names = ["phase A (noise + recurrence)", "wait + phase B (x = mu + y, stores)", "phase C loads + quadratic forms",
