@@ -96,14 +96,25 @@ __device__ __forceinline__ void box_muller_f64(uint32_t a, uint32_t b, uint32_t 
 // c: row of PriorDev::iso64 / iso32 = [g11 g21 g22 h11 h12 h21 h22 0].
 __device__ __forceinline__ float sg_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double sg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// (in two halves: the noise terms do not depend on the state -- the few-wave sampler forms them in parallel and leaves the two
+// dependent fmas per waypoint to its serial phase.  h = c[3 .. 6].)
+template <typename real, typename CP>
+__device__ __forceinline__ void scan_step_noise(CP c, real e_pos, real e_vel, real& tp, real& tv) {
+    tp = c[0] * e_pos;
+    tv = sg_fma((real)c[2], e_vel, c[1] * e_pos);
+}
+template <typename real, typename HP>
+__device__ __forceinline__ void scan_step_state(HP h, real tp, real tv, real& p, real& v) {
+    tp = sg_fma((real)h[0], p, tp);
+    tv = sg_fma((real)h[2], p, tv);
+    p = sg_fma((real)h[1], v, tp);
+    v = sg_fma((real)h[3], v, tv);
+}
 template <typename real, typename CP>
 __device__ __forceinline__ void scan_step(CP c, real e_pos, real e_vel, real& p, real& v) {
-    real tp = c[0] * e_pos;
-    real tv = sg_fma((real)c[2], e_vel, c[1] * e_pos);
-    tp = sg_fma((real)c[3], p, tp);
-    tv = sg_fma((real)c[5], p, tv);
-    p = sg_fma((real)c[4], v, tp);
-    v = sg_fma((real)c[6], v, tv);
+    real tp, tv;
+    scan_step_noise<real>(c, e_pos, e_vel, tp, tv);
+    scan_step_state<real>(c + 3, tp, tv, p, v);
 }
 
 // The same step on the packed-fp32 unit: (p, v) as one register pair, four instructions (v_pk_mul, v_fma, 2 x v_pk_fma with the

@@ -149,17 +149,18 @@ sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*
 // block each), parked in the LDS tile, and only the cheap 7-FMA recurrence runs serially, in place;
 // the tile is then flushed as row segments.  Same counter layout and the same recurrence expressions
 // as above, so the two kernels return identical samples.
-#define SGPMP_SMALL_TC 32
-#define SGPMP_SMALL_SPB 8
-template <typename real>
+// (SPB samples x TC waypoints per chunk and workgroup: the launch's choice.)
+// NC: the dof count as a compile-time constant (0: whatever n says) -- the serial phase is ONE wave issuing one instruction every
+// four cycles with nothing to overlap, and with run-time strides a third of its instructions were address arithmetic.
+template <typename real, int NC>
 __global__ void __launch_bounds__(256)
-sample_iso_small_kernel(int n, int T, int S, const real* __restrict__ coef, const real* __restrict__ means,
+sample_iso_small_kernel(int n_arg, int T, int S, int SPB, int TC, const real* __restrict__ coef, const real* __restrict__ means,
                         int mode_offset, uint64_t seed, uint64_t draw, real* __restrict__ out,
                         double* __restrict__ zero_stats) {
+    const int n = NC ? NC : n_arg;
     SGPMP_ZERO_STATS(zero_stats);
     typedef real vec __attribute__((ext_vector_type(2)));
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    constexpr int TC = SGPMP_SMALL_TC, SPB = SGPMP_SMALL_SPB;
     const int m = blockIdx.y, d = 2 * n, pitch = TC * d + 4;
     real* tile = reinterpret_cast<real*>(lds_raw);        // [SPB][TC*d + 4]
     real* cf = tile + (size_t)SPB * pitch;                // [TC][8] recurrence coefficients of the chunk
@@ -171,48 +172,95 @@ sample_iso_small_kernel(int n, int T, int S, const real* __restrict__ coef, cons
     const real* mu = means + (size_t)m * M;
     const int sl_scan = tid / n, k_scan = tid - sl_scan * n;
     real p = 0, v = 0;
+#ifdef SGPMP_SMALL_STAMPS      // diagnostic build: cycles of workgroup (0, 0)'s phases over the first waypoints of its first row
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t;
+#define SST_NOW() ([]() { unsigned long long t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); return t_; }())
+#define SST(i) do { const unsigned long long n_ = SST_NOW(); st_[i] += n_ - st_t; st_t = n_; } while (0)
+    st_t = SST_NOW();
+#else
+#define SST(i) do {} while (0)
+#endif
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int tc = min(TC, T - t0);
-        // ---- phase 1: noise of this chunk, one RNG block per thread and trip (+ the coefficients: the
-        // serial phase must not wait for global memory at every waypoint)
+        // ---- phase 1: noise of this chunk, one RNG block per thread and trip -- left in the tile as the recurrence's NOISE TERMS
+        // (rng.h scan_step_noise: the half of a step that does not depend on the state, three products per waypoint), so that the
+        // serial phase is the two dependent fmas per waypoint and nothing else -- + the coefficients it needs (it must not wait for
+        // global memory at every waypoint)
         for (int w = tid; w < tc * 8; w += blockDim.x) cf[w] = coef[(size_t)t0 * 8 + w];
+#if defined(SGPMP_SMALL_SKIP) && SGPMP_SMALL_SKIP == 1
+        if (false) {} else if (false)
+#endif
         if (sizeof(real) == 4) {
             const int pairs = (tc + 1) >> 1;              // t0 is even: blocks cover waypoints (2b, 2b+1)
             for (int w = tid; w < chains * pairs; w += blockDim.x) {
                 const int c = w / pairs, b = w - c * pairs;
                 const int sl = c / n, k = c - sl * n;
+                const real* cw = coef + (size_t)(t0 + 2 * b) * 8;        // (rows of waypoints t0 + 2b, + 1: the table is padded to even T)
                 NoiseGen<real> gen;
                 gen.init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)(s0 + sl), (uint32_t)k);
                 real e[4];
                 gen.get4(t0 + 2 * b, e);
                 real* o = tile + (size_t)sl * pitch + (2 * b) * d + k;
-                o[0] = e[0]; o[n] = e[1];
-                if (2 * b + 1 < tc) { o[d] = e[2]; o[d + n] = e[3]; }
+                scan_step_noise<real>(cw, e[0], e[1], o[0], o[n]);
+                if (2 * b + 1 < tc) scan_step_noise<real>(cw + 8, e[2], e[3], o[d], o[d + n]);
             }
         } else {
             for (int w = tid; w < chains * tc; w += blockDim.x) {
                 const int c = w / tc, tt = w - c * tc;
                 const int sl = c / n, k = c - sl * n;
+                const real* cw = coef + (size_t)(t0 + tt) * 8;
                 NoiseGen<real> gen;
                 gen.init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)(s0 + sl), (uint32_t)k);
                 real e1, e2;
                 gen.get(t0 + tt, e1, e2);
                 real* o = tile + (size_t)sl * pitch + tt * d + k;
-                o[0] = e1; o[n] = e2;
+                scan_step_noise<real>(cw, e1, e2, o[0], o[n]);
             }
         }
+        SST(0);
         __syncthreads();
-        // ---- phase 2: the recurrence, in place, one thread per chain
+        SST(1);
+        // ---- phase 2: the recurrence, in place, one thread per chain: blocks of four waypoints, the next block's noise terms and
+        // coefficients on their way out of LDS while this block's fmas run (as one loop the chain waited for an LDS round trip
+        // per waypoint: 32 x ~250 cycles per chunk, half of this kernel's time)
+#if defined(SGPMP_SMALL_SKIP) && SGPMP_SMALL_SKIP == 2
+        if (false)
+#endif
         if (tid < chains) {
-            const real* c = cf;
+            constexpr int SB = 8;
             real* o = tile + (size_t)sl_scan * pitch + k_scan;
-#pragma unroll 4
-            for (int tt = 0; tt < tc; ++tt, c += 8, o += d) {
-                scan_step(c, o[0], o[n], p, v);
-                o[0] = p; o[n] = v;
+            struct Blk { real tp[SB], tv[SB], h[SB][4]; } A, B;
+            auto fetch = [&](int tb, Blk& x) {
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int tt = tb + i;                                 // (up to 2 SB waypoints past the chunk: inside the allocation -- the launch pads it -- and never used)
+                    x.tp[i] = o[tt * d]; x.tv[i] = o[tt * d + n];
+                    x.h[i][0] = cf[tt * 8 + 3]; x.h[i][1] = cf[tt * 8 + 4]; x.h[i][2] = cf[tt * 8 + 5]; x.h[i][3] = cf[tt * 8 + 6];
+                }
+            };
+            // (no guard per waypoint: a short chunk is the LAST one, its steps past tc stay inside the tile -- TC is a multiple of the
+            // 16 waypoints of a loop trip -- and nothing reads them or the state after them; with guards every step was a basic
+            // block of its own, two taken branches per waypoint: 170 cycles per step instead of 40)
+            auto run = [&](int tb, const Blk& x) {
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    scan_step_state<real>(x.h[i], x.tp[i], x.tv[i], p, v);
+                    o[(tb + i) * d] = p; o[(tb + i) * d + n] = v;
+                }
+            };
+            // two register sets, alternating: the loads of one block are issued before the other block's fmas (in source order, so
+            // nothing has to be proved about the in-place stores)
+            fetch(0, A);
+            for (int tb = 0; tb < tc; tb += 2 * SB) {
+                fetch(tb + SB, B);
+                run(tb, A);
+                fetch(tb + 2 * SB, A);
+                run(tb + SB, B);
             }
         }
+        SST(2);
         __syncthreads();
+        SST(3);
         // ---- phase 3: flush row segments, x = mu + y
         const int seg = tc * d / 2;
         for (int w = tid; w < rows * seg; w += blockDim.x) {
@@ -221,8 +269,13 @@ sample_iso_small_kernel(int n, int T, int S, const real* __restrict__ coef, cons
             val += *reinterpret_cast<const vec*>(mu + (size_t)t0 * d + j * 2);
             *reinterpret_cast<vec*>(out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d + j * 2) = val;
         }
+        SST(4);
         __syncthreads();
+        SST(5);
     }
+#ifdef SGPMP_SMALL_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 6) out[tid] = (real)st_[tid];
+#endif
 }
 
 // ---- dense d x d factors (user-supplied Q_c^-1: gp_factor.py:25-27 accepts any matrix; per-mode precisions of
@@ -329,10 +382,21 @@ static hipError_t sample_dispatch(int n, int T, const PriorDev& prior, uint64_t 
         if (!eps && (long long)waves * n_modes < 256 && !tg.no_small_sampler) {
             // less than one wave per CU: noise in parallel, recurrence from LDS (config 1: 48 -> 16 us;
             // at config 2's 512 waves the standard kernel is still the faster one, 33 vs 45 us)
-            dim3 sgrid((S + SGPMP_SMALL_SPB - 1) / SGPMP_SMALL_SPB, n_modes);
-            const size_t slds = ((size_t)SGPMP_SMALL_SPB * (SGPMP_SMALL_TC * d + 4) + SGPMP_SMALL_TC * 8) * sizeof(real);
-            hipLaunchKernelGGL((sample_iso_small_kernel<real>), sgrid, dim3(256), slds, stream, n, T, S, coef, means,
-                               mode_offset, seed, draw, out, zero_stats);
+            // (a workgroup's share: 8 or 4 samples x up to 64 waypoints per chunk.  Measured on the reference's planar example, 15 x 128
+            // x 64 fp64 -- tools/small_sampler_shapes.sh, tools/small_sampler_stamps.py: the serial recurrence of a workgroup, 64
+            // steps of ~90 cycles on one wave, is what the launch waits for; more, smaller workgroups only add to it)
+            // fp64: 4 samples per workgroup while that keeps the grid within two workgroups per CU -- the noise phase (a double-precision
+            // Box-Muller per block) halves, 10.6 -> 9.9 us on the example; 2 samples: 13.9 us
+            int tc = T > 32 ? 64 : 32, spb = (f64 && (long long)((S + 3) / 4) * n_modes <= 512) ? 4 : 8;
+#ifdef SGPMP_SMALL_SHAPE_ENV      // diagnostic build (tools/small_sampler_shapes.sh): SGPMP_SMALL_SHAPE="spb,tc"
+            if (const char* e = getenv("SGPMP_SMALL_SHAPE")) sscanf(e, "%d,%d", &spb, &tc);
+#endif
+            dim3 sgrid((S + spb - 1) / spb, n_modes);
+            const size_t slds = ((size_t)spb * (tc * d + 4) + (size_t)tc * 8 + 16 * (size_t)(d + 8)) * sizeof(real);   // (+ the serial phase's read-ahead)
+#define SMALL_LAUNCH(NC_) hipLaunchKernelGGL((sample_iso_small_kernel<real, NC_>), sgrid, dim3(256), slds, stream, n, T, S, spb, tc, coef, means, \
+                                              mode_offset, seed, draw, out, zero_stats)
+            if (n == 2) SMALL_LAUNCH(2); else if (n == 3) SMALL_LAUNCH(3); else if (n == 7) SMALL_LAUNCH(7); else SMALL_LAUNCH(0);
+#undef SMALL_LAUNCH
             return hipGetLastError();
         }
         const int wpb = waves < 4 ? waves : 4;

@@ -1,4 +1,5 @@
-"""Host-side cost of one StochGPMP.optimize(opt_iters=1) call (config 1 is host-bound: its kernels are a few us)."""
+"""Host-side cost of one StochGPMP.optimize(opt_iters=1) call (config 1 is host-bound: its kernels are a few us).
+usage: host_profile.py [panda]"""
 import cProfile
 import os
 import pstats
@@ -11,7 +12,10 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 dev = torch.device("cuda", 0)
-pl, obs, _ = bench.build_planner(torch, "planar", 4, 16, 64, torch.float64, dev, goals=2)
+if len(sys.argv) > 1 and sys.argv[1] == "panda":          # the reference's example size (panda_environment.py:29-32)
+    pl, obs, _ = bench.build_planner(torch, "panda", 5, 32, 64, torch.float32, dev)
+else:
+    pl, obs, _ = bench.build_planner(torch, "planar", 4, 16, 64, torch.float64, dev, goals=2)
 for _ in range(200):
     pl.optimize(opt_iters=1, **obs)
 torch.cuda.synchronize()
