@@ -916,6 +916,7 @@ static int dense_buffers(sgpmp_ctx* c, FusedDenseHost* d, double temperature, bo
     // and for every particle that gets partials (they re-read the rows): never above the partials' threshold
     d->store_threshold = d->threshold < 4u ? d->threshold : 4u;
     d->particles_total = D.num_particles;
+    d->particles_global = D.num_particles_global > 0 ? D.num_particles_global : D.num_particles;
     if (D.dtype != SGPMP_F32 || D.num_particles < 1) return SGPMP_OK;
     if (!c->d_nnz) {
         const size_t P = (size_t)D.num_particles;

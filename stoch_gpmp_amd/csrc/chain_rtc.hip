@@ -171,6 +171,7 @@ struct RtcChain {
     hipModule_t mod[3] = {nullptr, nullptr, nullptr};
     hipFunction_t fused[3] = {nullptr, nullptr, nullptr}, sweep[3] = {nullptr, nullptr, nullptr}, probe = nullptr;
     hipFunction_t fused_rag[3] = {nullptr, nullptr, nullptr};   // ... for S, T off the launch's grid of 8 x 16 (fused_step.inc: RAG)
+    hipFunction_t fused_small[3] = {nullptr, nullptr, nullptr}, fused_small_rag[3] = {nullptr, nullptr, nullptr};   // ... for steps of few items: one workgroup per item (fused_step.inc: LAT)
     bool tried[3] = {false, false, false};
     std::string err;             // why a compilation failed (sgpmp_fk_codegen_info)
     double compile_s = 0.;       // seconds spent in hiprtc for this chain (0: every code object came from the cache)
@@ -200,6 +201,12 @@ static std::string translation_unit(const RtcChain& c) {
           "extern \"C\" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGPMP_FUSED_WAVES, SGPMP_FUSED_WAVES)))\n"
           "sgpmp_rtc_fused_rag(const CostArgs<float> a, const FlatProg<float> F, const FusedArgs s) {\n"
           "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, false, true>(a, F, s);\n}\n"
+          "extern \"C\" __global__ void __launch_bounds__(256)\n"
+          "sgpmp_rtc_fused_small(const CostArgs<float> a, const FlatProg<float> F, const FusedArgs s) {\n"
+          "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, false, false, true>(a, F, s);\n}\n"
+          "extern \"C\" __global__ void __launch_bounds__(256)\n"
+          "sgpmp_rtc_fused_small_rag(const CostArgs<float> a, const FlatProg<float> F, const FusedArgs s) {\n"
+          "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, false, true, true>(a, F, s);\n}\n"
           "extern \"C\" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGPMP_FUSED_WAVES, SGPMP_FUSED_WAVES)))\n"
           "sgpmp_rtc_sweep(const CostArgs<float> a, const FlatProg<float> F, const FusedArgs s) {\n"
           "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, true>(a, F, s);\n}\n"
@@ -317,15 +324,16 @@ static bool build_module(RtcChain& c, int ft) {
     }
     hipModule_t m = nullptr;
     if (hipModuleLoadData(&m, code.data()) != hipSuccess) { c.err = "hipModuleLoadData failed for the chain kernels"; (void)hipGetLastError(); return false; }
-    hipFunction_t f1 = nullptr, f2 = nullptr, f3 = nullptr, f4 = nullptr;
+    hipFunction_t f1 = nullptr, f2 = nullptr, f3 = nullptr, f4 = nullptr, f5 = nullptr, f6 = nullptr;
     if (hipModuleGetFunction(&f1, m, "sgpmp_rtc_fused") != hipSuccess || hipModuleGetFunction(&f2, m, "sgpmp_rtc_sweep") != hipSuccess ||
-        hipModuleGetFunction(&f3, m, "sgpmp_rtc_probe") != hipSuccess || hipModuleGetFunction(&f4, m, "sgpmp_rtc_fused_rag") != hipSuccess) {
+        hipModuleGetFunction(&f3, m, "sgpmp_rtc_probe") != hipSuccess || hipModuleGetFunction(&f4, m, "sgpmp_rtc_fused_rag") != hipSuccess ||
+        hipModuleGetFunction(&f5, m, "sgpmp_rtc_fused_small") != hipSuccess || hipModuleGetFunction(&f6, m, "sgpmp_rtc_fused_small_rag") != hipSuccess) {
         c.err = "chain code object lacks its kernels";
         (void)hipGetLastError();
         hipModuleUnload(m);
         return false;
     }
-    c.mod[ft] = m; c.fused[ft] = f1; c.sweep[ft] = f2; c.fused_rag[ft] = f4;
+    c.mod[ft] = m; c.fused[ft] = f1; c.sweep[ft] = f2; c.fused_rag[ft] = f4; c.fused_small[ft] = f5; c.fused_small_rag[ft] = f6;
     if (!c.probe) c.probe = f3;
     return true;
 }
@@ -348,11 +356,11 @@ const char* rtc_chain_get(const char* struct_src, int n_dof, RtcChain** out) {
 }
 
 // The kernel for (field type, fused launch | stand-alone sweep), compiled on first use; null when unavailable (c->err says why).
-hipFunction_t rtc_kernel(RtcChain* c, int ft, bool sweep, bool rag) {
+hipFunction_t rtc_kernel(RtcChain* c, int ft, bool sweep, bool rag, bool small) {
     if (!c || ft < 0 || ft > 2) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
     if (!build_module(*c, ft)) return nullptr;
-    return sweep ? c->sweep[ft] : rag ? c->fused_rag[ft] : c->fused[ft];
+    return sweep ? c->sweep[ft] : small ? (rag ? c->fused_small_rag[ft] : c->fused_small[ft]) : rag ? c->fused_rag[ft] : c->fused[ft];
 }
 
 const char* rtc_error(const RtcChain* c) { return c ? c->err.c_str() : ""; }

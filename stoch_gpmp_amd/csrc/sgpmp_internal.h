@@ -153,7 +153,7 @@ const char* comm_allgather(SgpmpComm* c, const void* send, void* recv, size_t by
 // ---------------------------------------------------------------------------------- run-time chain kernels (chain_rtc.hip)
 struct RtcChain;
 const char* rtc_chain_get(const char* struct_src, int n_dof, RtcChain** out);       // null on success, else the reason
-hipFunction_t rtc_kernel(RtcChain* c, int field_type, bool sweep, bool rag = false); // compiled on first use; null: unavailable (rag: the fused launch for S, T off its 8 x 16 grid)
+hipFunction_t rtc_kernel(RtcChain* c, int ft, bool sweep, bool rag = false, bool small = false); // compiled on first use; null: unavailable (rag: the fused launch for S, T off its 8 x 16 grid)
 hipError_t rtc_launch(hipFunction_t f, unsigned blocks, unsigned dyn_lds, hipStream_t stream, void** args, hipEvent_t done);
 const char* rtc_verify(RtcChain* c, const ChainDev& chain, int field_type_hint, int* mismatch = nullptr);   // generated code == this chain?  (*mismatch: 1 = no, 0 = kernels unavailable)
 const char* rtc_error(const RtcChain* c);
@@ -193,6 +193,7 @@ struct FusedDenseHost {
     int nostore;                  // the caller does not need this step's samples (SGPMP_STEP_NO_SAMPLES) and the update can regenerate rows
     unsigned store_threshold;     // ... rows are then stored for particles with nnz above it only
     int particles_total;          // particles of the whole step (a pipelined step launches halves): the size a regenerating store-free step is judged on
+    int particles_global;         // ... of all ranks (sgpmp_dims::num_particles_global): the size the small-step launch is judged on
     // the update INSIDE fused_planar_seg_kernel (store-free steps, S = 64; fused_planar_seg.inc: seg_update) -- what update_kernel
     // would have been given; tail_done == null: not offered (per-step mean statistics, ...)
     unsigned* tail_done;          // finished-particle counter of this launch (zero between launches)

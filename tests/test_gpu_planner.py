@@ -1233,6 +1233,27 @@ def test_small_step_launch_equals_the_one_wave_per_item_launch_bitwise(shape):
     assert a._engine.last_cost_kernel() == ("fused_step_small_kernel" if shape == "one_particle" else "fused_step_kernel")
 
 
+def test_small_step_launch_costs_bitwise_over_many_seeds():
+    """The rare event the shapes above could miss: the small-step launch once ran the MASKED instantiation for every shape, and
+    against the unmasked one-wave-per-item launch of an on-grid shape ~0.1 % of the costs came out one ulp apart (hipcc pairs the
+    cost terms' multiplies and adds differently around the masks' branches).  Both launches now take the instantiation the shape
+    calls for: 12 seeds x 3 iterations x 160 costs at the reference's example size, near and far obstacles -- every bit equal."""
+    for far in (False, True):
+        for seed in range(12):
+            sph = torch.as_tensor(SC.panda_spheres(num=5, seed=seed)).to(**F32)
+            if far:
+                sph = sph.clone()
+                sph[:, :3] += 50.0
+            a = hip_panda_planner(SC.PANDA, 64, 5, 32, F32, seed=seed)
+            b = hip_panda_planner(SC.PANDA, 64, 5, 32, F32, seed=seed)
+            a._engine.set_option("no_small_step", 0)
+            for it in range(3):
+                a.optimize(obstacle_spheres=sph)
+                b.optimize(obstacle_spheres=sph)
+                assert a._engine.last_cost_kernel() == "fused_step_small_kernel" and b._engine.last_cost_kernel() == "fused_step_kernel"
+                assert torch.equal(a._costs, b._costs) and torch.equal(a.particle_means, b.particle_means), (far, seed, it)
+
+
 def test_store_free_steps_are_taken_where_they_pay(golden):
     """The permission is not an order: a step that would REGENERATE rows in update_kernel runs store-free only when the bytes it
     does not write outweigh the regeneration (2.8 MB per waypoint of all samples, measured: tools/store_free_sizes.py) -- a
@@ -1375,6 +1396,18 @@ def test_any_serial_chain_runs_the_fused_launch_through_run_time_chain_code(arm,
         assert a2._engine.last_cost_kernel() == "fused_step_kernel (run-time chain code)", a2._engine.last_cost_kernel()
         assert torch.equal(a2.state_samples, b2.state_samples) and rel_err(a2._costs, b2._costs) < 2e-5
         assert float((a2.particle_means - b2.particle_means).abs().max()) <= 1e-6 * float(b2.particle_means.abs().max())
+    # ... and the chain's small-step launch (one workgroup per item; tests/conftest.py keeps it off elsewhere): the same samples
+    # bit for bit, the costs to fp32 rounding (like the two-launch path above: for run-time chain code every launch is a
+    # compilation of its own, and hiprtc need not pair the cost terms' multiplies and adds alike in each; the built-in chain's
+    # launches ARE bit-identical: test_small_step_launch_equals_the_one_wave_per_item_launch_bitwise)
+    a3 = hip_panda_planner(c, 24, 5, 12, F32, seed=seed, field_type=field_type, chain=chain)
+    a3._engine.set_option("no_small_step", 0)
+    for it in range(2):
+        a3.optimize(obstacle_spheres=sph.to(**F32))
+        assert a3._engine.last_cost_kernel() == "fused_step_small_kernel (run-time chain code)", a3._engine.last_cost_kernel()
+    assert torch.equal(a3.state_samples, a2.state_samples) and rel_err(a3._costs, a2._costs) < 2e-6
+    assert float((a3.particle_means - a2.particle_means).abs().max()) <= 1e-6 * float(a2.particle_means.abs().max())
+    print(f"[run-time chain code] small-step launch against the one-wave launch: {int((a3._costs != a2._costs).sum())} of {a3._costs.numel()} costs differ")
 
 
 def test_chain_code_of_another_robot_is_refused():
