@@ -24,7 +24,9 @@ average duration measured with HIP events on the launch stream is in `roofline_d
 product's default inside optimize(opt_iters=K) since round 5 -- iterations 1 .. K - 1 do not write their samples,
 bit-identical results -- beside it, never instead of it; `parity` is a free-running K = 10 comparison with the fp64 CPU oracle made by this run; `cpu_baseline` times the reference-equivalent PyTorch-CPU
 oracle on a bounded sample of the same workload on this box's host cores, `cpu_fair` the banded fp64
-restatement (what a careful CPU implementation of the same mathematics costs).
+restatement (what a careful CPU implementation of the same mathematics costs).  `other_configs` are BASELINE.json's other
+single-GPU configurations; `reference_examples` the reference's own two example problems at their own sizes, one
+optimize(opt_iters=1) per call as its scripts run them (microseconds per call).
 """
 import argparse
 import json
@@ -328,6 +330,45 @@ def other_configs(torch, dev, copy_gbs=None):
                     "dtype": "f32" if spec["dtype"] == f32 else "f64"})
         del pl
         torch.cuda.empty_cache()
+    return out
+
+
+def reference_examples(torch):
+    """The reference's own example problems at their own sizes, run the way its scripts run them -- one optimize(opt_iters=1)
+    per loop trip (examples/panda_environment.py:29-32,107,141-147: 5 particles x 32 samples x 64 waypoints, fp32, five cost
+    terms incl. the end-effector goal; planar_environment.py:14-20,82,102-108: 15 x 128 x 64, fp64): microseconds per call,
+    free-running (the queue drains behind the host) and with the host's enqueue alone.  Latency-bound launches: the step goes
+    out as fused_step_small_kernel / the few-wave sampler."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    out = {}
+    for which in ("panda", "planar"):
+        try:
+            ex = __import__(which + "_environment")
+            pl, _ = ex.main(opt_iters=20, seed=0, verbose=False)
+            obs = {}
+            if which == "panda":
+                import numpy as np
+                sph = np.zeros((1, 5, 4))
+                sph[0, :, :3] = [[0.8, 0., 0.8], [0.7, -0.1, 0.7], [0.9, 0.1, 0.9], [0.65, 0.15, 0.95], [0.95, -0.15, 0.65]]
+                sph[0, :, 3] = 0.12
+                obs = {"obstacle_spheres": torch.from_numpy(sph).to(**pl.tensor_args)}
+            calls = 500
+            for _ in range(50):
+                pl.optimize(**obs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                pl.optimize(**obs)
+            t_host = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+            out[which] = {"shape": f"{pl.num_particles} x {pl.num_samples} x {pl.traj_len}", "dtype": str(pl.tensor_args["dtype"]).split(".")[-1],
+                          "us_per_call": 1e6 * t_all / calls, "host_enqueue_us_per_call": 1e6 * t_host / calls,
+                          "launches_per_call": pl._engine.last_step_launches(), "cost_kernel": pl._engine.last_cost_kernel()}
+            del pl
+        except Exception as e:                                    # (reported, never fatal for the bench line)
+            out[which] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
     return out
 
 
@@ -773,6 +814,7 @@ def main():
             del pl
             torch.cuda.empty_cache()
             out["other_configs"] = other_configs(torch, dev, copy_gbs)
+            out["reference_examples"] = reference_examples(torch)
         line = json.dumps(out)
         head = line[:1500]
         assert all(k in head for k in ('"value"', '"single_iteration_calls"', '"roofline"', '"cpu_baseline"')), len(head)
