@@ -110,7 +110,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
     {"comm_packet_event", &SgpmpToggles::comm_packet_event}, {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"planar_store_free", &SgpmpToggles::planar_store_free}, {"no_planar_tail", &SgpmpToggles::no_planar_tail},
-    {"no_small_step", &SgpmpToggles::no_small_step}, {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
+    {"no_small_step", &SgpmpToggles::no_small_step}, {"no_ee_fold", &SgpmpToggles::no_ee_fold}, {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {
@@ -902,6 +902,17 @@ extern "C" int sgpmp_update(sgpmp_ctx* c, const void* costs, int costs_dtype, co
     return SGPMP_OK;
 }
 
+// The step's end-effector goal term goes INTO update_kernel (update_common.h: EeFold) when it is the only one and the kernel's
+// scratch has room: one launch less per iteration (the term is a few hundred flops per trajectory; as a launch of its own it
+// cost 6 us of the reference's Panda example's 24).  -> the term, or null: ee_goal_kernel in front of update_kernel as before.
+static const CostTerm* ee_term_to_fold(const sgpmp_ctx* c) {
+    if (c->tg.no_ee_fold || c->h_prog.n_ee != 1) return nullptr;
+    if (!update_ee_fold_fits(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, c->dims.num_samples)) return nullptr;
+    for (int i = 0; i < c->h_prog.n_terms; ++i)
+        if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) return &c->h_prog.terms[i];
+    return nullptr;
+}
+
 // Buffers the fused launch and update_kernel share across steps (allocated once, by the first fp32 step).
 // Particles whose previous update spread its weight over more than S / 4 rows get partials (a fused wave pays ~6 % for them,
 // the update reads ceil(S / 8) rows instead of nnz).  Everything here is a function of stream-ordered device state -- the
@@ -1087,7 +1098,9 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
             if (k4_done[h]) HIPCHK(hipEventRecord(k4_done[h], sh));
             continue;
         }
-        for (int i = 0; i < c->h_prog.n_terms; ++i)
+        const CostTerm* eet = ee_term_to_fold(c);
+        const EeFoldHost eeh = {eet, c->d_chain, cs};
+        for (int i = 0; !eet && i < c->h_prog.n_terms; ++i)
             if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) {
                 HIPCHK(launch_ee_goal(D.dtype, D.n_dof, D.traj_len, c->h_prog.terms[i], c->d_chain, X,
                                       (long long)Ph * S, cs, c64, sh));
@@ -1095,7 +1108,7 @@ static int step_split(sgpmp_ctx* c, uint64_t seed, uint64_t draw, char* means, c
             }
         HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, Ph, S, c64, SGPMP_F64, X, mu, temperature, step_size, wh, gh, mph,
                              slot, sh, c->tg.comm_packet_event ? k4_done[h] : nullptr, &pr, isw, &isw_next[h], nullptr,
-                             armed ? dh.part : nullptr, dh.nnz, dh.threshold, &rgh));
+                             armed ? dh.part : nullptr, dh.nnz, dh.threshold, &rgh, eet ? &eeh : nullptr));
         if (h == 0 && rgh.recipe != 0) c->store_free_steps += 1;
         if (!c->tg.comm_packet_event && k4_done[h]) HIPCHK(hipEventRecord(k4_done[h], sh));
         c->last_step_launches += 1;
@@ -1212,6 +1225,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     bool partials = false, tail_ran = false;                     // tail_ran: the launch also updated its particles (fused_planar_seg.inc: seg_update)
     RegenHost regen;                                             // store-free step: how the update regenerates rows
     std::memset(&regen, 0, sizeof(regen));
+    const CostTerm* eet = nullptr;                               // the end-effector goal term update_kernel evaluates itself (fused steps)
     if (fused) {
         if (se) { HIPCHK(hipEventRecord(se->ev[2], st)); se->has[1] = false; }   // (fused: the whole launch is booked on the sweep)
         if ((rc = dense_buffers(c, &dense, temperature, c->h_prog.needs_fk != 0)) != SGPMP_OK) return rc;
@@ -1225,7 +1239,8 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
                                  D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, acc_stats, costs,
                                  c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, &dense, &partials, &regen, &tail_ran));
         if (fused) { c->last_step_launches += 1; if (partials) c->dense_armed_steps += 1; if (regen.recipe != 0 || tail_ran) c->store_free_steps += 1; }
-        for (int i = 0; fused && i < c->h_prog.n_terms; ++i)
+        eet = fused ? ee_term_to_fold(c) : nullptr;
+        for (int i = 0; fused && !eet && i < c->h_prog.n_terms; ++i)
             if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) {
                 HIPCHK(launch_ee_goal(D.dtype, D.n_dof, D.traj_len, c->h_prog.terms[i], c->d_chain, samples,
                                       (long long)P * S, costs, c->d_costs64, st));
@@ -1254,12 +1269,13 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         const int slot = (int)(c->ms_step & 1);
         if (c->ms_buf && c->ms_used[slot] && hipEventQuery(c->ms_read[slot]) != hipSuccess)
             HIPCHK(hipStreamWaitEvent(st, c->ms_read[slot], 0));
+        const EeFoldHost eeh = {eet, c->d_chain, costs};
         HIPCHK(launch_update(D.dtype, D.n_dof, D.traj_len, P, S, c->d_costs64, SGPMP_F64, samples, means,
                              temperature, step_size, weights, grad, means_prev, acc_stats, st,
                              c->tg.comm_packet_event ? k4_done : nullptr, &pr, c->d_isw,
                              &isw_written, c->ms_buf ? c->ms_snap[slot] : nullptr,
                              (fused && partials) ? dense.part : nullptr, fused ? dense.nnz : nullptr, dense.threshold,
-                             (fused && regen.recipe != 0) ? &regen : nullptr));
+                             (fused && regen.recipe != 0) ? &regen : nullptr, eet ? &eeh : nullptr));
         if (!c->tg.comm_packet_event && k4_done) HIPCHK(hipEventRecord(k4_done, st));
         c->last_step_launches += 1;
         if (c->ms_buf) {

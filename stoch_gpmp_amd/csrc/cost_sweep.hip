@@ -519,66 +519,22 @@ hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const
 // CostGoal + EESE3DistanceField (cost_functions.py:308-321, fields.py:146-150): K * dist^2 on the last
 // waypoint, dist = SE3_distance(H_ee, H_target).  SE3_distance is third-party (torch_robotics) and
 // un-vendored; this build defines it as  w_pos |p - p*| + w_rot angle(R*^T R)  (DESIGN.md).
-template <typename real> struct EeTarget { real R[9], p[3], w_pos, w_rot, K; int square; };
-
-template <typename real>
-__device__ __forceinline__ real se3_distance(const real (&R)[9], const real (&p)[3], const EeTarget<real>& tg) {
-    using O = RealOps<real>;
-    const real dx = p[0] - tg.p[0], dy = p[1] - tg.p[1], dz = p[2] - tg.p[2];
-    const real dpos = O::sqrt_(dx * dx + dy * dy + dz * dz);
-    real tr = 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) tr += R[i] * tg.R[i];                  // trace(R*^T R)
-    const real c = fmin(fmax((tr - (real)1) * (real)0.5, (real)-1), (real)1);
-    return tg.w_pos * dpos + tg.w_rot * acos(c);
-}
-
+// (EeTarget, se3_distance and the row's cost ee_goal_add live in update_common.h: update_kernel evaluates the term itself when it
+// is the step's only end-effector goal -- one launch less per iteration)
 template <typename real>
 __global__ void ee_goal_kernel(int n, int T, const ChainDev* __restrict__ ch, const real* __restrict__ trajs,
                                long long batch, EeTarget<real> tg, real* __restrict__ costs,
                                double* __restrict__ costs64) {
-    using O = RealOps<real>;
+    __shared__ real jr[SGPMP_MAX_JOINTS * SGPMP_EE_JR];
+    __shared__ int ji[SGPMP_MAX_JOINTS * 2];
+    ee_stage_chain<real>(ch, jr, ji, threadIdx.x, blockDim.x);
+    const int nj = ch->n_joints;
+    __syncthreads();
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    const real* q = trajs + ((size_t)b * T + (T - 1)) * 2 * n;
-    real R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
-    for (int j = 0; j < ch->n_joints; ++j) {
-        const JointDev& J = ch->j[j];
-        real F[9], tt[3], Rn[9];
-        for (int i = 0; i < 9; ++i) F[i] = (real)J.R[i];
-        for (int i = 0; i < 3; ++i) tt[i] = (real)J.t[i];
-        for (int r = 0; r < 3; ++r) p[r] += R[r * 3 + 0] * tt[0] + R[r * 3 + 1] * tt[1] + R[r * 3 + 2] * tt[2];
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c)
-                Rn[r * 3 + c] = R[r * 3 + 0] * F[c] + R[r * 3 + 1] * F[3 + c] + R[r * 3 + 2] * F[6 + c];
-        if (J.revolute) {
-            real s, c;
-            O::sincos_(q[J.qidx], &s, &c);
-            for (int r = 0; r < 3; ++r) {
-                const real aa = Rn[r * 3 + 0], bb = Rn[r * 3 + 1];
-                Rn[r * 3 + 0] = aa * c + bb * s;
-                Rn[r * 3 + 1] = bb * c - aa * s;
-            }
-        }
-        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
-    }
-    real dist = se3_distance<real>(R, p, tg);
-    if (tg.square) dist = dist * dist;
-    const double add = (double)(tg.K * dist);
+    const double add = ee_goal_add<real>(jr, ji, nj, trajs + ((size_t)b * T + (T - 1)) * 2 * n, tg);
     if (costs) costs[b] = (real)((double)costs[b] + add);
     if (costs64) costs64[b] += add;
-}
-
-template <typename real>
-static EeTarget<real> make_ee_target(const CostTerm& t) {
-    EeTarget<real> g;
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) g.R[r * 3 + c] = (real)t.target[r * 4 + c];
-        g.p[r] = (real)t.target[r * 4 + 3];
-    }
-    g.w_pos = (real)t.w_pos; g.w_rot = (real)t.w_rot; g.K = (real)t.K;
-    g.square = (t.flags & SGPMP_FLAG_EE_SQUARE) ? 1 : 0;
-    return g;
 }
 
 hipError_t launch_ee_goal(int dtype, int n, int T, const CostTerm& term, const ChainDev* d_chain,

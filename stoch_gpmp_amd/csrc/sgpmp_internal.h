@@ -120,6 +120,7 @@ struct SgpmpToggles {
     int no_planar_tail;       // SGPMP_NO_PLANAR_TAIL       store-free steps of S = 64 planar problems: update_kernel (+ regeneration, if planar_store_free) instead of the update inside fused_planar_seg_kernel
     int planar_store_free;    // SGPMP_PLANAR_STORE_FREE    store-free steps (SGPMP_STEP_NO_SAMPLES) also for fused_planar_seg_kernel: measured SLOWER at config 2 (the launch saves 3.8 us, the update's regeneration costs 5.2: 42.4 k -> 40.0 k it/s, profiles/r05), hence opt-in
     int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
+    int no_ee_fold;           // SGPMP_NO_EE_FOLD           the step's end-effector goal term by a launch of ee_goal_kernel in front of update_kernel (rounds 1-4) instead of inside it
     int no_small_step;        // SGPMP_NO_SMALL_STEP        small steps through fused_step_kernel (one wave per item) instead of fused_step_small_kernel (one workgroup per item)
     long long small_step_items;   // SGPMP_SMALL_STEP_ITEMS     items (groups of 8 samples) up to which a step counts as small (0: default 256, one workgroup per CU)
     long long store_free_min_bytes;   // SGPMP_STORE_FREE_MIN_BYTES  a store-free step that REGENERATES rows in update_kernel is taken when one waypoint of all the step's samples (P S 2n floats) has at least this many bytes (0: the measured break-even, SGPMP_STORE_FREE_BREAK_EVEN; 1: always)
@@ -205,6 +206,12 @@ struct FusedDenseHost {
 // bytes of one waypoint of all samples of a step above which a regenerating store-free step is faster than a storing one
 // (cost_sweep.hip: launch_fused_step has the measurement)
 #define SGPMP_STORE_FREE_BREAK_EVEN 2800000LL
+// The step's end-effector goal term evaluated by update_kernel itself (update_common.h: EeFold) instead of ee_goal_kernel
+struct EeFoldHost {
+    const CostTerm* term;         // the SGPMP_COST_EE_GOAL term
+    const ChainDev* d_chain;      // DEVICE chain
+    void* costs;                  // [P][S] cost output of the step (context dtype) or null
+};
 // How update_kernel regenerates the rows a store-free step did not write (update_common.h: RegenArgs)
 struct RegenHost {
     int recipe;                   // 0: all rows are in memory; 1: fused_step_kernel's rows; 2: fused_planar_seg_kernel's (segments of L)
@@ -238,13 +245,14 @@ hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& prior, con
                              int n_particles, double temperature, void* out, double* zero_stats,
                              hipStream_t stream);
 
+bool update_ee_fold_fits(int dtype, int n, int T, int S);
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int costs_dtype,
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
                          hipStream_t stream, hipEvent_t done = nullptr, const PriorDev* isw_prior = nullptr,
                          void* isw_next = nullptr, bool* isw_written = nullptr, void* means_copy = nullptr,
                          const float* part = nullptr, unsigned* nnz = nullptr, unsigned nnz_threshold = 0,
-                         const RegenHost* regen = nullptr);
+                         const RegenHost* regen = nullptr, const EeFoldHost* ee = nullptr);
 
 hipError_t launch_stats_add(double* dst, const double* src, hipStream_t stream);
 hipError_t launch_mode_stats(int dtype, int n, int T, int P, long long p_offset, int nppg, int G, const void* means,

@@ -37,12 +37,17 @@ int update_regen_rows(int dtype, int n, int T, int S, int recipe) {
     return 0;
 }
 
+// does update_kernel's scratch leave room for the folded end-effector term (S more doubles)?
+bool update_ee_fold_fits(int dtype, int n, int T, int S) {
+    return ((update_base_lds(dtype, n, T, S) + 15) & ~(size_t)15) + (size_t)S * sizeof(double) + 256 <= 65536;
+}
+
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int costs_dtype,
                          const void* samples, void* means, double temperature, double step_size,
                          void* weights, void* grad, void* means_prev, double* stats,
                          hipStream_t stream, hipEvent_t done, const PriorDev* isw_prior, void* isw_next,
                          bool* isw_written, void* means_copy, const float* part, unsigned* nnz, unsigned nnz_threshold,
-                         const RegenHost* regen) {
+                         const RegenHost* regen, const EeFoldHost* ee) {
     const int M = T * 2 * n;
     size_t lds = (size_t)S * (sizeof(double) + sizeof(int));
     // (the softmax coefficients of the partials reuse the index array as doubles: 8 bytes per group of 8 rows fit its 4 S)
@@ -71,6 +76,13 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
         if (lds < regen_off) lds = regen_off;
         lds = regen_off + regen_lds_bytes(rg.recipe, T, n, R);
     }
+    // the step's end-effector goal term inside this kernel: S doubles behind everything else
+    unsigned ee_off = 0;
+    if (ee && ee->term) {
+        ee_off = (unsigned)((lds + 15) & ~(size_t)15);
+        lds = ee_off + (size_t)S * sizeof(double);
+        if (lds + 256 > 65536) return hipErrorInvalidValue;      // (the caller checks update_ee_fold_fits first)
+    }
     dim3 grid(P), block(256);
     // `done` (multi-GPU statistics): the event is signalled by this kernel's own dispatch packet
     // (hipExtLaunchKernelGGL stop event) instead of a separate barrier packet behind it
@@ -81,7 +93,8 @@ hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* cost
                           IswNext<REAL>{isw_prior ? (REAL*)isw_next : nullptr, isw_prior ? isw_prior->Qinv : nullptr, \
                                         isw_prior ? isw_prior->ks : 0., isw_prior ? isw_prior->kg : -1., \
                                         isw_prior ? isw_prior->dt : 0., n, isw_prior ? isw_prior->isotropic : 1}, \
-                          (REAL*)means_copy, (dtype == SGPMP_F32 && M % 4 == 0) ? part : (const float*)nullptr, (S + 7) / 8, nnz, nnz_threshold, rg, regen_off)
+                          (REAL*)means_copy, (dtype == SGPMP_F32 && M % 4 == 0) ? part : (const float*)nullptr, (S + 7) / 8, nnz, nnz_threshold, rg, regen_off, \
+                          (ee && ee->term) ? EeFold<REAL>{ee->d_chain, make_ee_target<REAL>(*ee->term), n, T, (REAL*)ee->costs} : EeFold<REAL>{nullptr, EeTarget<REAL>{}, n, T, nullptr}, ee_off)
     if (dtype == SGPMP_F64) {
         if (M % 4 == 0) UPD(double, double, 4); else UPD(double, double, 2);
     } else if (costs_dtype == SGPMP_F64) {

@@ -96,6 +96,95 @@ template <typename T> __device__ __forceinline__ T block_reduce(T v, T* scratch,
     return r;
 }
 
+// ---- end-effector goal term ------------------------------------------------------------------------------------------------
+// CostGoal + EESE3DistanceField (cost_functions.py:308-321, fields.py:146-150): K * dist^2 on the LAST waypoint, dist =
+// SE3_distance(H_ee, H_target).  SE3_distance is third-party (torch_robotics) and un-vendored; this build defines it as
+// w_pos |p - p*| + w_rot angle(R*^T R)  (DESIGN.md).  One trajectory per thread: the chain's frames down to the end effector.
+// Evaluated by ee_goal_kernel (cost_sweep.hip) behind a sweep -- or, inside sgpmp_step, by update_kernel itself before its
+// softmax (EeFold below: the same function, the same additions in the same order: bit-identical, one launch less).
+template <typename real> struct EeTarget { real R[9], p[3], w_pos, w_rot, K; int square; };
+__device__ __forceinline__ void sg_sincos(float a, float* s, float* c) { sincosf(a, s, c); }
+__device__ __forceinline__ void sg_sincos(double a, double* s, double* c) { sincos(a, s, c); }
+__device__ __forceinline__ float sg_sqrt(float a) { return sqrtf(a); }
+__device__ __forceinline__ double sg_sqrt(double a) { return sqrt(a); }
+
+template <typename real>
+__device__ __forceinline__ real se3_distance(const real (&R)[9], const real (&p)[3], const EeTarget<real>& tg) {
+    const real dx = p[0] - tg.p[0], dy = p[1] - tg.p[1], dz = p[2] - tg.p[2];
+    const real dpos = sg_sqrt(dx * dx + dy * dy + dz * dz);
+    real tr = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tr += R[i] * tg.R[i];                  // trace(R*^T R)
+    const real c = fmin(fmax((tr - (real)1) * (real)0.5, (real)-1), (real)1);
+    return tg.w_pos * dpos + tg.w_rot * acos(c);
+}
+
+// The chain's joint constants as the term reads them, staged ONCE per workgroup (LDS): the frames are a dependent chain joint
+// after joint, and with the constants behind a global (scalar) load in every trip each joint waited for memory -- 5 of the 12 us
+// of update_kernel with the term inside.  jr [joint][12] = R (row-major 3 x 3), t; ji [joint][2] = revolute, index into q.
+#define SGPMP_EE_JR 12
+template <typename real>
+__device__ __forceinline__ void ee_stage_chain(const ChainDev* __restrict__ ch, real* jr, int* ji, int tid, int nthr) {
+    const int nj = ch->n_joints;
+    for (int i = tid; i < nj * SGPMP_EE_JR; i += nthr) {
+        const int j = i / SGPMP_EE_JR, e = i - j * SGPMP_EE_JR;
+        jr[i] = e < 9 ? (real)ch->j[j].R[e] : (real)ch->j[j].t[e - 9];
+    }
+    for (int j = tid; j < nj; j += nthr) { ji[2 * j] = ch->j[j].revolute; ji[2 * j + 1] = ch->j[j].qidx; }
+}
+
+// the term's cost of the trajectory whose last waypoint's state is q [2n] (positions first)
+template <typename real>
+__device__ __forceinline__ double ee_goal_add(const real* jr, const int* ji, int nj, const real* __restrict__ q, const EeTarget<real>& tg) {
+    real R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    for (int j = 0; j < nj; ++j) {
+        const real* F = jr + j * SGPMP_EE_JR;
+        const real* tt = F + 9;
+        real Rn[9];
+        for (int r = 0; r < 3; ++r) p[r] += R[r * 3 + 0] * tt[0] + R[r * 3 + 1] * tt[1] + R[r * 3 + 2] * tt[2];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                Rn[r * 3 + c] = R[r * 3 + 0] * F[c] + R[r * 3 + 1] * F[3 + c] + R[r * 3 + 2] * F[6 + c];
+        if (ji[2 * j]) {
+            real s, c;
+            sg_sincos(q[ji[2 * j + 1]], &s, &c);
+            for (int r = 0; r < 3; ++r) {
+                const real aa = Rn[r * 3 + 0], bb = Rn[r * 3 + 1];
+                Rn[r * 3 + 0] = aa * c + bb * s;
+                Rn[r * 3 + 1] = bb * c - aa * s;
+            }
+        }
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    }
+    real dist = se3_distance<real>(R, p, tg);
+    if (tg.square) dist = dist * dist;
+    return (double)(tg.K * dist);
+}
+
+// update_kernel evaluates the step's end-effector goal term itself (sgpmp_step, one such term): what ee_goal_kernel would have
+// been launched with.  ch == null: no term.
+template <typename real> struct EeFold {
+    const ChainDev* ch;
+    EeTarget<real> tg;
+    int n, T;
+    real* costs;                // [P][S] the step's cost output in the context dtype, or null (the fp64 scratch update_kernel reads
+                                // its costs from stays WITHOUT the term: it is the step's own, nothing reads it after this kernel)
+};
+
+#ifndef __HIPCC_RTC__
+template <typename real>
+static inline EeTarget<real> make_ee_target(const CostTerm& t) {
+    EeTarget<real> g;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) g.R[r * 3 + c] = (real)t.target[r * 4 + c];
+        g.p[r] = (real)t.target[r * 4 + 3];
+    }
+    g.w_pos = (real)t.w_pos; g.w_rot = (real)t.w_rot; g.K = (real)t.K;
+    g.square = (t.flags & SGPMP_FLAG_EE_SQUARE) ? 1 : 0;
+    return g;
+}
+#endif
+
 // ---- store-free steps: the rows a particle's update needs, regenerated from their noise keys -----------------------------
 // A step whose samples nobody reads (SGPMP_STEP_NO_SAMPLES: iterations 1 .. K - 1 of optimize(opt_iters = K); the reference
 // returns the last iteration's tensors only, planner.py:289-317) does not write them: 470 MB per launch at config 3.  With the
@@ -212,7 +301,8 @@ __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_
                                                 double* __restrict__ stats, const IswNext<real>& nx, real* __restrict__ means_copy,
                                                 unsigned char* lds_raw, const real* mu_rd = nullptr,
                                                 const float* __restrict__ partials = nullptr, int gpp = 0, unsigned* __restrict__ nnz_out = nullptr,
-                                                const RegenArgs& rg = RegenArgs{}, bool regen = false, unsigned char* regen_lds = nullptr) {
+                                                const RegenArgs& rg = RegenArgs{}, bool regen = false, unsigned char* regen_lds = nullptr,
+                                                const double* c_add = nullptr) {
     // (rg by reference and a separate flag: a POINTER to the kernel-argument struct made every thread copy the struct to scratch
     // -- 72 bytes of private segment, 16 KB of scratch stores per workgroup: +2.6 us on update_kernel until it was found)
     typedef real vec __attribute__((ext_vector_type(VW)));
@@ -233,7 +323,8 @@ __device__ __forceinline__ void update_particle(int p, int M, int S, const cost_
     // softmax(-c / temperature) exactly as torch.softmax: exp(z - max z) / sum
     double zmax = -1.7976931348623157e308, csum = 0., cmin = 1.7976931348623157e308;
     for (int s = tid; s < S; s += nthr) {
-        const double cv = (double)c[s];
+        double cv = (double)c[s];
+        if (c_add) cv += c_add[s];                      // (LDS: a cost term the caller evaluated itself -- update_kernel's EeFold)
         const double z = -cv / temperature;
         w[s] = z;
         zmax = z > zmax ? z : zmax;
@@ -445,9 +536,27 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
               real* __restrict__ weights, real* __restrict__ grad, real* __restrict__ means_prev,
               double* __restrict__ stats, IswNext<real> nx, real* __restrict__ means_copy,
               const float* __restrict__ part, int gpp, unsigned* __restrict__ nnz, unsigned nnz_threshold,
-              RegenArgs rg, unsigned regen_lds_offset) {
+              RegenArgs rg, unsigned regen_lds_offset, EeFold<real> ee, unsigned ee_lds_offset) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int p = blockIdx.x;
+    // the step's end-effector goal term, evaluated here instead of by a launch of its own in front of this one: thread s has
+    // row s of the particle; the sums are ee_goal_kernel's (cost64 + add in update_particle; costs = (real)((double)costs + add))
+    double* c_add = nullptr;
+    if (ee.ch != nullptr) {
+        __shared__ real ee_jr[SGPMP_MAX_JOINTS * SGPMP_EE_JR];
+        __shared__ int ee_ji[SGPMP_MAX_JOINTS * 2];
+        ee_stage_chain<real>(ee.ch, ee_jr, ee_ji, threadIdx.x, blockDim.x);
+        const int nj = ee.ch->n_joints;
+        __syncthreads();
+        c_add = reinterpret_cast<double*>(lds_raw + ee_lds_offset);
+        for (int s = threadIdx.x; s < S; s += blockDim.x) {
+            const size_t b = (size_t)p * S + s;
+            const double add = ee_goal_add<real>(ee_jr, ee_ji, nj, samples + (b * ee.T + (ee.T - 1)) * 2 * ee.n, ee.tg);
+            c_add[s] = add;
+            if (ee.costs) ee.costs[b] = (real)((double)ee.costs[b] + add);
+        }
+        __syncthreads();
+    }
     // partials of this particle exist iff the fused launch of THIS step saw nnz[p] above the threshold: the same word,
     // read here before this particle's new count replaces it -- and, after a store-free step, its rows exist iff that word
     // was above the store threshold
@@ -457,6 +566,6 @@ update_kernel(int M, int S, const cost_t* __restrict__ costs, const real* __rest
     const bool regen = rg.recipe != 0 && !(prev > rg.store_threshold);
     update_particle<real, cost_t, VW>(p, M, S, costs + (size_t)p * S, samples + (size_t)p * S * M, (size_t)M, means, temperature,
                                       step_size, weights, grad, means_prev, stats, nx, means_copy, lds_raw, nullptr, part_p, gpp,
-                                      nnz ? nnz + p : nullptr, rg, regen, lds_raw + regen_lds_offset);
+                                      nnz ? nnz + p : nullptr, rg, regen, lds_raw + regen_lds_offset, c_add);
 }
 

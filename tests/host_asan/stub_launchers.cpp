@@ -58,6 +58,7 @@ hipError_t launch_cost(int dtype, int n, int T, const CostProgram&, const ChainD
     *picked = "stub_cost";
     return hipSuccess;
 }
+bool update_ee_fold_fits(int, int, int, int S) { return S <= 4096; }
 int update_regen_rows(int dtype, int, int T, int, int recipe) { return dtype == SGPMP_F32 && T % 2 == 0 && recipe == 1 ? 4 : 0; }
 int fused_step_regen_recipe(int dtype, int n, int T, const PriorDev& pr, const CostProgram& prog, const ChainDev& ch, int P, int off, int S, int ns,
                             const SgpmpToggles& tg, int* seg_len) {
@@ -107,9 +108,13 @@ hipError_t launch_is_weights(int dtype, int n, int T, const PriorDev& p, const v
 }
 hipError_t launch_update(int dtype, int n, int T, int P, int S, const void* costs, int cdt, const void* samples, void* means, double, double, void* weights,
                          void* grad, void* means_prev, double* stats, hipStream_t, hipEvent_t done, const PriorDev* ip, void* isw_next, bool* isw_written,
-                         void* means_copy, const float* part, unsigned* nnz, unsigned, const RegenHost* regen) {
+                         void* means_copy, const float* part, unsigned* nnz, unsigned, const RegenHost* regen, const EeFoldHost* ee) {
     const size_t M = (size_t)T * 2 * n, w = esz(dtype);
     rd(costs, (size_t)P * S * esz(cdt));
+    if (ee && ee->term) {                                      // the end-effector goal term inside the update: chain, rows, the cost output
+        rd(ee->d_chain, sizeof(ChainDev)); rd(samples, (size_t)P * S * M * w);
+        if (ee->costs) { rd(ee->costs, (size_t)P * S * w); wr(ee->costs, (size_t)P * S * w); }
+    }
     if (regen && regen->recipe) {                              // store-free step: tables instead of rows
         rd(regen->coef, sizeof(float) * T * 8);
         if (regen->recipe == 2) rd(regen->pre, sizeof(float) * T * 4);

@@ -1734,7 +1734,7 @@ def test_pipelined_optimize_equals_single_steps_bitwise(golden, kind):
         def mk(**kw):
             pl = hip_panda_planner(c, 32, 64 if two else 129, 128, F32, seed=41, goals=g,
                                    field_type="sdf" if two else "rbf", **kw)
-            if kind == "panda_ee_goal":          # CostGoal (end-effector term): its own kernel behind each half's launch
+            if kind == "panda_ee_goal":          # CostGoal (end-effector term): evaluated by each half's update kernel
                 from stoch_gpmp_amd.costs.cost_functions import CostGoal
                 from stoch_gpmp_amd.costs.fields import EESE3DistanceField
                 from oracle.fk import fk_all_links
@@ -1781,6 +1781,40 @@ def test_pipelined_optimize_equals_single_steps_bitwise(golden, kind):
     both(3, obs1)
     assert a._engine.pipeline_split_steps() == 12
     same()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_end_effector_goal_term_inside_the_update_kernel_bitwise(dtype):
+    """CostGoal (the reference's Panda example has it, panda_environment.py:90-96): inside sgpmp_step update_kernel evaluates the
+    term for its particle's rows itself, in front of its softmax -- ee_goal_kernel's function, its additions in its order --
+    instead of a launch of ee_goal_kernel between the fused launch and the update (option no_ee_fold: rounds 1-4).  One launch
+    less per iteration; costs, weights, means, gradient bit-identical, as single steps and as two chains, fp32 (fused launch)
+    and fp64 (three launches: the sweep adds the term itself, nothing to fold)."""
+    from stoch_gpmp_amd.costs.cost_functions import CostGoal
+    from stoch_gpmp_amd.costs.fields import EESE3DistanceField
+    from oracle.fk import fk_all_links
+    ta = F32 if dtype == "f32" else F64
+    H = fk_all_links(torch.tensor([[0.3, -0.5, 0.2, -1.9, 0.1, 1.6, 0.4]], dtype=torch.float64))[0, -1].clone()
+    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=3)).to(**ta)
+
+    def mk(nppg, S, T):
+        pl = hip_panda_planner(SC.PANDA, T, nppg, S, ta, seed=43)
+        pl.cost.cost_list.append(CostGoal(7, T, field=EESE3DistanceField(H, w_pos=1., w_rot=0.5, tensor_args=ta), sigma_goal=1e-2,
+                                          tensor_args=ta))
+        return pl
+    for nppg, S, T, calls in ((5, 32, 64, (1, 3, 1)), (129, 128, 32, (4, 1))):
+        a, b = mk(nppg, S, T), mk(nppg, S, T)
+        b._engine.set_option("no_ee_fold", 1)
+        for k in calls:
+            ra, rb = a.optimize(opt_iters=k, obstacle_spheres=sph), b.optimize(opt_iters=k, obstacle_spheres=sph)
+            for i, (x, y) in enumerate(zip(ra, rb)):
+                assert torch.equal(x, y), (k, i)
+            assert torch.equal(a._costs, b._costs) and torch.equal(a._weights_buf, b._weights_buf)
+            assert torch.equal(a.particle_means, b.particle_means) and torch.equal(a._grad, b._grad)
+        if dtype == "f32":
+            assert a._engine.last_step_launches() == 2 and b._engine.last_step_launches() == 3
+        else:
+            assert a._engine.last_step_launches() == b._engine.last_step_launches()
 
 
 @pytest.mark.parametrize("nppg,G,S,T", [(2, 2, 8, 16), (3, 2, 24, 48), (64, 2, 64, 64)])
