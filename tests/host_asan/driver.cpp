@@ -58,6 +58,10 @@ static void run_planner(int n, int T, int P, int P_global, int offset, int S, in
         f.kind = SGPMP_COST_SELF; f.sigma = 0.01; f.sigma2 = 0.03; descs.push_back(f);
         f.kind = SGPMP_COST_SPHERES; f.flags = SGPMP_FIELD_SDF | SGPMP_FLAG_SDF_CLAMP; f.sigma = 0.01; f.num_interpolate = 2; f.interp_lo = 1; f.interp_hi = 3;
         f.alpha[0] = 1. / 3; f.alpha[1] = 2. / 3; descs.push_back(f);
+        // + an end-effector goal term (CostGoal): inside sgpmp_step the update kernel evaluates it (EeFoldHost) -- unless SGPMP_NO_EE_FOLD
+        static const double target[16] = {1, 0, 0, 0.3, 0, 1, 0, 0.1, 0, 0, 1, 0.5, 0, 0, 0, 1};
+        sgpmp_cost_desc e; std::memset(&e, 0, sizeof(e));
+        e.kind = SGPMP_COST_EE_GOAL; e.sigma = 1e-2; e.data = target; e.p0 = 1.0; e.p1 = 0.5; descs.push_back(e);
     }
     CHECK(sgpmp_set_costs(c, descs.data(), (int)descs.size()));
     if (n >= 3) {

@@ -390,7 +390,8 @@ def test_host_bookkeeping_under_address_and_ub_sanitizers(tmp_path):
     base["ASAN_OPTIONS"] = "detect_leaks=1:abort_on_error=0"
     for extra in ({}, {"SGPMP_RCCL_LIB": fake}, {"SGPMP_RCCL_LIB": fake, "STUB_FUSED": "1", "STUB_EVENT_LAG": "1"},
                   {"STUB_FUSED": "1", "SGPMP_NO_STEP_PIPELINE": "1"}, {"STUB_FUSED": "1", "SGPMP_NO_DENSE_PARTIALS": "1"},
-                  {"STUB_FUSED": "1", "STUB_TAIL": "1"}, {"SGPMP_RCCL_LIB": fake, "STUB_FUSED": "1", "STUB_TAIL": "1"}):
+                  {"STUB_FUSED": "1", "STUB_TAIL": "1"}, {"SGPMP_RCCL_LIB": fake, "STUB_FUSED": "1", "STUB_TAIL": "1"},
+                  {"STUB_FUSED": "1", "SGPMP_NO_EE_FOLD": "1"}):
         p = subprocess.run([exe], env=dict(base, **extra), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "HOST_ASAN_OK" in p.stdout, (extra, p.stdout[-1000:], p.stderr[-4000:])
         assert "Sanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
