@@ -137,7 +137,8 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * no_planar_tail (those steps with update_kernel behind the launch instead),
  * no_ee_fold (the step's end-effector goal term by a launch of ee_goal_kernel in front of update_kernel, as in rounds 1-4, instead of
  * inside update_kernel: same numbers, one launch more),
- * no_small_step (steps of up to small_step_items items -- groups of 8 samples; default 256, one per CU -- go out as
+ * no_small_step (steps of up to small_step_items items -- groups of 8 samples; default 512, two per CU, 256 for shapes off the
+ * launch's 8 x 16 grid -- go out as
  * fused_step_small_kernel, one WORKGROUP per item with its four waves on the item's time chunks side by side, bit-identical to
  * the one-wave-per-item launch and about twice as fast where every wave sits alone on its SIMD; 1: always fused_step_kernel),
  * small_step_items (count),

@@ -201,7 +201,7 @@ static std::string translation_unit(const RtcChain& c) {
           "extern \"C\" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGPMP_FUSED_WAVES, SGPMP_FUSED_WAVES)))\n"
           "sgpmp_rtc_fused_rag(const CostArgs<float> a, const FlatProg<float> F, const FusedArgs s) {\n"
           "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, false, true>(a, F, s);\n}\n"
-          "extern \"C\" __global__ void __launch_bounds__(256)\n"
+          "extern \"C\" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))\n"
           "sgpmp_rtc_fused_small(const CostArgs<float> a, const FlatProg<float> F, const FusedArgs s) {\n"
           "    chunked_body<ChainCode_rt::N, ChainCode_rt, SGPMP_RTC_FT, false, false, true>(a, F, s);\n}\n"
           "extern \"C\" __global__ void __launch_bounds__(256)\n"

@@ -278,15 +278,17 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     const int ft = F.has_sph ? (F.sph.flags & 15) : SGPMP_FIELD_RBF;
     // a SMALL step -- fewer items than SIMDs: every wave of the one-wave-per-item launch would sit alone on its SIMD for as long as
     // one item takes one wave (~20 us) -- goes out with one WORKGROUP per item instead, its four waves on the item's chunks side
-    // by side (fused_step.inc: LAT; same samples and costs, bit for bit).  Up to one workgroup per CU: beyond, its 260 registers
-    // and 55 KB of LDS per workgroup make a second round of what the other launch does in one (tools/small_step_sizes.py).
-    const long long small_items = tg.small_step_items > 0 ? tg.small_step_items : 256;
+    // by side (fused_step.inc: LAT; same samples and costs, bit for bit).  Up to two workgroups per CU for shapes on the launch's
+    // 8 x 16 grid (253 registers, 57 KB of LDS: two per SIMD set), one for the others (the masked instantiation needs 262 registers):
+    // beyond, a second round of workgroups costs what the other launch does in one (tools/small_step_sizes.py).
+    const bool srag = S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0;           // (the instantiation fused_step_kernel would take)
+    const long long small_items = tg.small_step_items > 0 ? tg.small_step_items : srag ? 256 : 512;
     // (judged on the WHOLE problem -- all ranks' particles, both halves of a pipelined step -- so that a shard takes the launch its
     // unsharded run takes)
     const long long items_global = (long long)(dense && dense->particles_global > 0 ? dense->particles_global : P) * fs.gpp;
     const bool small = !tg.no_small_step && items_global <= small_items && (T + SGPMP_FUSED_TC - 1) / SGPMP_FUSED_TC <= 16;
     if (h_chain.plan.codegen_id == 2) {           // this chain's kernels were compiled at run time (chain_rtc.hip)
-        hipFunction_t f = rtc_kernel((RtcChain*)h_chain.rtc, ft, false, S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0, small);
+        hipFunction_t f = rtc_kernel((RtcChain*)h_chain.rtc, ft, false, srag, small);
         if (!f) return hipSuccess;                // (not launched: the caller takes the two-launch path)
         void* args[] = {&a, &F, &fs};
         const hipError_t e = rtc_launch(f, small ? (unsigned)fs.nitems : (unsigned)blocks, (unsigned)fused_wave_dyn_lds(n_spheres, F.has_goal ? F.goal.dim0 : 0), stream, args, nullptr);
@@ -303,7 +305,6 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     // S, T off the launch's grid of 8 rows x 16 waypoints: the instantiation with the masks (fused_step.inc: RAG)
     if (small) {
 #define SMALL_LAUNCH(FT_, RAG_) hipLaunchKernelGGL((fused_step_small_kernel<CCp::N, CCp, FT_, RAG_>), dim3((unsigned)fs.nitems), dim3(256), (unsigned)dyn, stream, a, F, fs)
-        const bool srag = S % SGPMP_FUSED_SPW != 0 || T % SGPMP_FUSED_TC != 0;       // (the instantiation fused_step_kernel would take)
         if (ft == SGPMP_FIELD_RBF) { if (srag) SMALL_LAUNCH(SGPMP_FIELD_RBF, true); else SMALL_LAUNCH(SGPMP_FIELD_RBF, false); }
         else if (ft == SGPMP_FIELD_SDF) { if (srag) SMALL_LAUNCH(SGPMP_FIELD_SDF, true); else SMALL_LAUNCH(SGPMP_FIELD_SDF, false); }
         else { if (srag) SMALL_LAUNCH(SGPMP_FIELD_OCCUPANCY, true); else SMALL_LAUNCH(SGPMP_FIELD_OCCUPANCY, false); }

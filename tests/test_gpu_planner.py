@@ -1227,7 +1227,7 @@ def test_small_step_launch_equals_the_one_wave_per_item_launch_bitwise(shape):
         assert a._engine.dense_armed_steps() > 0 and int(a._engine.row_counts().max()) > 16
     if shape == "store_free":
         assert a._engine.store_free_steps() == 7 and b._engine.store_free_steps() == 7
-    # above the size bar the step is the one-wave-per-item launch again (256 items by default; here: 3)
+    # above the size bar the step is the one-wave-per-item launch again (512 items by default -- 256 off the 8 x 16 grid; here: 3)
     a._engine.set_option("small_step_items", 3)
     a.optimize(opt_iters=1, obstacle_spheres=sph)
     assert a._engine.last_cost_kernel() == ("fused_step_small_kernel" if shape == "one_particle" else "fused_step_kernel")
