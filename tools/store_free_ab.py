@@ -51,11 +51,14 @@ def main():
                 el = bench.time_loop(torch, pl, obs, steps, 10)
                 rates[m].append(steps / el)
         row = {m: {"it_per_s": [round(r, 1) for r in rates[m]], "best_ms_per_step": round(1e3 / max(rates[m]), 4)} for m in pls}
+        # (compared HERE: both planners have run the same iterations; the event passes below run on one of them only -- round 5's first
+        # records compared after them and said "same_means": false for what tests/test_gpu_planner.py::test_store_free_* prove bit-identical)
+        same = bool(torch.equal(pls["storing"][0].particle_means, pls["store_free"][0].particle_means))
         pl, obs = pls["store_free"]
         row["kernel_us_event_timed"] = {"storing": event_pass(pl, obs, 60, False), "store_free": event_pass(pl, obs, 60, True)}
         row["kernel"] = pl._engine.last_cost_kernel()
         row["store_free_steps"] = pl._engine.store_free_steps()
-        row["same_means"] = bool(torch.equal(pls["storing"][0].particle_means, pls["store_free"][0].particle_means))
+        row["same_means"] = same
         out[name] = row
         print(name, json.dumps(row), flush=True)
         del pls, pl
