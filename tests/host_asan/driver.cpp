@@ -162,13 +162,17 @@ static void run_planner(int n, int T, int P, int P_global, int offset, int S, in
         CHECK(sgpmp_get_prior(c, SGPMP_PRIOR_INIT, nullptr, G_.data(), H_.data()));
     }
     EXPECT(sgpmp_set_option(c, "no_such_switch", 1), SGPMP_EINVAL);
-    for (const char* name : {"no_fused_step", "no_step_pipeline", "no_dense_partials", "gpmp_cholesky", "comm_packet_event"}) {
+    for (const char* name : {"no_fused_step", "no_step_pipeline", "no_dense_partials", "gpmp_cholesky", "comm_packet_event", "no_ee_fold", "no_small_step",
+                             "planar_store_free", "no_planar_tail"}) {
         CHECK(sgpmp_set_option(c, name, 1));
         step(400, 0);
         CHECK(sgpmp_set_option(c, name, 0));
     }
     CHECK(sgpmp_set_option(c, "k3_blocks", 64));
     CHECK(sgpmp_set_option(c, "pipe_split", 5));
+    CHECK(sgpmp_set_option(c, "small_step_items", 64));
+    CHECK(sgpmp_set_option(c, "store_free_min_bytes", 1));
+    step(401, SGPMP_STEP_NO_SAMPLES);
     sgpmp_destroy(c);
 }
 
