@@ -11,8 +11,13 @@ nsph = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 pl = W.hip_panda_planner(W.PANDA, T, P, S, ta, seed=0, pipeline_steps=False)
 sph = torch.as_tensor(W.panda_spheres(num=nsph)).to(**ta)
 pl._engine.set_option("no_step_pipeline", 1)
+UNREAD = os.environ.get("FUSED_STAMPS_STORE_FREE") == "1"      # the last stamped step as a store-free one (no sample stores)
 for _ in range(30):
     pl.optimize(opt_iters=1, obstacle_spheres=sph)
+if UNREAD:
+    pl._engine.set_option("store_free_min_bytes", 1)
+    pl.step(_samples_unread=True, obstacle_spheres=sph)
+    print("store-free step:", pl._engine.store_free_steps())
 torch.cuda.synchronize()
 assert pl._engine.last_cost_kernel() in ("fused_step_kernel", "fused_step_small_kernel")
 print("kernel:", pl._engine.last_cost_kernel())
