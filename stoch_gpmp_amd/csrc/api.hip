@@ -127,6 +127,16 @@ static void toggles_from_env(SgpmpToggles& tg) {
     if (const char* e = getenv("SGPMP_SMALL_STEP_ITEMS")) tg.small_step_items = atoll(e);
 }
 
+#ifdef SGPMP_HOST_TIMING      // diagnostic build (tools/host_step_cost.py): host nanoseconds of sgpmp_step's segments, printed by sgpmp_destroy
+#include <ctime>
+static double g_ht[8]; static long long g_htn;
+static inline double ht_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e9 * (double)t.tv_sec + (double)t.tv_nsec; }
+#define HT_START() double ht_t = ht_now()
+#define HT(i) do { const double n_ = ht_now(); g_ht[i] += n_ - ht_t; ht_t = n_; } while (0)
+#else
+#define HT_START() do {} while (0)
+#define HT(i) do {} while (0)
+#endif
 extern "C" int sgpmp_abi_version(void) { return SGPMP_ABI_VERSION; }
 extern "C" int sgpmp_philox_rounds(void) { return SGPMP_PHILOX_ROUNDS; }
 extern "C" const char* sgpmp_last_error(void) { return g_err.c_str(); }
@@ -344,6 +354,13 @@ extern "C" int sgpmp_allgather_means(sgpmp_ctx* c, const void* local_means, void
 }
 
 extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
+#ifdef SGPMP_HOST_TIMING
+    if (g_htn) {
+        std::fprintf(stderr, "[host timing] %lld steps: checks+split %.2f us, eligibility %.2f, fused launch %.2f, update launch %.2f\n", g_htn,
+                     1e-3 * g_ht[0] / g_htn, 1e-3 * g_ht[1] / g_htn, 1e-3 * g_ht[2] / g_htn, 1e-3 * g_ht[3] / g_htn);
+        g_htn = 0; for (double& v : g_ht) v = 0.;
+    }
+#endif
     if (!c) return;
     comm_destroy(c->comm);
     free_prior(c->prior[0]);
@@ -1128,6 +1145,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
                           void* grad, void* means_prev, const void* spheres, int n_spheres, double temperature,
                           double step_size, double* stats, int flags, void* stream) {
     if (!c) return fail(SGPMP_EINVAL, "sgpmp_step: null context");
+    HT_START();
     if (c->dims.num_particles == 0) {
         // A rank whose shard is empty (more ranks than particles) has no kernels to run, but the per-step
         // statistics all-reduce is a collective: it contributes a zeroed slot, or the other ranks' all-reduce
@@ -1192,6 +1210,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
                               (char*)means_prev, spheres, n_spheres, temperature, step_size, stats, flags, st);
         if ((rc = pipe_join(c, st)) != SGPMP_OK) return rc;      // an ordinary step: after the chains
     }
+    HT(0);                                                       // checks + the pipeline's split decision
     StepEvents* se = nullptr;
     if (c->profiling) {
         c->events.emplace_back();
@@ -1213,6 +1232,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     // K5 is skipped when the previous step's update kernel already prepared the weights for exactly these
     // means (the caller vouches with SGPMP_STEP_MEANS_KEPT that nothing else wrote them since); the fused
     // launch then zeroes the statistics itself
+    HT(1);                                                       // eligibility
     const bool prepared = (flags & SGPMP_STEP_MEANS_KEPT) && c->isw_ready && c->isw_means == means &&
                           c->isw_temperature == temperature;
     c->isw_ready = false;
@@ -1256,6 +1276,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
                            c->d_isw, S, pr.dt, costs, c->d_costs64, st, c->tg, &c->last_cost_kernel));
         c->last_step_launches += 2;
     }
+    HT(2);                                                       // the fused launch (or sampler + sweep)
     if (se) HIPCHK(hipEventRecord(se->ev[3], st));
     // (the update also prepares the NEXT step's importance-sampling weights -- unless, as a kernel of its own, the new
     // means do not fit its LDS beside the weights: launch_update decides)
@@ -1283,6 +1304,10 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
             c->ms_step += 1;
         }
     }
+    HT(3);                                                       // the update launch
+#ifdef SGPMP_HOST_TIMING
+    g_htn += 1;
+#endif
     c->isw_ready = isw_written; c->isw_means = means; c->isw_temperature = temperature;
     if (se) { HIPCHK(hipEventRecord(se->ev[4], st)); se->has[3] = !tail_ran; }
     // multi-GPU: sum the statistics over all ranks on the side stream (never gates the next step)
