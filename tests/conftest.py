@@ -13,7 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # the parity tests run small shapes and want the store-free form all the same.  Read once per context, at sgpmp_create;
 # test_store_free_steps_are_taken_where_they_pay puts the default back.
 os.environ.setdefault("SGPMP_STORE_FREE_MIN_BYTES", "1")
-# Likewise the launch of small steps: up to 1024 items a Panda step goes out as fused_step_small_kernel (one workgroup per item;
+# Likewise the launch of small steps: up to 512 items a Panda step goes out as fused_step_small_kernel (one workgroup per item;
 # bit-identical).  The parity tests are small by necessity and are there for the kernel the big configurations run, so they keep
 # it; test_small_step_launch_* compare the two and run the small one against the oracle.
 os.environ.setdefault("SGPMP_NO_SMALL_STEP", "1")
