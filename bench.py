@@ -3,33 +3,34 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is ONE planner iteration = one body of the loop at reference planner.py:289-299 (draw S
-samples per particle, evaluate the composite cost, softmax-reweight, update the particle means) on
-synthetic data.  Workload at N = 1: BASELINE.json configs[2] -- Panda 7-DoF (14-D state), 1024
-particles x 128 samples x 64 waypoints, 5 synthetic sphere obstacles (rbf field) + self-collision,
-fp32 compute with the prior factored in fp64.  At N > 1 every rank holds 1024 particles of a
-(1024 N)-particle problem (configs[3] at N = 8: weak scaling, particles sharded, no data-path
-collective; a [64,4]-double statistics all-reduce over RCCL per iteration, enqueued by sgpmp_step).
+A step is ONE planner iteration = one body of the loop at reference planner.py:289-299 (draw S samples per
+particle, evaluate the composite cost, softmax-reweight, update the particle means) on synthetic data.
+Workload at N = 1: BASELINE.json configs[2] -- Panda 7-DoF (14-D state), 1024 particles x 128 samples x 64
+waypoints, 5 synthetic sphere obstacles (rbf field) + self-collision, fp32 compute, prior factored in fp64.
+At N > 1 every rank holds 1024 particles of a (1024 N)-particle problem (configs[3] at N = 8: weak scaling,
+particles sharded, no data-path collective; a [64,4]-double statistics all-reduce over RCCL per iteration,
+enqueued by sgpmp_step).  With N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks
+BEFORE anything touches the GPU and relays rank 0's line and the exit code.
 
-With N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks
-(`python -m torch.distributed.run --nproc-per-node N bench.py ...`) BEFORE anything touches the GPU
-and relays rank 0's JSON line and the exit code; under a launcher (WORLD_SIZE set) it is a rank.
+Output (rank 0):
+  * stdout: ONE compact JSON line, < 4 KB, strict JSON (`compact_line`, tests/test_cpu_host.py holds it to
+    that): value / ms_per_step (storing mode: every iteration writes its samples -- the mode SURVEY.md 8(d)'s
+    algorithmic bytes are defined on), roofline, cpu_baseline, single_iteration_calls, store_free, parity,
+    rccl, one short row per other single-GPU configuration;
+  * bench_detail.json beside this script (and on stderr): everything else -- per-kernel event timings, the
+    counters' sources, the measured CPU points, per-pass times.
 
-Prints one JSON line (rank 0).  `value` / `roofline` are the STORING mode -- every iteration writes its samples,
-the mode SURVEY.md 8(d)'s algorithmic bytes are defined on: `roofline.frac` prices the dominant kernel against
-the HBM peak using those bytes over the TIMED pass's ms_per_step (a lower bound: the step also holds the update
-kernel), `roofline.bound` says what really bounds the launch (the vector ALU: `valu_frac` = its instruction-issue
-floor / the launch's duration; `moved_frac` = bytes the counters saw / time / HBM peak); the launch's own
-average duration measured with HIP events on the launch stream is in `roofline_detail`.  `store_free` reports the
-product's default inside optimize(opt_iters=K) since round 5 -- iterations 1 .. K - 1 do not write their samples,
-bit-identical results -- beside it, never instead of it; `parity` is a free-running K = 10 comparison with the fp64 CPU oracle made by this run; `cpu_baseline` times the reference-equivalent PyTorch-CPU
-oracle on a bounded sample of the same workload on this box's host cores, `cpu_fair` the banded fp64
-restatement (what a careful CPU implementation of the same mathematics costs).  `other_configs` are BASELINE.json's other
-single-GPU configurations; `reference_examples` the reference's own two example problems at their own sizes, one
-optimize(opt_iters=1) per call as its scripts run them (microseconds per call).
+`roofline.frac` = SURVEY 8(d)'s algorithmic bytes of the dominant launch / the TIMED pass's ms_per_step / 8 TB/s
+(a lower bound: the step also holds the update kernel); `launch_ms` is the launch's own average duration from
+a separate pass with HIP events on the launch stream and `frac_launch` the fraction it gives; `bound` says
+what really bounds the launch (`valu_frac` = the vector ALU's instruction-issue floor / launch_ms; `moved_frac`
+= bytes the committed rocprofv3 counters saw / launch_ms / 8 TB/s; `traffic` = those bytes per launch).
+The variants that used to ride in this line (sdf field, 64 spheres, fp64 shape, the reference's example sizes,
+the banded "fair CPU" figure, the all-host-cores point) are tools/bench_variants.py -> profiles/rNN/.
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -42,11 +43,15 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0       # same guide: 6.29 TB/s measured float4 copy (79 % of spec)
-PROFILE_ROUNDS = ("r05", "r04", "r03")   # committed rocprofv3 --pmc sets (traffic / VALU figures quoted beside the live timings): newest first
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03")   # committed rocprofv3 --pmc sets, newest first
+LINE_LIMIT = 4096           # the driver parses the whole stdout line or nothing (round-5 verdict): keep it small
+DETAIL_FILE = "bench_detail.json"
 GOALS4_PLANAR = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]]
+PANDA_GOALS = [[0.5, 0.2, 0.3, -1.5, 0.1, 2.0, 0.3], [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5],
+               [0.9, -0.2, 0.4, -1.1, -0.3, 1.9, 0.8], [-0.8, 0.1, 0.6, -2.4, 0.4, 2.6, -0.2]]
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -64,17 +69,19 @@ def parse():
                          "(config 5's per-GPU share: --goals 4 --particles 512 --samples 256 --traj-len 128 --shard-of 3,8)")
     ap.add_argument("--store-free", action="store_true",
                     help="the MAIN planner runs optimize(opt_iters=K) store-free (the product's default) and the event pass "
-                         "times store-free launches: for rocprofv3 runs of that mode (tools/profile_config.sh); the line's "
-                         "`mode` says so.  Without it value / roofline are the storing mode and `store_free` reports the other.")
+                         "times store-free launches: for rocprofv3 runs of that mode (tools/profile_config.sh)")
     ap.add_argument("--single-iteration-calls", action="store_true",
                     help="time K calls of optimize(opt_iters=1) instead of one optimize(opt_iters=K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-store-free", action="store_true", help="skip the store-free leg (a second planner of the same workload)")
-    ap.add_argument("--no-parity", action="store_true", help="skip the free-running K = 10 parity leg (fp64 CPU oracle, ~10 s)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the free-running K = 10 parity leg (fp64 CPU oracle)")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-sweep-alone", action="store_true", help="skip the stand-alone sampler / sweep event pass")
     ap.add_argument("--cpu-particles", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=2)
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the cpu_baseline leg")
+    ap.add_argument("--detail", default=os.path.join(ROOT, DETAIL_FILE), help="where the detailed record goes")
+    return ap.parse_args(argv)
 
 
 # --------------------------------------------------------------------------------------- N > 1 launch
@@ -101,11 +108,97 @@ def self_launch(args):
     return proc.returncode if proc.returncode != 0 or line is not None else 1
 
 
+# --------------------------------------------------------------------------------------- the line
+def _clean(o, digits=None):
+    """JSON-safe copy: NaN / Infinity -> None (strict JSON), floats optionally rounded to `digits` significant digits."""
+    if isinstance(o, float):
+        if not math.isfinite(o):
+            return None
+        if digits and o != 0.0:
+            return float(f"{o:.{digits}g}")
+        return o
+    if isinstance(o, dict):
+        return {str(k): _clean(v, digits) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_clean(v, digits) for v in o]
+    if isinstance(o, (str, int, bool)) or o is None:
+        return o
+    return str(o)
+
+
+def _pick(d, keys, digits=5):
+    return None if not d else {k: _clean(d.get(k), digits) for k in keys if k in d}
+
+
+def compact_line(full):
+    """The ONE stdout line from the detailed record: the contract keys, short, strict JSON, < LINE_LIMIT characters.
+    Optional parts are dropped (last first) if a run ever grows past the limit -- the contract keys never are."""
+    roof = full.get("roofline") or {}
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    out["config"] = {k: cfg.get(k) for k in ("workload", "particles_total", "particles_per_gpu", "samples", "traj_len",
+                                             "parallelism") if k in cfg}
+    out["roofline"] = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "valu_frac",
+                                   "moved_frac", "launch_ms", "frac_launch"))
+    out["cpu_baseline"] = _pick(full.get("cpu_baseline"), ("value", "unit", "cores", "kind", "sample"))
+    optional = []                                    # (key, value): dropped from the END if the line is too long
+
+    def opt(key, val):
+        if val is not None:
+            out[key] = val
+            optional.append(key)
+    opt("speedup_vs_cpu_baseline", _clean(full.get("speedup_vs_cpu_baseline"), 4))
+    opt("single_iteration_calls", _pick(full.get("single_iteration_calls"), ("iterations_per_s", "ms_per_step")))
+    opt("store_free", _pick(full.get("store_free"), ("iterations_per_s", "ms_per_step", "valu_frac", "launch_ms")))
+    opt("parity", _pick(full.get("parity"), ("ok", "means_rel_err_max_after_K", "cost_rel_err_max_while_tracking",
+                                              "iterations", "tolerance_on_means"), 3))
+    opt("rccl", _pick(full.get("rccl"), ("ranks", "rank", "version")))
+    opt("shared_gpu_test_double", full.get("shared_gpu_test_double"))
+    opt("per_rank_iterations_per_s", full.get("per_rank_iterations_per_s"))
+    opt("last_iteration", _clean(full.get("last_iteration")))
+    opt("sweep_alone_frac", _clean((full.get("sweep_alone") or {}).get("frac"), 4))
+    opt("sweep_alone", _pick(full.get("sweep_alone"), ("kernel", "launch_ms", "frac", "sampler_kernel", "sampler_launch_ms",
+                                                       "sampler_frac"), 4))
+    opt("mode", full.get("mode"))
+    opt("field", full.get("field"))
+    opt("launches_per_iteration", full.get("launches_per_iteration"))
+    rows = []
+    for r in full.get("other_configs") or []:
+        rr = r.get("roofline") or {}
+        rows.append(_clean({"config": r.get("config"), "it_per_s": r.get("iterations_per_s"),
+                            "store_free_it_per_s": (r.get("store_free") or {}).get("iterations_per_s"),
+                            "frac": rr.get("frac"), "bound": rr.get("bound"), "kernel": r.get("cost_kernel"),
+                            "dtype": r.get("dtype")}, 4))
+    opt("other_configs", rows or None)
+    opt("detail", full.get("detail_file"))
+    out = _clean(out)
+    line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    while len(line) >= LINE_LIMIT and optional:
+        out.pop(optional.pop())
+        line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    assert len(line) < LINE_LIMIT, len(line)
+    return line
+
+
+def emit(full, json_fd, detail_path):
+    """Write the detailed record beside the script (and to stderr), the compact line to the saved stdout."""
+    full = dict(full)
+    full["detail_file"] = os.path.basename(detail_path) if detail_path else None
+    try:
+        if detail_path:
+            with open(detail_path, "w") as f:
+                json.dump(_clean(full), f, indent=1, allow_nan=False)
+    except OSError as e:                                  # (a read-only tree must not cost the line)
+        full["detail_file"] = None
+        print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+    print("bench.py detail: " + json.dumps(_clean(full), allow_nan=False), file=sys.stderr)
+    line = compact_line(full)
+    os.write(json_fd, (line + "\n").encode())
+    return line
+
+
 # --------------------------------------------------------------------------------------- workloads
-PANDA_GOALS = [[0.5, 0.2, 0.3, -1.5, 0.1, 2.0, 0.3], [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5],
-               [0.9, -0.2, 0.4, -1.1, -0.3, 1.9, 0.8], [-0.8, 0.1, 0.6, -2.4, 0.4, 2.6, -0.2]]
-
-
 def build_planner(torch, workload, P_local, S, T, dtype, dev, rank=0, world=1, field="rbf", spheres=5,
                   goals=1, shard_of=None, seed=0, **kw):
     """-> (planner, observation dict, workload name).  `shard_of` = (rank, world_size) builds one shard
@@ -133,24 +226,6 @@ def build_planner(torch, workload, P_local, S, T, dtype, dev, rank=0, world=1, f
     return pl, obs, name
 
 
-def box_copy_bandwidth():
-    """This box's own streaming figures (tools/membw.hip: 470 MB tensors, float4 per lane): GB/s of a device-to-device
-    copy (read + write) -- the denominator SURVEY.md 8d asks for beside the 8 TB/s spec.  None if the binary is absent."""
-    exe = os.path.join(ROOT, "tools", "membw")
-    if not os.path.exists(exe):
-        return None
-    try:
-        out = subprocess.run([exe], capture_output=True, text=True, timeout=60).stdout
-        best = {}
-        for ln in out.splitlines():
-            f = ln.split()
-            if len(f) >= 6 and f[0] in ("fill", "read", "copy") and f[-1] == "TB/s":
-                best[f[0]] = max(best.get(f[0], 0.0), float(f[-2]) * 1e3)
-        return best or None
-    except Exception:
-        return None
-
-
 def profiled(config_key, kernel):
     """HBM traffic / VALU figures of `kernel` from the committed rocprofv3 --pmc passes of THIS configuration
     (profiles/<round>/traffic_by_config.json, assembled by tools/collect_traffic.py); None when not profiled."""
@@ -162,28 +237,23 @@ def profiled(config_key, kernel):
         if not prof:
             continue
         k = prof["kernels"].get(kernel.split("<")[0].split(" ")[0])
-        src = f"profiles/{rnd}/{prof.get('files', '')} (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE; {prof.get('command', '')})"
-        return k, src
+        if not k:
+            continue
+        return k, f"profiles/{rnd}/{prof.get('files', '')} ({prof.get('command', '')})"
     return None, None
 
 
-def roofline_of(kernel, kernel_ms, N_elems, w, costs_bytes, fused, config_key, copy_gbs, step_ms=None, step_mode="", field=None):
-    """`roofline` object of one configuration.  Algorithmic bytes per launch = SURVEY.md 8(d): N w (sampler write) + N w
-    (sweep read) + P S 8 for the fused launch, N w + P S 8 for the sweep alone.
-    `achieved` / `frac` divide them by the TIMED pass's ms_per_step (the whole iteration: this launch, the update kernel
-    and whatever the schedule does not hide) -- a lower bound of the launch's own figure that needs no second timing mode
-    (round-3 verdict: the event pass runs one launch chain with events between the kernels, the timed pass two
-    particle-half chains).  The launch's own average duration from the event pass, and the fraction it gives, are in
-    roofline_detail ("event_pass")."""
+def roofline_of(kernel, kernel_ms, N_elems, w, costs_bytes, fused, config_key, step_ms=None):
+    """(`roofline`, detail) of one configuration.  Algorithmic bytes per launch = SURVEY.md 8(d): N w (sampler write) + N w
+    (sweep read) + P S 8 for the fused launch, N w + P S 8 for the sweep alone.  `achieved` / `frac` divide them by the
+    TIMED pass's ms_per_step (round-3 verdict: a bound nobody can dispute -- the event pass runs one launch chain with
+    events between the kernels, the timed pass two particle-half chains); `launch_ms` / `frac_launch`: the launch's own
+    average duration from the event pass.  `bound` = "valu" when the committed counters of this configuration show the
+    vector ALU busy > 70 % of the launch while the bytes they saw are < 60 % of the algorithmic ones."""
     alg = (2 if fused else 1) * N_elems * w + costs_bytes
     t_ms = step_ms if step_ms else kernel_ms
     achieved = alg / (t_ms * 1e-3) / 1e9
-    ev = alg / (kernel_ms * 1e-3) / 1e9
     k, src = profiled(config_key, kernel)
-    # what bounds the launch (round-4 verdict): the vector ALU when the committed counters of this configuration show it busy
-    # > 70 % of the launch while the bytes they saw are < 60 % of the algorithmic ones -- the 8(d) fraction `frac` stays (it is
-    # what north_star's 40 % clause is about), `valu_frac` = instruction-issue floor / this run's launch duration and
-    # `moved_frac` = counter bytes / this run's launch duration / HBM peak say where the launch really stands
     moved = k.get("bytes") if k else None
     valu_busy = k.get("valu_busy_frac_under_profiler") if k else None
     bound = "valu" if (valu_busy is not None and moved is not None and valu_busy > 0.7 and moved / alg < 0.6) else "hbm"
@@ -191,21 +261,11 @@ def roofline_of(kernel, kernel_ms, N_elems, w, costs_bytes, fused, config_key, c
          "frac": achieved / HBM_PEAK_GBS, "traffic": moved,
          "valu_frac": (k["valu_floor_ms"] / kernel_ms) if (k and "valu_floor_ms" in k) else None,
          "moved_frac": (moved / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if moved else None,
-         "valu_busy_under_profiler": valu_busy, "field": field, "launch_ms": kernel_ms,
-         "timed_by": ("ms_per_step of the timed pass (" + step_mode + ")") if step_ms else "HIP events around the launch"}
-    detail = {"algorithmic_bytes_per_launch": alg, "divided_by_ms": t_ms,
-              "event_pass": {"avg_launch_ms": kernel_ms, "achieved_GBs": ev, "frac": ev / HBM_PEAK_GBS,
-                             "how": "optimize(opt_iters=1) calls, one launch chain, HIP events around every kernel on the launch stream"},
-              "traffic_source": src,
-              "frac_of_box_copy_bw": achieved / copy_gbs["copy"] if copy_gbs and "copy" in copy_gbs else None,
-              "frac_of_guide_copy_bw": achieved / HBM_COPY_GBS,
-              "box_streaming_GBs": copy_gbs}
+         "launch_ms": kernel_ms, "frac_launch": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    detail = {"algorithmic_bytes_per_launch": alg, "frac_divided_by_ms": t_ms, "traffic_source": src,
+              "frac_of_guide_copy_bw": achieved / HBM_COPY_GBS, "valu_busy_under_profiler": valu_busy}
     if k and "valu_floor_ms" in k:
-        detail["compute"] = {"valu_wave_insts_per_launch": k.get("valu_insts"),
-                             "valu_busy_cycles_per_simd": k.get("valu_busy_cycles_per_simd"),
-                             "valu_floor_ms": k["valu_floor_ms"], "frac_of_valu_floor": k["valu_floor_ms"] / kernel_ms,
-                             "valu_busy_frac_under_profiler": k.get("valu_busy_frac_under_profiler"),
-                             "profiled_clock_ghz": k.get("clock_ghz")}
+        detail["compute"] = {f: k.get(f) for f in ("valu_insts", "valu_busy_cycles_per_simd", "valu_floor_ms", "clock_ghz")}
     return r, detail
 
 
@@ -228,9 +288,8 @@ def kernel_profile(torch, pl, obs, steps, unread=False):
 
 def time_loop(torch, pl, obs, steps, warmup, barrier=None, one_call=True):
     """W warm-up iterations, then exactly `steps` timed iterations between two barriers.  one_call: the loop of
-    the reference itself, `optimize(opt_iters=steps)` (planner.py:289-299) -- nobody looks at the buffers between
-    its iterations, so the context may run them as two particle-half chains; else `steps` calls of
-    optimize(opt_iters=1), each returning its own tensors (one chain by construction)."""
+    the reference itself, `optimize(opt_iters=steps)` (planner.py:289-299); else `steps` calls of optimize(opt_iters=1),
+    each returning its own tensors (the loop the reference's example scripts run)."""
     if one_call:
         if warmup:
             pl.optimize(opt_iters=warmup, **obs)
@@ -248,131 +307,100 @@ def time_loop(torch, pl, obs, steps, warmup, barrier=None, one_call=True):
     return time.perf_counter() - t0
 
 
-def store_free_leg(torch, spec_kwargs, obs_builder, config_key, steps, N_elems, w, costs_bytes, storing_ms, dev):
-    """The product's default inside optimize(opt_iters = K) since round 5, reported BESIDE the storing headline (round-4
-    verdict, item 1c): iterations 1 .. K - 1 do not write their samples (SGPMP_STEP_NO_SAMPLES; update_kernel regenerates the
-    rows that carry weight from their noise keys -- every returned tensor bit-identical to the storing mode's,
-    tests/test_gpu_planner.py::test_store_free_*).  SURVEY 8(d)'s algorithmic bytes are defined on the storing mode (sampler
-    write + sweep read), so no HBM fraction is quoted for this launch: it is bound by the vector ALU (`valu_frac`), and what
-    it moves is what the committed counters of this mode saw."""
-    pl, obs, _ = obs_builder(store_free=True, **spec_kwargs)
+def store_free_leg(torch, spec_kwargs, dev, config_key, steps, storing_ms, passes=1):
+    """The product's default inside optimize(opt_iters = K), reported BESIDE the storing headline: iterations 1 .. K - 1 do
+    not write their samples (SGPMP_STEP_NO_SAMPLES; update_kernel regenerates the rows that carry weight from their noise
+    keys -- every returned tensor bit-identical to the storing mode's, tests/test_gpu_planner.py::test_store_free_*).
+    SURVEY 8(d)'s bytes are defined on the storing mode, so no HBM fraction is quoted for this launch: `valu_frac`."""
+    pl, obs, _ = build_planner(torch, dev=dev, store_free=True, **spec_kwargs)
     time_loop(torch, pl, obs, 150, 0)
-    els = [time_loop(torch, pl, obs, steps, 10), time_loop(torch, pl, obs, steps, 0)]
+    els = [time_loop(torch, pl, obs, steps, 10 if i == 0 else 0) for i in range(passes)]
     el = min(els)
     kms = kernel_profile(torch, pl, obs, min(steps, 60), unread=True)
     kernel = pl._engine.last_cost_kernel()
     ran = pl._engine.store_free_steps()
     k, src = profiled(config_key + "_store_free", kernel)
     launch_ms = kms["cost_sweep"]
-    out = {"mode": "optimize(opt_iters=K): iterations 1 .. K-1 without the sample stores (the default), the K-th storing",
-           "bound": ("valu" if kernel.startswith("fused_step") else "latency: one workgroup per CU in lockstep, three barriers, the update's dependent chain")
-           if ran else None, "kernel": kernel + (" with the update inside the launch" if ran and pl._engine.last_step_launches() == 2 and kernel.startswith("fused_planar_seg") else ""), "iterations_per_s": steps / el, "ms_per_step": 1e3 * el / steps,
+    out = {"kernel": kernel, "iterations_per_s": steps / el, "ms_per_step": 1e3 * el / steps,
            "ms_per_step_of_each_pass": [1e3 * e / steps for e in els], "steps": steps,
            "vs_storing": (storing_ms / (1e3 * el / steps)) if storing_ms else None,
-           "launch_ms": launch_ms, "update_ms": kms["update"],
+           "launch_ms": launch_ms, "update_ms": kms.get("update"), "launches_per_step": pl._engine.last_step_launches(),
            "valu_frac": (k["valu_floor_ms"] / launch_ms) if (k and "valu_floor_ms" in k) else None,
-           "moved_bytes_per_launch": k.get("bytes") if k else None,
-           "moved_frac_of_hbm_peak": (k["bytes"] / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (k and k.get("bytes")) else None,
-           "valu_wave_insts_per_launch": k.get("valu_insts") if k else None,
-           "counters": src, "store_free_steps_run": ran,
-           "bytes_not_written_per_launch": N_elems * w if ran else 0,
-           "results": "bit-identical to the storing mode (means, returned 6-tuple, state_samples): tests/test_gpu_planner.py::test_store_free_*"}
+           "moved_bytes_per_launch": k.get("bytes") if k else None, "counters": src, "store_free_steps_run": ran}
     del pl
     torch.cuda.empty_cache()
     return out
 
 
-def other_configs(torch, dev, copy_gbs=None):
-    """The other single-GPU configurations of BASELINE.json, each timed for a few hundred iterations
-    (they cost milliseconds): configs[0] in fp64, configs[1], configs[2] with the sdf field, and the
-    per-GPU share of configs[4] (512 of 4096 particles, 4 goals; shard 3 of 8)."""
-    f32, f64 = torch.float32, torch.float64
-    specs = [
-        ("config 1: planar 4 x 16 x 64, fp64", "cfg1", dict(workload="planar", P_local=4, S=16, T=64, dtype=f64, goals=2), 300),
-        ("config 2: planar 256 x 64 x 128, fp32", "cfg2", dict(workload="planar", P_local=256, S=64, T=128, dtype=f32, goals=4), 300),
-        ("config 3 with the sdf sphere field", "cfg3_sdf", dict(workload="panda", P_local=1024, S=128, T=64, dtype=f32, field="sdf"), 100),
-        ("config 3 with 64 sphere obstacles (SURVEY 8d stress variant)", "cfg3_64sph",
-         dict(workload="panda", P_local=1024, S=128, T=64, dtype=f32, spheres=64), 40),
-        ("config 5 share: Panda 4 goals, 512 of 4096 particles x 256 x 128, fp32 (shard 3 of 8)", "cfg5",
-         dict(workload="panda", P_local=512, S=256, T=128, dtype=f32, goals=4, shard_of=(3, 8)), 60),
-        # north_star's fp64 clause (means within 1e-5) at configs[2]'s shape: the fp64 context runs sampler, generic sweep and
-        # update as three launches (parity: tests/test_gpu_planner.py::test_config3_shape_fp64_free_running_*)
-        ("config 3's shape in fp64 (Panda 1024 x 128 x 64)", "cfg3_f64", dict(workload="panda", P_local=1024, S=128, T=64, dtype=f64), 20),
-    ]
-    out = []
-    for label, key, spec, steps in specs:
-        # (value / roofline: the storing mode, as for the headline; the store-free figure of the Panda launches beside it)
-        pl, obs, name = build_planner(torch, dev=dev, store_free=False, **spec)
-        time_loop(torch, pl, obs, 150, 0)                        # (clock and chain-stream warm-up, see main())
-        # (two passes, the faster one reported and both kept: these runs last 7-40 ms, and one host hiccup inside a pass --
-        # round 4 saw a 29 ms stall once -- would otherwise be read as a 5 x slower kernel.  The headline is one pass of K.)
-        els = [time_loop(torch, pl, obs, steps, 10), time_loop(torch, pl, obs, steps, 0)]
-        el = min(els)
-        el1 = time_loop(torch, pl, obs, steps, 10, one_call=False)
-        kms = kernel_profile(torch, pl, obs, min(steps, 30))
-        kernel = pl._engine.last_cost_kernel()
-        w = 4 if spec["dtype"] == f32 else 8
-        fused = kernel.startswith("fused_")
-        roof, roof_detail = roofline_of(kernel + (" (K2+K3 in one launch)" if fused else " (K3)"), kms["cost_sweep"],
-                                        spec["P_local"] * spec["S"] * spec["T"] * pl.d_state_opt, w,
-                                        spec["P_local"] * spec["S"] * 8, fused, key, copy_gbs,
-                                        step_ms=1e3 * el / steps, step_mode="optimize(opt_iters=K)",
-                                        field=spec.get("field", "rbf") if spec["workload"] == "panda" else "occupancy grid")
-        sf = None
-        if kernel == "fused_step_kernel" or (kernel == "fused_planar_seg_kernel" and spec["S"] == 64):
-            sf = store_free_leg(torch, spec, lambda **kw: build_planner(torch, dev=dev, **kw), key, steps,
-                                spec["P_local"] * spec["S"] * spec["T"] * pl.d_state_opt, w, spec["P_local"] * spec["S"] * 8,
-                                1e3 * el / steps, dev)
-        out.append({"config": label, "workload": name, "iterations_per_s": steps / el, "store_free": sf,
-                    "ms_per_step": 1e3 * el / steps, "steps": steps, "ms_per_step_of_each_pass": [1e3 * e / steps for e in els],
-                    "iterations_per_s_single_iteration_calls": steps / el1, "kernel_ms_per_step": kms,
-                    "cost_kernel": kernel, "roofline": roof, "roofline_detail": roof_detail,
-                    "dtype": "f32" if spec["dtype"] == f32 else "f64"})
-        del pl
-        torch.cuda.empty_cache()
+def sweep_alone_leg(torch, pl, obs, N_elems, w, costs_bytes, steps=30):
+    """north_star's ">= 40 % of the HBM roofline on the cost-gradient sweep" is about the STAND-ALONE sweep: the same planner
+    with K2 and K3 as separate launches (option no_fused_step), timed with HIP events on the launch stream.  Sweep bytes =
+    N w + P S 8; sampler bytes = N w."""
+    eng = pl._engine
+    eng.set_option("no_fused_step", 1)
+    try:
+        for _ in range(10):
+            pl.optimize(opt_iters=1, **obs)
+        kms = kernel_profile(torch, pl, obs, steps)
+        kernel = eng.last_cost_kernel()
+    finally:
+        eng.set_option("no_fused_step", 0)
+    pl.optimize(opt_iters=1, **obs)
+    sweep_ms, samp_ms = kms["cost_sweep"], kms.get("sample")
+    out = {"kernel": kernel, "launch_ms": sweep_ms, "algorithmic_bytes": N_elems * w + costs_bytes,
+           "frac": (N_elems * w + costs_bytes) / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "kernel_ms_per_step": kms}
+    if samp_ms:
+        out.update(sampler_kernel="sample_iso_kernel", sampler_launch_ms=samp_ms,
+                   sampler_frac=N_elems * w / (samp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
     return out
 
 
-def reference_examples(torch):
-    """The reference's own example problems at their own sizes, run the way its scripts run them -- one optimize(opt_iters=1)
-    per loop trip (examples/panda_environment.py:29-32,107,141-147: 5 particles x 32 samples x 64 waypoints, fp32, five cost
-    terms incl. the end-effector goal; planar_environment.py:14-20,82,102-108: 15 x 128 x 64, fp64): microseconds per call,
-    free-running (the queue drains behind the host) and with the host's enqueue alone.  Latency-bound launches: the step goes
-    out as fused_step_small_kernel / the few-wave sampler."""
-    sys.path.insert(0, os.path.join(ROOT, "examples"))
-    out = {}
-    for which in ("panda", "planar"):
-        try:
-            ex = __import__(which + "_environment")
-            pl, _ = ex.main(opt_iters=20, seed=0, verbose=False)
-            obs = {}
-            if which == "panda":
-                import numpy as np
-                sph = np.zeros((1, 5, 4))
-                sph[0, :, :3] = [[0.8, 0., 0.8], [0.7, -0.1, 0.7], [0.9, 0.1, 0.9], [0.65, 0.15, 0.95], [0.95, -0.15, 0.65]]
-                sph[0, :, 3] = 0.12
-                obs = {"obstacle_spheres": torch.from_numpy(sph).to(**pl.tensor_args)}
-            calls = 500
-            for _ in range(50):
-                pl.optimize(**obs)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(calls):
-                pl.optimize(**obs)
-            t_host = time.perf_counter() - t0
-            torch.cuda.synchronize()
-            t_all = time.perf_counter() - t0
-            out[which] = {"shape": f"{pl.num_particles} x {pl.num_samples} x {pl.traj_len}", "dtype": str(pl.tensor_args["dtype"]).split(".")[-1],
-                          "us_per_call": 1e6 * t_all / calls, "host_enqueue_us_per_call": 1e6 * t_host / calls,
-                          "launches_per_call": pl._engine.last_step_launches(), "cost_kernel": pl._engine.last_cost_kernel()}
-            del pl
-        except Exception as e:                                    # (reported, never fatal for the bench line)
-            out[which] = {"error": f"{type(e).__name__}: {e}"}
+OTHER_SPECS = [
+    ("config 1: planar 4x16x64 fp64", "cfg1", dict(workload="planar", P_local=4, S=16, T=64, dtype="f64", goals=2), 300),
+    ("config 2: planar 256x64x128 fp32", "cfg2", dict(workload="planar", P_local=256, S=64, T=128, dtype="f32", goals=4), 300),
+    ("config 5 share: Panda 4 goals, 512 of 4096 x256x128 fp32", "cfg5",
+     dict(workload="panda", P_local=512, S=256, T=128, dtype="f32", goals=4, shard_of=(3, 8)), 60),
+]
+
+
+def config_row(torch, dev, label, key, spec, steps, passes=1, single_calls=False):
+    """One other configuration: `passes` timed passes of K iterations (the fastest kept), an event pass, the store-free
+    mode beside it where the launch has one."""
+    spec = dict(spec)
+    dtype = {"f32": torch.float32, "f64": torch.float64}[spec.pop("dtype")]
+    pl, obs, name = build_planner(torch, dev=dev, dtype=dtype, store_free=False, **spec)
+    time_loop(torch, pl, obs, 150, 0)                        # (clock and chain-stream warm-up, see main())
+    els = [time_loop(torch, pl, obs, steps, 10 if i == 0 else 0) for i in range(passes)]
+    el = min(els)
+    el1 = time_loop(torch, pl, obs, steps, 10, one_call=False) if single_calls else None
+    kms = kernel_profile(torch, pl, obs, min(steps, 30))
+    kernel = pl._engine.last_cost_kernel()
+    w = 4 if dtype == torch.float32 else 8
+    fused = kernel.startswith("fused_")
+    N_elems = spec["P_local"] * spec["S"] * spec["T"] * pl.d_state_opt
+    roof, roof_detail = roofline_of(kernel, kms["cost_sweep"], N_elems, w, spec["P_local"] * spec["S"] * 8, fused, key,
+                                    step_ms=1e3 * el / steps)
+    launches = pl._engine.last_step_launches()
+    del pl
     torch.cuda.empty_cache()
-    return out
+    sf = None
+    if kernel == "fused_step_kernel" or (kernel == "fused_planar_seg_kernel" and spec["S"] == 64):
+        sf = store_free_leg(torch, dict(spec, dtype=dtype), dev, key, steps, 1e3 * el / steps, passes)
+    return {"config": label, "workload": name, "iterations_per_s": steps / el, "store_free": sf,
+            "ms_per_step": 1e3 * el / steps, "steps": steps, "ms_per_step_of_each_pass": [1e3 * e / steps for e in els],
+            "iterations_per_s_single_iteration_calls": (steps / el1) if el1 else None, "kernel_ms_per_step": kms,
+            "cost_kernel": kernel, "launches_per_iteration": launches, "roofline": roof, "roofline_detail": roof_detail,
+            "dtype": "f32" if dtype == torch.float32 else "f64"}
 
 
-# --------------------------------------------------------------------------------------- CPU figures
+def other_configs(torch, dev):
+    """The other single-GPU configurations of BASELINE.json: configs[0] in fp64, configs[1], and the per-GPU share of
+    configs[4] (512 of 4096 particles, 4 goals; shard 3 of 8).  One pass each (they cost milliseconds)."""
+    return [config_row(torch, dev, *spec) for spec in OTHER_SPECS]
+
+
+# --------------------------------------------------------------------------------------- CPU figure
 def host_cores():
     try:
         return len(os.sched_getaffinity(0))
@@ -381,156 +409,83 @@ def host_cores():
 
 
 def cpu_baseline(args, torch, S, T, P_full):
-    """Reference-equivalent PyTorch-CPU path (oracle/ref_equiv.py: replicated [P,M,M] precision,
-    MultivariateNormal rebuilt per iteration, dense sampling, dense IS matmul) on a bounded sample:
-    `cpu_particles` particles of the workload at its full S and T."""
+    """Reference-equivalent PyTorch-CPU path (oracle/ref_equiv.py: replicated [P,M,M] precision, MultivariateNormal rebuilt
+    per iteration, dense sampling, dense IS matmul) on a BOUNDED sample: `cpu_particles` and 2 x that many particles of the
+    workload at its full S and T, on 16 torch threads (the dense algorithm is dominated by batched small-matrix LAPACK / bmm
+    calls that do not scale with threads: 16 was the best count on every box of rounds 2-5; thread sweep, all-cores point
+    and the banded "fair CPU" figure: tools/bench_variants.py --cpu).  value = affine extrapolation of the time per
+    iteration through the measured points to the full particle count (time = fixed part + per-particle part)."""
     from tests import scenarios as SC
     from stoch_gpmp_amd import workloads as W
     cores = host_cores()
+    threads = min(cores, 16)
+    torch.set_num_threads(threads)
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     Pc = args.cpu_particles
-    if args.workload == "panda":
-        try:
-            ora = SC.oracle_panda_planner(W.PANDA, T, Pc, S, dtype=dtype, field_type=args.field, seed=0)
-        except ValueError:
-            # torch's MultivariateNormal validation can reject stiff fp32 priors (reference
-            # README.md:35); the reference must then be run in fp64, and so is its stand-in
-            dtype = torch.float64
-            ora = SC.oracle_panda_planner(W.PANDA, T, Pc, S, dtype=dtype, field_type=args.field, seed=0)
-        obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres(num=args.spheres)).to(dtype)}
-    else:
+    leg0 = time.perf_counter()
+
+    def make(P):
+        nonlocal dtype
+        if args.workload == "panda":
+            try:
+                return SC.oracle_panda_planner(W.PANDA, T, P, S, dtype=dtype, field_type=args.field, seed=0)
+            except ValueError:
+                # torch's MultivariateNormal validation can reject stiff fp32 priors (reference
+                # README.md:35); the reference must then be run in fp64, and so is its stand-in
+                dtype = torch.float64
+                return SC.oracle_panda_planner(W.PANDA, T, P, S, dtype=dtype, field_type=args.field, seed=0)
         from stoch_gpmp_amd.envs.obst_map import synthetic_obstacle_map
         om = synthetic_obstacle_map(seed=0, tensor_args={"device": torch.device("cpu"), "dtype": torch.float64})
-        Pc = max(Pc // 4, 1) * 4
         dtype = torch.float64      # the reference cannot build the planar priors in fp32 (README.md:35)
-        ora = SC.oracle_planar_planner(W.PLANAR, T, GOALS4_PLANAR, Pc // 4, S, om.map, om.cell_size,
-                                       [om.origin_xi, om.origin_yi], seed=0)
-        obs = {}
-    # The dense algorithm is dominated by batched small-matrix LAPACK / bmm calls that do not scale
-    # with threads (256 threads is ~30x SLOWER than 16 on this workload), so a few thread counts are
-    # tried and the best one is reported: the baseline is the reference algorithm at its best -- and the
-    # all-host-cores figure BASELINE.md section 3 asks for is measured beside it.
-    def timed(o, iters, warm=True):
-        if warm:
-            o.step(**obs)
+        return SC.oracle_planar_planner(W.PLANAR, T, GOALS4_PLANAR, max(P // 4, 1), S, om.map, om.cell_size,
+                                        [om.origin_xi, om.origin_yi], seed=0)
+
+    def timed(o, iters, obs):
+        o.step(**obs)                                       # warm-up
         t0 = time.perf_counter()
         for _ in range(iters):
             o.step(**obs)
         return (time.perf_counter() - t0) / iters
 
-    best = None
-    by_threads = {}
-    leg0 = time.perf_counter()
-    for threads in sorted({min(cores, 16), min(cores, 32)}):   # (16 has been the best count on every box so far)
-        torch.set_num_threads(threads)
-        dt = timed(ora, args.cpu_iters)
-        by_threads[threads] = 1.0 / dt
-        if best is None or dt < best[0]:
-            best = (dt, threads)
-        if time.perf_counter() - leg0 > 8.0:            # keep the whole baseline leg bounded
-            break
-    dt, threads = best
-    # measured points at 2 x and 4 x the particles (best thread count) while the leg stays inside ~25 s: the value is
-    # extrapolated from the TWO LARGEST measured P (time is affine in P: a fixed part + a per-particle part), not from the
-    # smallest sample alone (round-4 verdict: the P = 8 point lay 11 % off the line through P = 4 and the origin)
-    torch.set_num_threads(threads)
-    points = [{"particles": Pc, "it_per_s": 1.0 / dt, "s_per_it": dt}]
-    Pk = Pc
-    while args.workload == "panda" and len(points) < 3:
-        Pk *= 2
-        est = points[-1]["s_per_it"] * 2.2 * (args.cpu_iters + 1)
-        if time.perf_counter() - leg0 + est > 25.0 or Pk * 0.45e9 > 48e9:
-            break
+    if args.workload != "panda":
+        Pc = max(Pc // 4, 1) * 4
+    ora = make(Pc)
+    obs = {"obstacle_spheres": torch.as_tensor(W.panda_spheres(num=args.spheres)).to(dtype)} if args.workload == "panda" else {}
+    dt = timed(ora, args.cpu_iters, obs)
+    points = [{"particles": Pc, "s_per_it": dt, "iterations": args.cpu_iters}]
+    del ora
+    # a second point at 2 x the particles while the leg stays inside its bound (1 warm-up + 1 timed iteration)
+    est = 2.2 * dt * 2
+    if args.workload == "panda" and time.perf_counter() - leg0 + est < args.cpu_seconds and 2 * Pc * 0.45e9 < 48e9:
         try:
-            ora_k = SC.oracle_panda_planner(W.PANDA, T, Pk, S, dtype=dtype, field_type=args.field, seed=0)
-            dk = timed(ora_k, args.cpu_iters)
-            points.append({"particles": Pk, "it_per_s": 1.0 / dk, "s_per_it": dk})
-            del ora_k
+            ora = make(2 * Pc)
+            points.append({"particles": 2 * Pc, "s_per_it": timed(ora, 1, obs), "iterations": 1})
+            del ora
         except Exception:                                   # (memory) keep what was measured
-            break
-    # all host cores (one iteration, no warm-up beyond the runs above: it is the slow point)
-    all_cores = None
-    # (LAST: at 256 threads one iteration of the dense algorithm takes ~15 s, which must not eat the budget of the measured points)
-    if cores not in by_threads and time.perf_counter() - leg0 < 30.0:
-        torch.set_num_threads(cores)
-        dta = timed(ora, 1, warm=False)
-        torch.set_num_threads(threads)
-        all_cores = {"threads": cores, "it_per_s_at_sample": 1.0 / dta, "value_extrapolated_per_particle": (1.0 / dta) * Pc / P_full}
-        by_threads[cores] = 1.0 / dta
+            pass
     if len(points) >= 2:
         (p1, t1), (p2, t2) = [(q["particles"], q["s_per_it"]) for q in points[-2:]]
         t_full = t2 + (t2 - t1) / (p2 - p1) * (P_full - p2)
-        how = (f"affine extrapolation of the time per iteration through the two largest measured points (P = {p1}: {t1:.3f} s, "
-               f"P = {p2}: {t2:.3f} s) to P = {P_full}")
+        how = "affine extrapolation through the measured points"
     else:
         t_full = dt * P_full / Pc
-        how = f"per-particle linear extrapolation of the single measured point (P = {Pc}) to P = {P_full}"
-    its = 1.0 / dt
-    return {
-        "value": 1.0 / t_full, "unit": "iterations/s", "cores": threads, "kind": "port",
-        "sample": (f"{', '.join(str(q['particles']) for q in points)} of {P_full} particles at full S={S}, T={T}, "
-                   f"{str(dtype).split('.')[-1]}, {args.cpu_iters} iterations after 1 warm-up each, best of several torch thread "
-                   f"counts ({threads} threads of {cores} host cores); value = {how} (the dense reference algorithm needs "
-                   "~0.4 GB per particle)"),
-        "measured_it_per_s_at_sample": its, "sample_particles": Pc, "measured_points": points,
-        "it_per_s_at_sample_by_torch_threads": by_threads, "all_host_cores": all_cores,
-        "torch_threads": threads, "host_cores": cores, "extrapolation": how,
-    }
-
-
-def cpu_fair(args, torch, S, T, P_full):
-    """The banded fp64 restatement (oracle/banded_equiv.py): prior factored once, per-DOF 2T x 2T
-    sampling GEMM, IS term as a dot product, same cost functions -- what a careful CPU implementation
-    of the same mathematics costs.  Panda workloads only; bounded sample, linear in the particles."""
-    if args.workload != "panda":
-        return None
-    from oracle import banded_equiv as B
-    from stoch_gpmp_amd import workloads as W
-    c, n = W.PANDA, 7
-    cores = host_cores()
-    Pc = 32
-    dtype = torch.float64
-    goal = torch.tensor([c["goal_q"] + [0.] * n], dtype=dtype)
-    start = torch.tensor(c["start_q"] + [0.] * n, dtype=dtype)
-    means = torch.stack([start + (goal[0] - start) * t / (T - 1) for t in range(T)]).repeat(Pc, 1, 1)
-    band = B.BandedPlanner(Pc, S, T, c["dt"], n, start, goal, B.panda_chunk_cost(c, T, S, goal, args.field),
-                           c["step_size"], c["temperature"], c["sigma_start_sample"], c["sigma_goal_sample"],
-                           c["sigma_gp_sample"], means, chunk=8)
-    sph = torch.as_tensor(W.panda_spheres(num=args.spheres)).to(dtype)
-    g = torch.Generator().manual_seed(0)
-    best = None
-    leg0 = time.perf_counter()
-    for threads in sorted({min(cores, 16), min(cores, 64)}):
-        torch.set_num_threads(threads)
-        eps = torch.randn(S, Pc, T * 2 * n, generator=g, dtype=dtype)
-        band.step(eps, obstacle_spheres=sph)
-        t0 = time.perf_counter()
-        iters = 2
-        for _ in range(iters):
-            eps = torch.randn(S, Pc, T * 2 * n, generator=g, dtype=dtype)   # noise generation is part of an iteration
-            band.step(eps, obstacle_spheres=sph)
-        dt = (time.perf_counter() - t0) / iters
-        if best is None or dt < best[0]:
-            best = (dt, threads)
-        if time.perf_counter() - leg0 > 8.0:
-            break
-    dt, threads = best
-    return {"value": (1.0 / dt) * Pc / P_full, "unit": "iterations/s", "cores": threads, "kind": "port (banded restatement)",
-            "sample": (f"{Pc} of {P_full} particles at full S={S}, T={T}, float64, 2 iterations after 1 warm-up, "
-                       f"{threads} torch threads of {cores} host cores; measured {1.0 / dt:.3f} it/s at P={Pc}; "
-                       "value = linear extrapolation in the particle count (every step of this algorithm is "
-                       "linear in P)"),
-            "measured_it_per_s_at_sample": 1.0 / dt, "sample_particles": Pc, "host_cores": cores}
+        how = "per-particle linear extrapolation of the one measured point"
+    return {"value": 1.0 / t_full, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "sample": f"{'+'.join(str(q['particles']) for q in points)} of {P_full} particles at full S={S} T={T}, "
+                      f"{str(dtype).split('.')[-1]}, {threads} of {cores} host cores; {how} to P={P_full}",
+            "measured_points": points, "host_cores": cores, "torch_threads": threads,
+            "leg_seconds": time.perf_counter() - leg0}
 
 
 # --------------------------------------------------------------------------------------- parity leg
-def parity_leg(torch, args, dev, P_local, S, T, goals, K=10):
+def parity_leg(torch, args, dev, P_local, S, T, goals, K=10, followed=2):
     """Free-running fp32 (or fp64) parity, measured by THIS run, outside every timed region ("max rel err of
     particle_means after K = 10 iterations"): a fresh HIP planner of the benchmarked workload at its FULL size steps K
-    iterations; four of its particles are followed by the fp64 CPU oracle (oracle/ref_equiv.py: the reference's dense
+    iterations; `followed` of its particles are followed by the fp64 CPU oracle (oracle/ref_equiv.py: the reference's dense
     algorithm restated and pinned to the reference's own runs, tests/golden) on the restated noise of exactly those global
-    particle indices (oracle/native_noise.py) -- the oracle is given the four particles' means ONCE, before iteration 1, and
-    nothing afterwards.  The oracle is the checker here, never the thing measured."""
+    particle indices (oracle/native_noise.py) -- the oracle is given the particles' means ONCE, before iteration 1, and
+    nothing afterwards.  The oracle is the checker here, never the thing measured.  (Whole populations:
+    tests/test_gpu_planner.py::test_whole_population_*.)"""
     from oracle import native_noise
     from oracle.native_noise import native_eps
     from tests import scenarios as SC
@@ -544,7 +499,9 @@ def parity_leg(torch, args, dev, P_local, S, T, goals, K=10):
         if goals != 1 or args.shard_of:
             return None                                  # (the multi-goal share is covered by tests/test_gpu_planner.py)
         pl, obs, _ = build_planner(torch, "panda", P_local, S, T, dtype, dev, field=args.field, spheres=args.spheres, seed=seed)
-        sub = sorted({0, 1, P_local // 2 - 1, P_local - 1} & set(range(P_local)))
+        sub = sorted({0, P_local - 1, P_local // 2 - 1, 1}.intersection(range(P_local)))
+        if followed < len(sub):
+            sub = sorted(set([0, P_local - 1] + sub[:followed - 2]))[:followed]
         n = 7
         ora = SC.oracle_panda_planner(W.PANDA, T, len(sub), S, field_type=args.field, seed=seed,
                                       eps_init=torch.zeros(len(sub), 1, T * 2 * n, dtype=torch.float64))
@@ -593,21 +550,16 @@ def parity_leg(torch, args, dev, P_local, S, T, goals, K=10):
     del pl
     torch.cuda.empty_cache()
     tol = 1e-3 if dtype == torch.float32 else 1e-5
-    return {
-        "measured_by": "this run (bench.py parity_leg; outside the timed region)",
-        "what": f"{k} particles {[int(i) for i in sub]} of a fresh full-size run ({P_local} x {S} x {T}), {K} iterations, "
-                "HIP planner and fp64 dense oracle each free-running from the same initial means on the same restated noise",
-        "kernel": kernel, "iterations": K, "resynchronised": False,
-        "tolerance_on_means": tol,
-        "means_rel_err_max_after_K": worst_means if all(tracking) else None,
-        "means_rel_err_max_while_tracking": worst_means,
-        "particles_within_tolerance_per_iteration": per_iter,
-        "cost_rel_err_max_while_tracking": worst_cost,
-        "departures_on_near_ties": departures,       # arg-min flips between two samples whose oracle costs differ by < 2e-5
-        "unexplained_departures": unexplained,
-        "ok": (not unexplained) and worst_cost < 5e-3 and (worst_means < tol),
-        "leg_seconds": time.perf_counter() - t0,
-    }
+    return {"particles_followed": [int(i) for i in sub], "full_size": [P_local, S, T], "kernel": kernel, "iterations": K,
+            "resynchronised": False, "tolerance_on_means": tol,
+            "means_rel_err_max_after_K": worst_means if all(tracking) else None,
+            "means_rel_err_max_while_tracking": worst_means,
+            "particles_within_tolerance_per_iteration": per_iter,
+            "cost_rel_err_max_while_tracking": worst_cost,
+            "departures_on_near_ties": departures,       # arg-min flips between two samples whose oracle costs differ by < 2e-5
+            "unexplained_departures": unexplained,
+            "ok": (not unexplained) and worst_cost < 5e-3 and (worst_means < tol),
+            "leg_seconds": time.perf_counter() - t0}
 
 
 # --------------------------------------------------------------------------------------- main (a rank)
@@ -621,6 +573,7 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    t_start = time.perf_counter()
 
     import torch
     import torch.distributed as dist
@@ -658,9 +611,9 @@ def main():
     else:
         P_local, S, T = args.particles or 256, args.samples or 64, args.traj_len or 128
         goals = 4
+    shard_of = tuple(int(v) for v in args.shard_of.split(",")) if args.shard_of and world == 1 else None
     pl, obs, name = build_planner(torch, args.workload, P_local, S, T, dtype, dev, rank, world,
-                                  field=args.field, spheres=args.spheres, goals=goals,
-                                  shard_of=tuple(int(v) for v in args.shard_of.split(",")) if args.shard_of and world == 1 else None,
+                                  field=args.field, spheres=args.spheres, goals=goals, shard_of=shard_of,
                                   force_stats_allreduce=use_dist and world == 1, store_free=bool(args.store_free))
     w = 4 if dtype == torch.float32 else 8
     d = pl.d_state_opt
@@ -670,7 +623,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Pass 1: per-kernel device times (HIP events between the kernels; feeds `roofline`).  It runs first so
+    # Pass 1: per-kernel device times (HIP events between the kernels; feeds `roofline.launch_ms`).  It runs first so
     # that the wall-clock pass below starts on a GPU that is already at its working clock: with a cold
     # device the first ~100 iterations run 10-20 % slow, which a 5-step warm-up does not cover.
     # The context's two chain streams (optimize(opt_iters >= 2)) need the same: in a fresh process their first
@@ -680,10 +633,11 @@ def main():
     kms = kernel_profile(torch, pl, obs, 100, unread=bool(args.store_free))
     # Pass 2: W untimed warm-up steps, then EXACTLY K timed steps between barriers (the reported value)
     split0 = pl._engine.pipeline_split_steps()
+    t_timed = time.perf_counter()
     elapsed = time_loop(torch, pl, obs, args.steps, args.warmup, barrier, one_call=not args.single_iteration_calls)
     split_steps = pl._engine.pipeline_split_steps() - split0
-    # Pass 3 (reported beside it): the same K iterations as K optimize(opt_iters=1) calls
-    # (--store-free: skipped -- single-iteration calls always store, and a profile of the store-free launches must not mix them in)
+    # Pass 3 (reported beside it): the same K iterations as K optimize(opt_iters=1) calls -- the loop of the reference's
+    # example scripts (--store-free: skipped -- single-iteration calls always store)
     elapsed_calls = time_loop(torch, pl, obs, args.steps, args.warmup, barrier, one_call=False) if not args.store_free else None
     rank_rates = None
     if use_dist:
@@ -702,55 +656,41 @@ def main():
         N_elems = P_local * S * T * d
         sweep_kernel = pl._engine.last_cost_kernel()          # what the dispatcher really launched
         fused = sweep_kernel.startswith("fused_")
-        copy_gbs = box_copy_bandwidth() if world == 1 else None
         is_headline = args.workload == "panda" and (P_local, S, T, args.dtype, args.field, args.spheres, goals) == \
             (1024, 128, 64, "f32", "rbf", 5, 1)
         cfg_key = "cfg3" if is_headline else ("cfg2" if (args.workload, P_local, S, T) == ("planar", 256, 64, 128) else
-                                              "cfg5" if (args.workload, P_local, S, T, goals) == ("panda", 512, 256, 128, 4) else "")
-        # K2 and K3 in one launch: samples are written once and never re-read by the sweep; the algorithmic bytes of
-        # the pair stay SURVEY.md 8(d)'s N w + N w + P S 8 -- traffic the fusion legitimately avoids raises the fraction
+                                              "cfg5" if (args.workload, P_local, S, T, goals) == ("panda", 512, 256, 128, 4) else
+                                              "cfg3_f64" if (args.workload, P_local, S, T, args.dtype, goals) == ("panda", 1024, 128, 64, "f64", 1) else "")
+        if args.workload == "panda" and cfg_key == "cfg3" and args.field == "sdf":
+            cfg_key = "cfg3_sdf"
         ms_step = 1e3 * elapsed / args.steps
-        roof, roof_detail = roofline_of(sweep_kernel + (" (K2+K3 in one launch)" if fused else " (K3)"), kms["cost_sweep"],
-                                        N_elems, w, P_local * S * 8, fused, cfg_key + ("_store_free" if args.store_free and cfg_key else ""),
-                                        copy_gbs, step_ms=ms_step,
-                                        step_mode="optimize(opt_iters=1) x K" if args.single_iteration_calls else "optimize(opt_iters=K)",
-                                        field=args.field if args.workload == "panda" else "occupancy grid")
-        # the store-free mode of the same workload (the product's default inside one optimize() call), beside the headline
-        sfree = None
-        if world == 1 and not args.store_free and not args.no_store_free and fused:
-            sfree = store_free_leg(torch, dict(workload=args.workload, P_local=P_local, S=S, T=T, dtype=dtype, field=args.field,
-                                               spheres=args.spheres, goals=goals,
-                                               shard_of=tuple(int(v) for v in args.shard_of.split(",")) if args.shard_of else None),
-                                   lambda **kw: build_planner(torch, dev=dev, **kw), cfg_key, args.steps, N_elems, w,
-                                   P_local * S * 8, ms_step, dev)
+        launches_per_iteration = pl._engine.last_step_launches()
+        roof, roof_detail = roofline_of(sweep_kernel, kms["cost_sweep"], N_elems, w, P_local * S * 8, fused,
+                                        cfg_key + ("_store_free" if args.store_free and cfg_key else ""), step_ms=ms_step)
         # bytes the iteration really moves: K4 reads only the sample rows whose softmax weight is not exactly zero
         nnz_rows = int((pl._weights_buf != 0).sum())
         iter_alg = 3 * N_elems * w + 2 * P_local * T * d * w + 2 * P_local * S * 8
         iter_moved = ((1 if fused else 2) * N_elems * w + nnz_rows * T * d * w + 4 * P_local * T * d * w
                       + 3 * P_local * S * 8)
+        # the stand-alone sampler and sweep of the same planner (north_star's 40 % clause is about THAT launch)
+        alone = None
+        if world == 1 and fused and not args.no_sweep_alone and not args.store_free and sweep_kernel.startswith("fused_step"):
+            alone = sweep_alone_leg(torch, pl, obs, N_elems, w, P_local * S * 8)
+        # the store-free mode of the same workload (the product's default inside one optimize() call), beside the headline
+        sfree = None
+        spec = dict(workload=args.workload, P_local=P_local, S=S, T=T, dtype=dtype, field=args.field, spheres=args.spheres,
+                    goals=goals, shard_of=shard_of)
+        if world == 1 and not args.store_free and not args.no_store_free and fused:
+            sfree = store_free_leg(torch, spec, dev, cfg_key, args.steps, ms_step)
         # free-running K = 10 parity of the benchmarked workload, measured by this run (rank 0 at N = 1, like cpu_baseline)
         parity = None
         if world == 1 and not args.no_parity:
             parity = parity_leg(torch, args, dev, P_local, S, T, goals)
-        cpu = cpu_detail = fair = None
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            t_cpu = time.perf_counter()
-            cpu_detail = cpu_baseline(args, torch, S, T, P_local)
-            cpu_detail["leg_seconds"] = time.perf_counter() - t_cpu
-            cpu = {"value": cpu_detail["value"], "unit": cpu_detail["unit"], "cores": cpu_detail["cores"],
-                   "kind": cpu_detail["kind"],
-                   "sample": f"{', '.join(str(q['particles']) for q in cpu_detail['measured_points'])} of {P_local} particles, "
-                             f"full S x T, {args.cpu_iters} iterations each, extrapolated through the two largest; all "
-                             f"{cpu_detail['host_cores']} cores: "
-                             + (f"{cpu_detail['all_host_cores']['value_extrapolated_per_particle']:.4g} it/s" if cpu_detail.get('all_host_cores') else "= cores used")}
-            t_cpu = time.perf_counter()
-            fair = cpu_fair(args, torch, S, T, P_local)
-            if fair:
-                fair["leg_seconds"] = time.perf_counter() - t_cpu
+            cpu = cpu_baseline(args, torch, S, T, P_local)
         value = world * args.steps / elapsed
-        # The FIRST 1500 characters carry what the driver's record keeps: value, single_iteration_calls, roofline,
-        # cpu_baseline.  Everything verbose follows.
-        out = {
+        full = {
             "metric": "planner iterations/sec (and ms/iter) at fixed particles x samples x T",
             # whole-job aggregate: every rank advances its 1024-particle shard by one iteration per step (weak
             # scaling); at N = 1 this is plain planner iterations/s of the BASELINE config
@@ -760,65 +700,41 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
             "field": args.field if args.workload == "panda" else "occupancy grid",
-            "single_call_iterations_per_s": (world * args.steps / elapsed_calls) if elapsed_calls else None,   # K x optimize(opt_iters=1), the reference examples' loop
-            "single_iteration_calls": {"iterations_per_s": world * args.steps / elapsed_calls,
-                                       "ms_per_step": 1e3 * elapsed_calls / args.steps} if elapsed_calls else None,
-            "roofline": roof,
-            "cpu_baseline": cpu,
-            "mode": "store_free (--store-free: optimize(opt_iters=K) skips the sample stores of iterations 1 .. K-1)" if args.store_free
-                    else "storing (every iteration writes its samples: the mode SURVEY 8(d)'s bytes are defined on)",
-            "store_free": sfree,
             "config": {"workload": name, "particles_per_gpu": P_local, "particles_total": P_local * world,
                        "samples": S, "traj_len": T, "state_dim": d,
-                       "parallelism": f"particle-sharded x{world}, RCCL statistics all-reduce inside sgpmp_step"
-                       if world > 1 else "single GPU",
+                       "parallelism": f"particle-sharded x{world}, RCCL stats all-reduce in sgpmp_step" if world > 1 else "single GPU",
                        "noise": f"philox4x32-{pl._engine.lib.sgpmp_philox_rounds()} + Box-Muller (in-kernel)",
                        "prior_factor_dtype": "f64"},
-            "rccl": {"ranks": comm_world, "rank": comm_rank, "version": rccl_version,
-                     "library": comm_lib, "test_hooks_build": bool(comm_hooks),
-                     "how": "ncclCommCount / ncclCommUserRank / ncclGetVersion of the communicator sgpmp_step all-reduces on "
-                            "(0 ranks: no communicator attached, single GPU)"},
+            "roofline": roof, "roofline_detail": roof_detail,
+            "cpu_baseline": cpu,
+            "speedup_vs_cpu_baseline": value / cpu["value"] if cpu else None,
+            "single_iteration_calls": {"iterations_per_s": world * args.steps / elapsed_calls,
+                                       "ms_per_step": 1e3 * elapsed_calls / args.steps} if elapsed_calls else None,
+            "mode": "store_free" if args.store_free else "storing",
+            "store_free": sfree,
+            "sweep_alone": alone,
+            "parity": parity,
+            "rccl": {"ranks": comm_world, "rank": comm_rank, "version": rccl_version, "library": comm_lib,
+                     "test_hooks_build": bool(comm_hooks)},
             "shared_gpu_test_double": shared_gpu or bool(comm_hooks and "rccl" not in comm_lib),
             "per_rank_iterations_per_s": None if rank_rates is None else
             {"min": min(rank_rates), "max": max(rank_rates), "all": rank_rates},
-            "planner_iterations_per_s": args.steps / elapsed,
-            "speedup_vs_cpu_baseline": value / cpu["value"] if cpu else None,
-            "parity": parity,
-            "roofline_detail": roof_detail,
-            "cpu_baseline_detail": cpu_detail,
-            "cpu_fair": fair,
-            "speedup_vs_cpu_fair": value / fair["value"] if fair else None,
             "kernel_ms_per_step": kms,
-            "launches_per_iteration": pl._engine.last_step_launches(),
-            "passes": "1: 2 x optimize(opt_iters=100) untimed (clock and stream warm-up), then 100 iterations with HIP "
-                      "events between the kernels (kernel_ms_per_step, roofline_detail.event_pass); "
-                      "2: optimize(opt_iters=W) untimed, then optimize(opt_iters=K) -- the reference's own loop, "
-                      "planner.py:289-299 -- between barriers (value, ms_per_step, roofline.frac); "
-                      "3: the same as W + K calls of optimize(opt_iters=1) (single_iteration_calls)",
+            "launches_per_iteration": launches_per_iteration,
             "loop": {"call": "optimize(opt_iters=1) x K" if args.single_iteration_calls else "optimize(opt_iters=K)",
-                     "steps_run_as_two_particle_half_chains": split_steps,
-                     "note": "inside one optimize() call nobody reads the buffers between iterations, so the context "
-                             "runs the call's iterations as two particle-half launch sequences on two streams of "
-                             "its own (sgpmp_pipeline_begin/_end): one half's update kernel runs under the other "
-                             "half's sampler + sweep launch; bit-identical results"},
-            "iteration_roofline": {"algorithmic_bytes": iter_alg, "moved_bytes": iter_moved,
-                                   "k4_rows_read": nnz_rows,
-                                   "note": "algorithmic_bytes is SURVEY 8d's three-pass model (sampler write, sweep read, update "
-                                           "read); the fused launch and the one-hot update move moved_bytes -- the fraction "
-                                           "of the HBM peak is quoted for THAT",
+                     "steps_run_as_two_particle_half_chains": split_steps},
+            "iteration_roofline": {"algorithmic_bytes": iter_alg, "moved_bytes": iter_moved, "k4_rows_read": nnz_rows,
                                    "moved_GBs": iter_moved / (ms_step * 1e-3) / 1e9,
                                    "moved_frac_of_hbm_peak": iter_moved / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "last_iteration": {"mean_cost_sum": mean_cost, "mean_min_cost": mean_min_cost},
+            "timed_region_started_s": t_timed - t_start,
         }
         if world == 1 and not args.no_other_configs and is_headline:
             del pl
             torch.cuda.empty_cache()
-            out["other_configs"] = other_configs(torch, dev, copy_gbs)
-            out["reference_examples"] = reference_examples(torch)
-        line = json.dumps(out)
-        head = line[:1500]
-        assert all(k in head for k in ('"value"', '"single_iteration_calls"', '"roofline"', '"cpu_baseline"')), len(head)
-        os.write(json_fd, (line + "\n").encode())
+            full["other_configs"] = other_configs(torch, dev)
+        full["wall_seconds"] = time.perf_counter() - t_start
+        emit(full, json_fd, args.detail if world == 1 or not shared_gpu else None)
     # the context (and its RCCL communicator) goes before torch's process group does
     pl = None
     import gc

@@ -34,9 +34,10 @@ extern "C" {
 /* 2: sgpmp_step gained `flags`, sgpmp_set_priors / pipeline_* / comm_* appeared (round 2); 3: round 3 (see git log);
  * 4: sgpmp_comm_library, sgpmp_set_fk_codegen / _info / _compile, sgpmp_dense_particles (round 4);
  * 5: SGPMP_STEP_NO_SAMPLES, sgpmp_row_counts_get / _set, sgpmp_store_free_steps, sgpmp_step honours per-mode sampling
- *    precisions; the options of the retired experiments are gone (round 5).
+ *    precisions; the options of the retired experiments are gone (round 5);
+ * 6: sgpmp_optimize (the K-loop of optimize() behind the ABI), sgpmp_row_counts_clear (round 6).
  * The Python binding refuses any other value at load time. */
-#define SGPMP_ABI_VERSION 5
+#define SGPMP_ABI_VERSION 6
 
 enum { SGPMP_F32 = 0, SGPMP_F64 = 1 };
 enum { SGPMP_PRIOR_INIT = 0, SGPMP_PRIOR_SAMPLE = 1 };
@@ -267,6 +268,8 @@ int sgpmp_dense_particles(sgpmp_ctx* ctx, int64_t* count, int64_t* armed_steps);
  * Synchronous.  get: out HOST uint32[P] (zeros before the first fp32 step); set: in HOST uint32[P], or NULL = all zero. */
 int sgpmp_row_counts_get(sgpmp_ctx* ctx, uint32_t* out);
 int sgpmp_row_counts_set(sgpmp_ctx* ctx, const uint32_t* in);
+/* reset()'s clear (planner.py:181-227 starts a fresh problem): all zero, asynchronous on `stream`, no host synchronisation. */
+int sgpmp_row_counts_clear(sgpmp_ctx* ctx, void* stream);
 /* steps of this context that ran store-free so far (SGPMP_STEP_NO_SAMPLES honoured; tests and bench.py report it) */
 long long sgpmp_store_free_steps(sgpmp_ctx* ctx);
 
@@ -317,6 +320,21 @@ int sgpmp_step(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, const void* eps, in
  * usual inside the bracket.  Switch: SGPMP_NO_STEP_PIPELINE / "no_step_pipeline". */
 int sgpmp_pipeline_begin(sgpmp_ctx* ctx, void* stream);
 int sgpmp_pipeline_end(sgpmp_ctx* ctx, void* stream);
+/* StochGPMP.optimize's loop (planner.py:289-299) as ONE call: opt_iters x sgpmp_step with in-kernel noise on `stream`,
+ * draw counters draw0 .. draw0 + opt_iters - 1; step k accumulates its statistics in stats_pair[(first_slot + k) & 1]
+ * (DEVICE double[2][SGPMP_STAT_SHARDS][4], or NULL); steps 0 .. K - 2 leave their pre-update means in means_prev_scratch,
+ * the last one in means_prev_last (either may be NULL) -- the tensor optimize() hands out (planner.py:252-253).
+ * flags: SGPMP_STEP_MEANS_KEPT speaks for the FIRST step (the later ones follow this call's own steps and always carry it);
+ * SGPMP_OPT_STORE_FREE gives steps 0 .. K - 2 SGPMP_STEP_NO_SAMPLES (the reference returns the last iteration's tensors
+ * only); SGPMP_OPT_PIPELINE brackets the call with sgpmp_pipeline_begin / _end when opt_iters >= 2.  Results are those of
+ * the same sgpmp_step calls made one by one, bit for bit; the first failing step's status is returned (the bracket is
+ * closed first).  No host synchronisation. */
+#define SGPMP_OPT_PIPELINE 4
+#define SGPMP_OPT_STORE_FREE 8
+int sgpmp_optimize(sgpmp_ctx* ctx, int opt_iters, uint64_t seed, uint64_t draw0, void* means, void* samples,
+                   void* costs, void* weights, void* grad, void* means_prev_scratch, void* means_prev_last,
+                   const void* spheres, int n_spheres, double temperature, double step_size,
+                   double* stats_pair, int first_slot, int flags, void* stream);
 /* Kernels the last sgpmp_step enqueued for its particle range (per chain when it ran as two): 2 = fused sampler + sweep,
  * then update_kernel (the default); 3-4 = separate kernels; 1 = a store-free planar step whose launch also updated its
  * particles (fused_planar_seg.inc: seg_update). */

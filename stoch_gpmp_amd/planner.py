@@ -34,6 +34,8 @@ Additions over the reference API (all optional keyword arguments):
   pipeline_steps=True        optimize(opt_iters >= 2) lets the context run the iterations of the call as two
                              particle-half chains on streams of its own (one half's update kernel under the
                              other half's sampler + sweep launch); same results, bit for bit.
+  c_loop=True                optimize() is ONE call into the library (include/sgpmp.h: sgpmp_optimize runs the K-loop);
+                             False: one sgpmp_step call per iteration from Python, as in rounds 1-5 (same results, bit for bit).
   store_free=True            optimize(opt_iters = K) returns the LAST iteration's tensors only (planner.py:289-317), so
                              iterations 1 .. K - 1 do not write their samples (470 MB per iteration at 1024 x 128 x 64):
                              the update regenerates the rows that carry weight from their noise keys, bit for bit
@@ -162,6 +164,7 @@ class StochGPMP:
         self.mode_stats_every_step = bool(kwargs.get('mode_stats', False))
         self.clone_outputs = bool(kwargs.get('clone_outputs', True))
         self.store_free = bool(kwargs.get('store_free', True))
+        self.c_loop = bool(kwargs.get('c_loop', True))
         self._mode_buf = None
 
         self.reset(start_state, multi_goal_states, initial_particle_means=initial_particle_means)
@@ -296,8 +299,9 @@ class StochGPMP:
         self._stats_slot = 0
         # per-particle row counts of the last update (they steer the next step's launch and update per particle): a fresh
         # problem starts without them, whatever ran on this context before
-        eng.set_row_counts(None)
+        eng.clear_row_counts()                          # (stream-ordered: a replanning loop resets every control cycle)
         self._step_calls = {}
+        self._opt_calls = {}
         self._pm_obj, self._pm_version = None, -1       # means tensor / version after our last fused step
         self._mode_fresh = False                        # _mode_buf holds the statistics of the current means
         self._Sigma_inv = None
@@ -586,6 +590,9 @@ class StochGPMP:
         piped = (opt_iters >= 2 and not debug and self._native_cost and self.noise == 'philox'
                  and self.num_particles_local > 0 and self.pipeline_steps and not torch_reduce
                  and not self.mode_stats_every_step)
+        if (not debug and self._native_cost and self.noise == 'philox' and self.num_particles_local > 0
+                and not torch_reduce and opt_iters >= 1 and self.c_loop):
+            return self._optimize_one_call(opt_iters, piped, observation)
         if piped:
             self._spheres(observation)                   # (a first use copies on THIS stream: before the chains fork)
             self._engine.pipeline_begin()
@@ -612,6 +619,54 @@ class StochGPMP:
         self._recent_weights = self._weights
         return (state_particles, control_particles, state_trajectories, control_samples, costs,
                 approx_grad)
+
+    def _optimize_one_call(self, opt_iters, piped, observation):
+        """optimize() as ONE call into the library (include/sgpmp.h: sgpmp_optimize -- the K-loop, the draw counters, the
+        alternating statistics slot, the flags of every step and the two-chain bracket on the C side): what the per-iteration
+        step() calls of the loop above do, bit for bit (tests/test_gpu_planner.py::test_pipelined_optimize_*)."""
+        self.state_samples = self._samples_buf
+        cv = self.cost.version()
+        if cv != self._cost_version:                     # a field / cost was edited (e.g. update_target)
+            self.cost.compile_into(self._engine)
+            self._cost_version = cv
+        sph = self._spheres(observation)
+        pm = self.particle_means
+        key = (0 if sph is None else sph.data_ptr(), 0 if sph is None else sph.shape[0], self.temperature, self.step_size,
+               pm.data_ptr(), self.state_samples.data_ptr())
+        call = self._opt_calls.get(key)
+        if call is None:
+            if len(self._opt_calls) > 8:
+                self._opt_calls.clear()
+            call = self._engine.prepare_optimize(
+                self.seed, pm, self.state_samples, self.temperature, self.step_size, costs=self._costs,
+                weights=self._weights_buf, grad=self._grad, means_prev=self._means_prev_buf, spheres=sph,
+                stats_pair=self._stats)
+            self._opt_calls[key] = call
+        fresh_prev = torch.empty_like(self._means_prev_buf) if self.clone_outputs else None   # (caching allocator: no launch)
+        kept = pm is self._pm_obj and pm._version == self._pm_version
+        flags = (L.STEP_MEANS_KEPT if kept else 0) | (L.OPT_PIPELINE if piped else 0) \
+            | (L.OPT_STORE_FREE if self.store_free else 0)
+        try:
+            call(opt_iters, self._draw, self._stats_slot, flags, None if fresh_prev is None else fresh_prev.data_ptr())
+        finally:
+            # (a failing step leaves the counters where a Python loop would have left them at worst: past the call)
+            self._draw += opt_iters
+            self._stats_slot ^= opt_iters & 1
+        self._pm_obj, self._pm_version = pm, pm._version
+        self._mode_fresh = self.mode_stats_every_step
+        n = self.n_dof
+        state_particles, control_particles, state_trajectories, control_samples = self._views
+        if fresh_prev is not None:
+            self._means_prev = fresh_prev
+            state_particles, control_particles = fresh_prev[..., :n], fresh_prev[..., -n:]
+        else:
+            self._means_prev = self._means_prev_buf
+        self._recent_control_samples = control_samples
+        self._recent_control_particles = control_particles
+        self._recent_state_trajectories = state_trajectories
+        self._recent_state_particles = state_particles
+        self._recent_weights = self._weights
+        return (state_particles, control_particles, state_trajectories, control_samples, self._costs, self._grad)
 
     def _get_traj(self, mode='best'):
         if mode == 'best':
@@ -683,6 +738,7 @@ class StochGPMP:
         self.particle_means.copy_(pm)                    # (in place: bumps the version counter -> no prepared IS weights)
         self.seed, self._draw = int(sd['seed']), int(sd['draw'])
         self._step_calls = {}                            # (the seed is pre-bound in the prepared calls)
+        self._opt_calls = {}
         self._pm_obj, self._pm_version = None, -1
         self._mode_fresh = False
         self._stats_slot = int(sd['stats_slot'])

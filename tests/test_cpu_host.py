@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libsgpmp.so does not export {name}"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in stoch_gpmp_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.sgpmp_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.sgpmp_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_ctypes_structs_match_the_c_layout(tmp_path):
@@ -272,6 +272,91 @@ def test_dense_linear_systems_match_the_oracle():
 
 
 
+def _canned_bench_record():
+    """A record of the shape bench.py's main() assembles (values of a round-5 run), with the things that once broke or could
+    break the driver's parse: NaN / Infinity, paragraphs of prose, an eight-rank table, fat per-configuration objects."""
+    roof = {"bound": "valu", "kernel": "fused_step_kernel", "achieved": 5115.123456789, "peak": 8000.0, "unit": "GB/s",
+            "frac": 0.6393904320987, "traffic": 480102400, "valu_frac": 0.7812345, "moved_frac": 0.3412345,
+            "launch_ms": 0.175512345, "frac_launch": 0.669912345}
+    sf = {"kernel": "fused_step_kernel", "iterations_per_s": 6086.123456, "ms_per_step": 0.16431, "valu_frac": 0.851234,
+          "launch_ms": 0.1574, "counters": "profiles/r05/final_cfg3_store_free_* " * 20, "steps": 20}
+    row = {"config": "config 5 share: Panda 4 goals, 512 of 4096 x256x128 fp32", "workload": "w" * 200,
+           "iterations_per_s": 2929.123456, "store_free": dict(sf), "roofline": dict(roof), "roofline_detail": {"x": "y" * 500},
+           "cost_kernel": "fused_step_kernel", "dtype": "f32", "kernel_ms_per_step": {"cost_sweep": 0.33}}
+    return {
+        "metric": "planner iterations/sec (and ms/iter) at fixed particles x samples x T", "value": 5438.4321012345,
+        "unit": "iterations/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 0.18387654321,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "field": "rbf",
+        "config": {"workload": "Panda 7-DoF 1024p (1024/GPU) x 128s x 64t, 1 goal, GP+goal+self+5 spheres rbf",
+                   "particles_per_gpu": 1024, "particles_total": 1024, "samples": 128, "traj_len": 64, "state_dim": 14,
+                   "parallelism": "single GPU", "noise": "philox4x32-7 + Box-Muller (in-kernel)", "prior_factor_dtype": "f64"},
+        "roofline": roof, "roofline_detail": {"algorithmic_bytes_per_launch": 940572672, "note": "n" * 3000},
+        "cpu_baseline": {"value": 0.0111234, "unit": "iterations/s", "cores": 16, "kind": "port",
+                         "sample": "4+8 of 1024 particles at full S=128 T=64, float32, 16 of 256 host cores; affine "
+                                   "extrapolation through the measured points to P=1024",
+                         "measured_points": [{"particles": 4, "s_per_it": 0.45}] * 3, "leg_seconds": float("inf")},
+        "speedup_vs_cpu_baseline": 489000.123, "single_iteration_calls": {"iterations_per_s": 5180.1, "ms_per_step": 0.19305},
+        "mode": "storing", "store_free": sf,
+        "sweep_alone": {"kernel": "cost_sweep_chunked_kernel", "launch_ms": 0.1296, "frac": 0.4541234,
+                        "sampler_kernel": "sample_iso_kernel", "sampler_launch_ms": 0.1059, "sampler_frac": 0.5551,
+                        "kernel_ms_per_step": {"a": 1.0}},
+        "parity": {"ok": True, "means_rel_err_max_after_K": 2.3e-7, "cost_rel_err_max_while_tracking": float("nan"),
+                   "iterations": 10, "tolerance_on_means": 1e-3, "departures_on_near_ties": [], "what": "p" * 900},
+        "rccl": {"ranks": 8, "rank": 0, "version": 22204, "library": "librccl.so", "test_hooks_build": False},
+        "shared_gpu_test_double": False,
+        "per_rank_iterations_per_s": {"min": 5400.123456789, "max": 5500.123456789, "all": [5400.123456789 + i for i in range(8)]},
+        "kernel_ms_per_step": {"cost_sweep": 0.1755, "update": 0.0139}, "launches_per_iteration": 2,
+        "last_iteration": {"mean_cost_sum": 1.234e11, "mean_min_cost": 5.6e8},
+        "other_configs": [dict(row) for _ in range(3)], "passes": "prose " * 400,
+    }
+
+
+def test_bench_line_is_compact_strict_json_with_the_contract_keys(tmp_path):
+    """The driver parses bench.py's single stdout line whole or not at all (round 5: a 23 KB line was kept as `parsed:
+    null`).  `compact_line` / `emit` must give < 4 KB of strict JSON carrying the contract keys, whatever the detailed
+    record holds; the detail goes to bench_detail.json."""
+    import json
+    import bench
+
+    def no_constants(name):
+        raise AssertionError(f"non-strict JSON constant {name}")
+    full = _canned_bench_record()
+    line = bench.compact_line(full)
+    assert len(line) < 4096 and "\n" not in line
+    rec = json.loads(line, parse_constant=no_constants)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["value"] == full["value"] and rec["ms_per_step"] == full["ms_per_step"] and rec["vs_baseline"] is None
+    assert set(rec["config"]) >= {"workload", "particles_total", "samples", "traj_len"} and "model" not in rec["config"]
+    assert set(rec["roofline"]) >= {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "valu_frac",
+                                    "moved_frac", "launch_ms"}
+    assert set(rec["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
+    assert rec["single_iteration_calls"]["iterations_per_s"] > 0 and rec["store_free"]["iterations_per_s"] > 0
+    assert rec["parity"]["ok"] is True and rec["parity"]["cost_rel_err_max_while_tracking"] is None     # NaN -> null
+    assert rec["rccl"]["ranks"] == 8 and len(rec["per_rank_iterations_per_s"]["all"]) == 8
+    assert rec["per_rank_iterations_per_s"]["min"] == full["per_rank_iterations_per_s"]["min"]          # (not rounded)
+    assert rec["sweep_alone_frac"] == pytest.approx(0.4541, rel=1e-3)
+    assert [set(r) for r in rec["other_configs"]] == [{"config", "it_per_s", "store_free_it_per_s", "frac", "bound", "kernel",
+                                                       "dtype"}] * 3
+    # a record that grew (forty configurations) loses optional parts, never the contract keys, and stays under the limit
+    fat = dict(full, other_configs=[dict(full["other_configs"][0]) for _ in range(40)])
+    line2 = bench.compact_line(fat)
+    rec2 = json.loads(line2, parse_constant=no_constants)
+    assert len(line2) < 4096 and "other_configs" not in rec2 and rec2["roofline"]["frac"] > 0 and rec2["cpu_baseline"]["value"] > 0
+    # emit(): the detail file is strict JSON too and holds what the line leaves out; the line goes to the given descriptor
+    r, w = os.pipe()
+    detail = str(tmp_path / "bench_detail.json")
+    out = bench.emit(full, w, detail)
+    os.close(w)
+    got = os.read(r, 65536).decode()
+    os.close(r)
+    assert got == out + "\n" and got.count("\n") == 1
+    det = json.loads(open(detail).read(), parse_constant=no_constants)
+    assert det["roofline_detail"]["algorithmic_bytes_per_launch"] == 940572672 and det["cpu_baseline"]["leg_seconds"] is None
+    assert json.loads(out)["detail"] == "bench_detail.json"
+
+
 def test_bench_multi_gpu_launch_starts_ranks_and_relays_failure():
     """`python bench.py --gpus 2` with no launcher around it starts its own ranks (torch.distributed.run)
     from a parent that never touches the GPU, and relays the outcome: in this GPU-less container both
@@ -284,7 +369,8 @@ def test_bench_multi_gpu_launch_starts_ranks_and_relays_failure():
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
     import torch
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
-        assert p.returncode == 0 and '"n_gpus": 2' in p.stdout
+        import json
+        assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 2
     else:
         assert p.returncode != 0
         assert '"metric"' not in p.stdout
