@@ -79,7 +79,7 @@ def parse(argv=None):
     ap.add_argument("--no-sweep-alone", action="store_true", help="skip the stand-alone sampler / sweep event pass")
     ap.add_argument("--cpu-particles", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=2)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the cpu_baseline leg")
     ap.add_argument("--detail", default=os.path.join(ROOT, DETAIL_FILE), help="where the detailed record goes")
     return ap.parse_args(argv)
 
@@ -410,8 +410,8 @@ def host_cores():
 
 def cpu_baseline(args, torch, S, T, P_full):
     """Reference-equivalent PyTorch-CPU path (oracle/ref_equiv.py: replicated [P,M,M] precision, MultivariateNormal rebuilt
-    per iteration, dense sampling, dense IS matmul) on a BOUNDED sample: `cpu_particles` and 2 x that many particles of the
-    workload at its full S and T, on 16 torch threads (the dense algorithm is dominated by batched small-matrix LAPACK / bmm
+    per iteration, dense sampling, dense IS matmul) on a BOUNDED sample: `cpu_particles`, 2 x and 4 x that many particles of the
+    workload at its full S and T (while they fit `cpu_seconds`), on 16 torch threads (the dense algorithm is dominated by batched small-matrix LAPACK / bmm
     calls that do not scale with threads: 16 was the best count on every box of rounds 2-5; thread sweep, all-cores point
     and the banded "fair CPU" figure: tools/bench_variants.py --cpu).  value = affine extrapolation of the time per
     iteration through the measured points to the full particle count (time = fixed part + per-particle part)."""
@@ -454,15 +454,22 @@ def cpu_baseline(args, torch, S, T, P_full):
     dt = timed(ora, args.cpu_iters, obs)
     points = [{"particles": Pc, "s_per_it": dt, "iterations": args.cpu_iters}]
     del ora
-    # a second point at 2 x the particles while the leg stays inside its bound (1 warm-up + 1 timed iteration)
-    est = 2.2 * dt * 2
-    if args.workload == "panda" and time.perf_counter() - leg0 + est < args.cpu_seconds and 2 * Pc * 0.45e9 < 48e9:
+    # more points at 2 x, 4 x the particles while the leg stays inside its bound (1 warm-up + `cpu_iters` timed iterations, 1 for
+    # the last point that fits)
+    Pk = Pc
+    while args.workload == "panda" and len(points) < 3:
+        Pk *= 2
+        per_it = 2.2 * points[-1]["s_per_it"]
+        left = args.cpu_seconds - (time.perf_counter() - leg0)
+        iters = args.cpu_iters if per_it * (args.cpu_iters + 1) < left else 1
+        if per_it * (iters + 1) > left or Pk * 0.45e9 > 48e9:
+            break
         try:
-            ora = make(2 * Pc)
-            points.append({"particles": 2 * Pc, "s_per_it": timed(ora, 1, obs), "iterations": 1})
+            ora = make(Pk)
+            points.append({"particles": Pk, "s_per_it": timed(ora, iters, obs), "iterations": iters})
             del ora
         except Exception:                                   # (memory) keep what was measured
-            pass
+            break
     if len(points) >= 2:
         (p1, t1), (p2, t2) = [(q["particles"], q["s_per_it"]) for q in points[-2:]]
         t_full = t2 + (t2 - t1) / (p2 - p1) * (P_full - p2)

@@ -156,6 +156,7 @@ static int alloc_prior(sgpmp_ctx* c, PriorDev& p) {
     HIPCHK(hipMemset(p.iso32, 0, sizeof(float) * Tpad * 8));
     HIPCHK(hipMemset(p.iso32p, 0, sizeof(float) * Tpad * 8));
     HIPCHK(hipMalloc(&p.slabpre, sizeof(float) * 5 * T * 4));
+    HIPCHK(hipMalloc(&p.scan64, sizeof(double) * T * 28));
     HIPCHK(hipMalloc(&p.Qinv, sizeof(double) * d * d));
     HIPCHK(hipMalloc(&p.G32, sizeof(float) * T * d * d));
     HIPCHK(hipMalloc(&p.H32, sizeof(float) * T * d * d));
@@ -165,7 +166,7 @@ static int alloc_prior(sgpmp_ctx* c, PriorDev& p) {
 
 static void free_prior(PriorDev& p) {
     hipFree(p.blocks); hipFree(p.G); hipFree(p.H); hipFree(p.iso64); hipFree(p.iso32); hipFree(p.iso32p); hipFree(p.slabpre);
-    hipFree(p.Qinv); hipFree(p.G32); hipFree(p.H32); hipFree(p.status); hipFree(p.Dm); hipFree(p.Em);
+    hipFree(p.scan64); hipFree(p.Qinv); hipFree(p.G32); hipFree(p.H32); hipFree(p.status); hipFree(p.Dm); hipFree(p.Em);
     std::memset(&p, 0, sizeof(p));
 }
 
@@ -418,6 +419,45 @@ static int upload_slab_prefix(sgpmp_ctx* c, PriorDev& p, hipStream_t st) {
     return SGPMP_OK;
 }
 
+// The Kogge-Stone tables of the fp64 one-launch step (cost_sweep_kernel.inc: GenArgs64): the recurrence y_t = H_t y_{t-1} + b_t of
+// the 64 waypoints of a pass, all lanes at once, needs the propagator products A_t^(r) = H_t .. H_{t - 2^r + 1} of every round
+// and C_t = H_t .. H_{t0} for the state carried into a later pass.  Once per factorisation, fp64, on the host from K1's
+// coefficients (the propagators of an isotropic prior are the same for every dof, particle and sample).
+static int upload_scan64(sgpmp_ctx* c, PriorDev& p, hipStream_t st) {
+    if (!p.isotropic || c->dims.dtype != SGPMP_F64) return SGPMP_OK;
+    const int T = c->dims.traj_len;
+    std::vector<double> iso((size_t)T * 8);
+    HIPCHK(hipMemcpyAsync(iso.data(), p.iso64, sizeof(double) * T * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    struct M2 { double a, b, c, d; };
+    auto mul = [](const M2& x, const M2& y) { return M2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; };
+    std::vector<double> tab((size_t)T * 28, 0.);
+    std::vector<M2> cur((size_t)T), nxt((size_t)T);
+    for (int t = 0; t < T; ++t) cur[t] = M2{iso[(size_t)t * 8 + 3], iso[(size_t)t * 8 + 4], iso[(size_t)t * 8 + 5], iso[(size_t)t * 8 + 6]};
+    for (int r = 0; r < 6; ++r) {
+        const int d = 1 << r;
+        for (int t = 0; t < T; ++t) {
+            const int t0 = t & ~63;
+            double* o = &tab[(size_t)t * 28 + 4 * r];
+            if (t - d >= t0) {
+                o[0] = cur[t].a; o[1] = cur[t].b; o[2] = cur[t].c; o[3] = cur[t].d;
+                nxt[t] = mul(cur[t], cur[t - d]);                // H_t .. H_{t - 2d + 1} (used only where t - 2d >= t0)
+            } else nxt[t] = cur[t];
+        }
+        cur.swap(nxt);
+    }
+    M2 pre{1., 0., 0., 1.};
+    for (int t = 0; t < T; ++t) {
+        if ((t & 63) == 0) pre = M2{1., 0., 0., 1.};
+        pre = mul(M2{iso[(size_t)t * 8 + 3], iso[(size_t)t * 8 + 4], iso[(size_t)t * 8 + 5], iso[(size_t)t * 8 + 6]}, pre);
+        double* o = &tab[(size_t)t * 28 + 24];
+        o[0] = pre.a; o[1] = pre.b; o[2] = pre.c; o[3] = pre.d;
+    }
+    HIPCHK(hipMemcpyAsync(p.scan64, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return SGPMP_OK;
+}
+
 extern "C" int sgpmp_set_prior(sgpmp_ctx* c, int which, double dt, double sigma_start, double sigma_gp,
                                double sigma_goal, const double* qc_inv, void* stream) {
     if (!c || (which != 0 && which != 1)) return fail(SGPMP_EINVAL, "sgpmp_set_prior: bad argument");
@@ -445,6 +485,7 @@ extern "C" int sgpmp_set_prior(sgpmp_ctx* c, int which, double dt, double sigma_
         return fail(SGPMP_ENOTPD, "sgpmp_set_prior: prior precision matrix is not positive definite");
     int rcs;
     if ((rcs = upload_slab_prefix(c, p, st)) != SGPMP_OK) return rcs;
+    if ((rcs = upload_scan64(c, p, st)) != SGPMP_OK) return rcs;
     p.valid = 1;
     return SGPMP_OK;
 }
@@ -489,6 +530,7 @@ extern "C" int sgpmp_set_priors(sgpmp_ctx* c, double dt, const double* sigma_sta
         if (status[w] != 0) return fail(SGPMP_ENOTPD, "sgpmp_set_priors: prior precision matrix is not positive definite");
         int rcs;
         if ((rcs = upload_slab_prefix(c, c->prior[w], st)) != SGPMP_OK) return rcs;
+        if ((rcs = upload_scan64(c, c->prior[w], st)) != SGPMP_OK) return rcs;
         c->prior[w].valid = 1;
     }
     return SGPMP_OK;

@@ -25,11 +25,16 @@
 #include <string>
 #include <vector>
 
+#include <fcntl.h>
+#include <unistd.h>
 #include "rng.h"
 #include "sgpmp_internal.h"
 
 #ifndef SGPMP_CSRC_DEFAULT
 #define SGPMP_CSRC_DEFAULT ""
+#endif
+#if __has_include("build_extra.h")
+#include "build_extra.h"                     // SGPMP_BUILD_EXTRA as a properly escaped literal (Makefile, gen/build_extra.py)
 #endif
 #ifndef SGPMP_BUILD_EXTRA
 #define SGPMP_BUILD_EXTRA ""                 // the EXTRA compile flags of this build (Makefile): the run-time compiler gets the same -D's
@@ -231,7 +236,11 @@ static std::string translation_unit(const RtcChain& c) {
 }
 
 // hiprtc: translation unit -> gfx950 code object.  Needs no device.
-static bool compile_tu(const std::string& tu, const std::string& dir, int ft, std::vector<char>& code, std::string& err, double* secs) {
+// *compiler_verdict (may be null): true iff the failure is hiprtc's judgement of the SOURCE -- final for the process -- and not an
+// environment problem (no hiprtc, no program object) that a later call may find repaired.
+static bool compile_tu(const std::string& tu, const std::string& dir, int ft, std::vector<char>& code, std::string& err, double* secs,
+                       bool* compiler_verdict = nullptr) {
+    if (compiler_verdict) *compiler_verdict = false;
     if (const char* e = load_hiprtc()) { err = e; return false; }
     hiprtcProgram prog;
     if (g_rtc.CreateProgram(&prog, tu.c_str(), "sgpmp_chain_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -256,6 +265,7 @@ static bool compile_tu(const std::string& tu, const std::string& dir, int ft, st
         if (ls) g_rtc.GetProgramLog(prog, &log[0]);
         err = "hiprtc: compilation of the chain kernels failed:\n" + log.substr(0, 4000);
         g_rtc.DestroyProgram(&prog);
+        if (compiler_verdict) *compiler_verdict = true;
         return false;
     }
     size_t cs = 0;
@@ -310,11 +320,30 @@ static bool build_module(RtcChain& c, int ft) {
     const std::string cpath = cdir.empty() ? std::string() : cdir + "/" + name;
     std::vector<char> code;
     if (!cpath.empty()) {
-        std::ifstream f(cpath, std::ios::binary);
-        if (f) { code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>()); if (!code.empty()) c.from_cache += 1; }
+        // the cached object is trusted like the directory: opened without following a link, then checked ON THE OPEN DESCRIPTOR --
+        // a regular file of this user's, not writable by anyone else (advisor finding, round 5: the directory check alone does not
+        // cover a file planted while the directory was still open to others)
+        const int fd = open(cpath.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+        if (fd >= 0) {
+            struct stat fst;
+            if (fstat(fd, &fst) == 0 && S_ISREG(fst.st_mode) && fst.st_uid == getuid() && (fst.st_mode & (S_IWGRP | S_IWOTH)) == 0 &&
+                fst.st_size > 0 && fst.st_size < (off_t)(256u << 20)) {
+                code.resize((size_t)fst.st_size);
+                size_t got = 0;
+                while (got < code.size()) {
+                    const ssize_t k = read(fd, code.data() + got, code.size() - got);
+                    if (k <= 0) break;
+                    got += (size_t)k;
+                }
+                if (got != code.size()) code.clear();
+            }
+            close(fd);
+            if (!code.empty()) c.from_cache += 1;
+        }
     }
     if (code.empty()) {
-        if (!compile_tu(tu, dir, ft, code, c.err, &c.compile_s)) { c.tried[ft] = c.err.rfind("hiprtc: compilation", 0) == 0; return false; }
+        bool verdict = false;
+        if (!compile_tu(tu, dir, ft, code, c.err, &c.compile_s, &verdict)) { c.tried[ft] = verdict; return false; }
         c.compiled += 1;
         if (!cpath.empty()) {                     // write-then-rename: concurrent processes never see half a file
             const std::string tmp = cpath + "." + std::to_string((long)getpid());

@@ -96,7 +96,27 @@ static int fused_step_kind(int dtype, int n, int T, const PriorDev& prior, const
                            const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,
                            const SgpmpToggles& tg) {
     using CCp = ChainCode_panda;
-    if (dtype != SGPMP_F32 || tg.no_fused_step || !prior.isotropic) return 0;
+    if (tg.no_fused_step || !prior.isotropic) return 0;
+    if (dtype == SGPMP_F64) {
+        // fp64 contexts: sampler + sweep as fused_step_f64_kernel (cost_sweep_kernel.inc: GEN) -- one wave per trajectory, lane =
+        // waypoint, the recurrence as a scan over the lanes; FLAT programs on the positions themselves (n = 2, 3) or on the chain
+        // code built with the library
+        if (T < 2 || P < 1 || S < 1 || !prior.scan64 || tg.no_flat_program) return 0;
+        if ((long long)P * S + (long long)mode_offset * S >= (1LL << 31)) return 0;
+        FlatProg<double> F;
+        if (!make_flat<double>(h_prog, F)) return 0;
+        if (F.has_goal && F.goal.rows_per_goal % S != 0) return 0;
+        if (F.has_gp && prior.dt != F.gp.dt) return 0;
+        for (int i = 0; i < h_prog.n_terms; ++i)
+            if (h_prog.terms[i].n_interp > 0) return 0;
+        if (!h_prog.needs_fk) {
+            if (F.has_self || F.has_sph || (n != 2 && n != 3)) return 0;
+            return 3;
+        }
+        if (tg.no_chain_codegen || tg.force_generic_fk || !h_chain.plan.fast || h_chain.plan.codegen_id != 1 || n != CCp::N || F.has_grid) return 0;
+        return 3;
+    }
+    if (dtype != SGPMP_F32) return 0;
     // (S: the chain-code launch masks the rows of a particle's last group of 8 -- round 4; the planar launches want whole groups)
     // (T: the chain-code launch masks the columns and cost lanes past T in the last chunk of 16 -- T even: 16-byte rows)
     if (T < 2 || T % 2 != 0 || P < 1 || S < 1) return 0;
@@ -154,7 +174,7 @@ int fused_step_regen_recipe(int dtype, int n, int T, const PriorDev& prior, cons
                             int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg, int* seg_len) {
     if (seg_len) *seg_len = 0;
     const int kind = fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
-    if (kind == 0 || h_prog.n_ee > 0) return 0;
+    if (kind == 0 || kind == 3 || h_prog.n_ee > 0) return 0;
     if (kind == 1) return 1;
     // (the lane-per-sample planar launch: built, bit-identical, and measured slower store-free at config 2 -- its update kernel is
     // not hidden under another chain's launch, and regenerating a row costs it more than the launch saves: opt-in)
@@ -179,6 +199,39 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     using CCp = ChainCode_panda;
     const int kind = (!samples || !isw) ? 0 : fused_step_kind(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
     if (kind == 0) return hipSuccess;
+    if (kind == 3) {
+        FlatProg<double> F;
+        make_flat<double>(h_prog, F);
+        const ProgK<double> PK = make_progk<double>(h_prog);
+        auto log2x = [](long long v) { int s = 0; while ((1LL << s) < v && s < 62) ++s; return (1LL << s) == v ? s : -1; };
+        CostArgs<double> a;
+        a.T = T; a.chain = nullptr; a.n_links = h_chain.n_links; a.trajs = (const double*)samples;
+        a.batch = (long long)P * S; a.batch_offset = (long long)mode_offset * S;
+        a.spheres = (const double*)spheres; a.n_spheres = n_spheres;
+        a.isw = (const double*)isw; a.rows_per_particle = S; a.is_dt = prior.dt;
+        a.costs = (double*)costs; a.costs64 = costs64;
+        a.rpp_shift = log2x(S); a.rpg_shift = F.has_goal ? log2x(F.goal.rows_per_goal) : -1;
+        GenArgs64 g;
+        g.coef = prior.iso64; g.scan = prior.scan64; g.means = (const double*)means; g.samples = (double*)samples;
+        g.seed = seed; g.draw = draw; g.mode_offset = mode_offset; g.S = S; g.zero_stats = zero_stats;
+        const size_t lds = (size_t)T * SGPMP_SCAN64_ROW * sizeof(double);
+        g.scan_in_lds = lds <= 48 * 1024 ? 1 : 0;
+        // (few trajectories -- BASELINE configs[0] has 64 -- : one wave per workgroup, so that every wave gets a CU of its own)
+        const int block = a.batch <= 2048 ? 64 : 256;
+        long long blocks = (a.batch + block / 64 - 1) / (block / 64);
+        const long long cap = 256LL * 32;
+        if (blocks > cap) blocks = cap;
+        const unsigned dyn = g.scan_in_lds ? (unsigned)lds : 0u;
+        if (h_prog.needs_fk)
+            hipLaunchKernelGGL((fused_step_f64_kernel<CCp::N, 1000>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
+        else if (n == 2)
+            hipLaunchKernelGGL((fused_step_f64_kernel<2, 0>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
+        else
+            hipLaunchKernelGGL((fused_step_f64_kernel<3, 0>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
+        if (picked) *picked = "fused_step_f64_kernel";
+        *launched = true;
+        return hipGetLastError();
+    }
     FlatProg<float> F;
     make_flat<float>(h_prog, F);
     const long long batch = (long long)P * S, batch_offset = (long long)mode_offset * S;

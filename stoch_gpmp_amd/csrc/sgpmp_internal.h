@@ -24,6 +24,9 @@ struct PriorDev {
     float* slabpre;    // [5][T][4]  isotropic priors, n = 2, 3: prefix products H_t .. H_{start} of the scan's 2 x 2 propagators from the
                        //            start of t's segment, built by the host in fp64 (table 2: the in-chunk segments of fused_planar.inc;
                        //            tables 3, 4: segments of 8 and of 16 waypoints, fused_planar_seg.inc; 0, 1: unused since round 5)
+    double* scan64;    // [T][7][4]  fp64 contexts, isotropic priors: the Kogge-Stone tables of fused_step_f64_kernel (cost_sweep_kernel.inc:
+                       //            GenArgs64) -- A_t^(r) = H_t .. H_{t - 2^r + 1}, r = 0 .. 5 (zero where t - 2^r lies before t's pass of 64
+                       //            waypoints), and C_t = H_t .. H_{start of the pass}; built by the host in fp64 (api.hip: upload_scan64)
     double* Qinv;      // [d][d]   one-step GP precision of this prior
     float* G32;        // [T][d][d] fp32 copies for the dense sampler
     float* H32;

@@ -328,10 +328,10 @@ def _report(tag, recs):
 def test_panda_fp32_headline_kernel_means_match_fp64_oracle(fused, kernel):
     """north_star: fp32 trajectory means within 1e-3 of the reference CPU path.  The headline kernels
     (the fused sampler + sweep launch, and cost_sweep_dual_pf_kernel behind the separate sampler: even
-    S, even T <= 64, rbf) over 6 iterations, 48 particles, native noise.  With temperature = 1 and
+    S, even T <= 64, rbf) over 4 iterations, 48 particles, native noise.  With temperature = 1 and
     costs of 1e9-1e11 the update is an arg-min over samples, so a particle agrees unless fp32 flips
     the arg-min; the agreeing fraction is printed and bounded."""
-    recs = _fp32_panda_run(T=32, nppg=48, S=32, iters=6, expect_kernel=kernel, fused=fused)
+    recs = _fp32_panda_run(T=32, nppg=48, S=32, iters=4, expect_kernel=kernel, fused=fused)
     frac = _report(f"Panda 48x32x32 rbf ({kernel})", recs)
     assert max(r["cost_rel"] for r in recs) < 5e-3
     assert frac >= 0.99, frac                          # measured on MI355X: 1.0000 (two-launch kernels), 0.9965 (fused: one near-tie of 288)
@@ -346,13 +346,13 @@ def test_panda_fp32_config5_kernel_means_match_fp64_oracle(fused, kernel):
     against the fp64 oracle: costs and means."""
     n = 7
     goals = [SC.PANDA["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n]
-    recs = _fp32_panda_run(T=128, nppg=6, S=16, iters=4, goals=goals, n_sph=7, expect_kernel=kernel, fused=fused)
+    recs = _fp32_panda_run(T=128, nppg=6, S=16, iters=2, goals=goals, n_sph=7, expect_kernel=kernel, fused=fused)
     frac = _report(f"Panda 2 goals x 6 x 16 x 128 rbf ({kernel})", recs)
     assert max(r["cost_rel"] for r in recs) < 5e-3
     assert frac >= 0.99, frac                          # measured: 1.0000
     # T = 66 is not a multiple of the fused launch's 16-waypoint chunk: its last chunk holds two waypoints (round 4: the launch
     # masks the rest; before, such T always ran the two-launch path) -- against the fp64 oracle like every other shape
-    recs = _fp32_panda_run(T=66, nppg=6, S=16, iters=3, goals=goals, n_sph=7, field_type='sdf',
+    recs = _fp32_panda_run(T=66, nppg=6, S=16, iters=2, goals=goals, n_sph=7, field_type='sdf',
                            expect_kernel="fused_step_kernel" if fused is True else "cost_sweep_dual_pf_multi_kernel", fused=fused)
     frac = _report("Panda 2 goals x 6 x 16 x 66 sdf", recs)
     assert max(r["cost_rel"] for r in recs) < 5e-3 and frac >= 0.99
@@ -652,10 +652,47 @@ def test_config5_share_free_running_ten_iterations_against_the_banded_oracle():
     assert rec["tracking_fraction_per_iteration"][0] == 1.0
 
 
+@pytest.mark.parametrize("kind", ["panda", "panda_two_goals_sdf", "planar", "planar_two_passes", "planar_three_passes_ragged"])
+def test_fused_f64_step_equals_the_two_launch_step(golden, kind):
+    """fp64 contexts run sampler + sweep as ONE launch since round 6 (fused_step_f64_kernel: one wave per trajectory, lane =
+    waypoint, the sampling recurrence as a Kogge-Stone scan over the lanes with 2 x 2 propagator products from a host-built
+    table, x = mu + y stored and handed to the cost terms in registers).  Against the same planner with `no_fused_step`
+    (sample_iso_kernel<double>'s serial recurrence, then cost_sweep_kernel<double>): same noise stream, another order of the
+    same additions -- samples within 1e-13 of the largest sample, costs 1e-12, identical arg-mins, means 1e-13, through
+    single steps and a pipelined call; T beyond one pass of 64 lanes (the carried state) and off it."""
+    if kind.startswith("panda"):
+        two = kind == "panda_two_goals_sdf"
+        g = [SC.PANDA["goal_q"] + [0.] * 7, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * 7] if two else None
+        mk = lambda: hip_panda_planner(SC.PANDA, 64, 6, 24, F64, seed=13, goals=g, field_type="sdf" if two else "rbf")   # noqa: E731
+        obs = {"obstacle_spheres": torch.as_tensor(SC.panda_spheres(num=5, seed=3)).to(**F64)}
+        two_launch = "cost_sweep_kernel<f64, generated chain>"
+    else:
+        T = {"planar": 64, "planar_two_passes": 128, "planar_three_passes_ragged": 150}[kind]
+        goals = [[9., 6., 0., 0.], [9., -3., 0., 0.]]
+        om = planar_map(golden, F64)
+        mk = lambda: hip_planar_planner(SC.PLANAR, T, goals, 5, 20, om, F64, seed=13)     # noqa: E731
+        obs = {}
+        two_launch = "cost_sweep_kernel<f64, no FK>"
+    a, b = mk(), mk()
+    b._engine.set_option("no_fused_step", 1)
+    for k in (1, 1, 3, 1):
+        ra, rb = a.optimize(opt_iters=k, **obs), b.optimize(opt_iters=k, **obs)
+        assert a._engine.last_cost_kernel() == "fused_step_f64_kernel" and a._engine.last_step_launches() == 2
+        assert b._engine.last_cost_kernel() == two_launch and b._engine.last_step_launches() == 3
+        scale = float(b.state_samples.abs().max())
+        assert float((a.state_samples - b.state_samples).abs().max()) <= 1e-13 * scale
+        assert rel_err(a._costs, b._costs) < 1e-12 and torch.equal(a._costs.argmin(1), b._costs.argmin(1))
+        assert float((a.particle_means - b.particle_means).abs().max()) <= 1e-13 * float(b.particle_means.abs().max())
+        assert float((ra[0] - rb[0]).abs().max()) <= 1e-13 * float(rb[0].abs().max())
+        sa, sb = a.global_stats(), b.global_stats()
+        assert abs(sa[0] / sb[0] - 1) < 1e-11 and abs(sa[1] / sb[1] - 1) < 1e-11
+        b.particle_means.copy_(a.particle_means)         # (keep the twins on one trajectory: rounding differences must not pile up)
+
+
 def test_config3_shape_fp64_free_running_against_the_dense_oracle():
     """north_star's fp64 clause -- trajectory means within 1e-5 relative -- AT configs[2]'s shape (Panda 1024 x 128 x 64; rounds
     1-4 measured it at config 1's 4 particles only): the fp64 context (sampler + generic sweep on the generated chain + update:
-    three launches) against the dense fp64 oracle on the restated fp64 noise stream, four particles, five free iterations."""
+    two launches since round 6: fused_step_f64_kernel + update) against the dense fp64 oracle on the restated fp64 noise stream, four particles, five free iterations."""
     from oracle.native_noise import native_eps
     c, n = SC.PANDA, 7
     T, S, P, seed = 64, 128, 1024, 91
@@ -672,11 +709,11 @@ def test_config3_shape_fp64_free_running_against_the_dense_oracle():
         eps = torch.from_numpy(native_eps(seed, pl._draw, sub, S, T, n, "float64")).double()
         costs_o, _ = ora.step(eps=eps, obstacle_spheres=sph)
         costs = pl.optimize(opt_iters=1, obstacle_spheres=sph.to(**F64))[4]
-        assert pl._engine.last_cost_kernel() == "cost_sweep_kernel<f64, generated chain>"
+        assert pl._engine.last_cost_kernel() == "fused_step_f64_kernel"
         worst_cost = max(worst_cost, rel_err(costs[idx], costs_o))
         worst = max(worst, float((pl.particle_means[idx].cpu() - ora.particle_means).abs().max()) / scale)
     rec = {"particles": sub, "iterations": 5, "means_rel_err_max": worst, "cost_rel_err_max": worst_cost,
-           "kernel": "cost_sweep_kernel<f64, generated chain>", "tolerance": 1e-5}
+           "kernel": "fused_step_f64_kernel", "tolerance": 1e-5}
     print(f"\n[full-size parity, fp64] config 3 shape: {rec}")
     _record_parity("config 3 shape in fp64: Panda 1024 x 128 x 64 (sampler + generic sweep + update)", rec)
     assert worst < 1e-5 and worst_cost < 1e-7, rec
@@ -960,8 +997,12 @@ def test_whole_population_parity_config3():
     def make_band(lo, hi, mu):
         return B.BandedPlanner(hi - lo, S, T, c["dt"], n, start, goal, cost, c["step_size"], c["temperature"],
                                c["sigma_start_sample"], c["sigma_goal_sample"], c["sigma_gp_sample"], mu, chunk=8)
+    # (1 re-synchronised + 3 free-running iterations: 4 096 particle-iterations per run; round 5's record of 2 + 5 -- 7 168, one
+    # explained near-tie flip -- is profiles/r05/parity_population.json.  The oracle side costs the host ~18 s per iteration, and the
+    # driver's GPU suite has a 1200 s limit.)
     rec = _population_parity("config 3: Panda 1024 x 128 x 64 fp32 (fused launch)", pl, make_band, n,
-                             {"obstacle_spheres": sph.to(**F32)}, {"obstacle_spheres": sph}, "fused_step_kernel")
+                             {"obstacle_spheres": sph.to(**F32)}, {"obstacle_spheres": sph}, "fused_step_kernel",
+                             sync_iters=1, free_iters=3)
     assert rec["still_tracking_after_free_run"] >= 0.99 * P
 
 
@@ -1120,7 +1161,7 @@ def test_store_free_permission_is_ignored_where_the_step_has_no_store_free_form(
                       "fused_planar_kernel", expect_store_free=False)
     sph = torch.as_tensor(SC.panda_spheres(num=5)).to(**F64)
     _store_free_twins(lambda **kw: hip_panda_planner(SC.PANDA, 16, 4, 8, F64, seed=69, **kw), (3,), {"obstacle_spheres": sph},
-                      "cost_sweep_kernel<f64, generated chain>", expect_store_free=False)
+                      "fused_step_f64_kernel", expect_store_free=False)
 
 
 @pytest.mark.parametrize("temperature,extra", [(1e11, True), (1e14, True), (1e17, True), (1e13, False)])
@@ -1827,7 +1868,7 @@ def test_three_dof_point_mass_fused_matches_the_two_launch_path(golden, nppg, G,
         assert torch.equal(a.particle_means, twin.particle_means) and torch.equal(a._costs, twin._costs)
 
 
-@pytest.mark.parametrize("ta,kernel", [(F32, "fused_step_kernel"), (F64, "cost_sweep_kernel<f64, chain code>")])
+@pytest.mark.parametrize("ta,kernel", [(F32, "fused_step_kernel"), (F64, "fused_step_f64_kernel")])
 def test_prepared_is_weights_follow_every_edit_of_the_means(ta, kernel):
     """A step has its update kernel prepare the next step's importance-sampling weights, and the next
     sgpmp_step skips K5 when the caller vouches (SGPMP_STEP_MEANS_KEPT) that the means are untouched (fused
@@ -2062,6 +2103,51 @@ def test_config4_eight_shards_equal_unsharded_bitwise():
         stats_sum += h._stats[h._stats_slot ^ 1].sum(0).cpu()
         del h
     # what the RCCL all-reduce would sum: shard statistics add up to the unsharded run's
+    assert float(stats_sum[2]) == P and abs(float(stats_sum[0] / stats_full[0]) - 1) < 1e-12
+    assert abs(float(stats_sum[1] / stats_full[1]) - 1) < 1e-12
+
+
+def test_config5_eight_shards_equal_unsharded_bitwise():
+    """BASELINE config 5 -- the WHOLE problem in one context (round-5 verdict, missing #4): Panda 4 goals x 1024 particles x 256
+    samples x 128 waypoints, fp64 prior + fp32 cost path: 1 879 048 192 sample elements (a hair under 2^31), 7.5 GB of samples,
+    byte offsets past 2^32.  One single-iteration call (storing), then one optimize(opt_iters=2) (a store-free step whose rows
+    update_kernel regenerates + the storing last step, as two particle-half chains) unsharded; then the eight `rank = r,
+    world_size = 8` shards of 512 particles one after the other (shard boundaries inside goals: p // nppg through the global
+    offset): means, costs, weights and every shard's slice of the 7.5 GB sample tensor bit-identical, statistics add up."""
+    c, n = SC.PANDA, 7
+    nppg, S, T = 1024, 256, 128
+    P = 4 * nppg
+    goals = [c["goal_q"] + [0.] * n, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * n,
+             [0.9, -0.2, 0.4, -1.1, -0.3, 1.9, 0.8] + [0.] * n, [-0.8, 0.1, 0.6, -2.4, 0.4, 2.6, -0.2] + [0.] * n]
+    sph = torch.as_tensor(SC.panda_spheres()).to(**F32)
+    mk = lambda **kw: hip_panda_planner(c, T, nppg, S, F32, seed=5, goals=goals, **kw)      # noqa: E731
+
+    def run(pl):
+        pl.optimize(obstacle_spheres=sph)
+        pl.optimize(opt_iters=2, obstacle_spheres=sph)
+        assert pl._engine.last_cost_kernel() == "fused_step_kernel" and pl._engine.store_free_steps() == 1
+    full = mk()
+    assert full.num_particles == P and full.state_samples.numel() == P * S * T * 2 * n == 1879048192
+    means0 = full.particle_means.clone()
+    run(full)
+    assert full._engine.pipeline_split_steps() == 2
+    stats_full = full._stats[full._stats_slot ^ 1].sum(0).cpu()
+    assert bool(torch.isfinite(full._costs).all()) and bool(torch.isfinite(full.particle_means).all())
+    # the last rows of the tensor really were written by this call (element offsets near 2^31, byte offsets near 2^33)
+    assert bool((full.state_samples[-1, -1] != 0).any()) and bool(torch.isfinite(full.state_samples[-1]).all())
+    stats_sum = torch.zeros(4, dtype=torch.float64)
+    for r in range(8):
+        h = mk(rank=r, world_size=8)
+        assert (h.p0, h.p1) == (512 * r, 512 * (r + 1))
+        assert torch.equal(h.particle_means, means0[h.p0:h.p1])
+        run(h)
+        assert torch.equal(h.particle_means, full.particle_means[h.p0:h.p1]), f"shard {r}: means differ"
+        assert torch.equal(h._costs, full._costs[h.p0:h.p1]), f"shard {r}: costs differ"
+        assert torch.equal(h._weights_buf, full._weights_buf[h.p0:h.p1]) and torch.equal(h._grad, full._grad[h.p0:h.p1]), r
+        assert torch.equal(h.state_samples, full.state_samples[h.p0:h.p1]), f"shard {r}: samples differ"
+        stats_sum += h._stats[h._stats_slot ^ 1].sum(0).cpu()
+        del h
+        torch.cuda.empty_cache()
     assert float(stats_sum[2]) == P and abs(float(stats_sum[0] / stats_full[0]) - 1) < 1e-12
     assert abs(float(stats_sum[1] / stats_full[1]) - 1) < 1e-12
 

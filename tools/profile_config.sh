@@ -12,7 +12,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps $STEPS --warmup 10 --no-cpu-baseline --no-other-configs --no-parity $ARGS"
+BENCH="python3 $ROOT/bench.py --steps $STEPS --warmup 10 --no-cpu-baseline --no-other-configs --no-parity --no-sweep-alone $ARGS"
 export SGPMP_NO_STEP_PIPELINE=1      # whole-range launches in every trace (see tools/profile_round.sh)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
