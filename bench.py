@@ -332,28 +332,42 @@ def store_free_leg(torch, spec_kwargs, dev, config_key, steps, storing_ms, passe
     return out
 
 
-def sweep_alone_leg(torch, pl, obs, N_elems, w, costs_bytes, steps=30):
-    """north_star's ">= 40 % of the HBM roofline on the cost-gradient sweep" is about the STAND-ALONE sweep: the same planner
-    with K2 and K3 as separate launches (option no_fused_step), timed with HIP events on the launch stream.  Sweep bytes =
+def sweep_alone_leg(torch, pl, obs, N_elems, w, costs_bytes, reps=60):
+    """north_star's ">= 40 % of the HBM roofline on the cost-gradient sweep" is about the STAND-ALONE sweep: sgpmp_cost_eval on the
+    planner's own sample tensor (K3 as a launch of its own: what sample_and_eval() and the two-launch steps run), `reps` launches
+    back to back between two HIP events on the launch stream -- likewise the stand-alone sampler (sgpmp_sample).  Sweep bytes =
     N w + P S 8; sampler bytes = N w."""
-    eng = pl._engine
-    eng.set_option("no_fused_step", 1)
-    try:
-        for _ in range(10):
-            pl.optimize(opt_iters=1, **obs)
-        kms = kernel_profile(torch, pl, obs, steps)
-        kernel = eng.last_cost_kernel()
-    finally:
-        eng.set_option("no_fused_step", 0)
-    pl.optimize(opt_iters=1, **obs)
-    sweep_ms, samp_ms = kms["cost_sweep"], kms.get("sample")
-    out = {"kernel": kernel, "launch_ms": sweep_ms, "algorithmic_bytes": N_elems * w + costs_bytes,
-           "frac": (N_elems * w + costs_bytes) / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "kernel_ms_per_step": kms}
-    if samp_ms:
-        out.update(sampler_kernel="sample_iso_kernel", sampler_launch_ms=samp_ms,
-                   sampler_frac=N_elems * w / (samp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
-    return out
+    from stoch_gpmp_amd import _lib as L
+    eng, S = pl._engine, pl.num_samples
+    sph = pl._spheres(obs)
+    isw = eng.is_weights(pl.particle_means, pl.temperature)
+
+    def sweep():
+        eng.cost_eval(pl.state_samples, batch_offset=pl.p0 * S, spheres=sph, is_weights=isw, rows_per_particle=S,
+                      out=pl._costs, out64=pl._costs64)
+
+    def sampler():
+        eng.sample(L.PRIOR_SAMPLE, pl.seed, 1 << 20, pl.particle_means, S, out=pl.state_samples, mode_offset=pl.p0)
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+    sweep_ms = timed(sweep)
+    kernel = eng.last_cost_kernel()
+    samp_ms = timed(sampler)
+    pl.optimize(opt_iters=1, **obs)                        # (the planner's buffers hold a step's tensors again)
+    return {"kernel": kernel, "launch_ms": sweep_ms, "algorithmic_bytes": N_elems * w + costs_bytes,
+            "frac": (N_elems * w + costs_bytes) / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "sampler_kernel": "sample_iso_kernel", "sampler_launch_ms": samp_ms,
+            "sampler_frac": N_elems * w / (samp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_timed": reps,
+            "how": "launches back to back between two HIP events on the launch stream"}
 
 
 OTHER_SPECS = [
@@ -681,7 +695,7 @@ def main():
                       + 3 * P_local * S * 8)
         # the stand-alone sampler and sweep of the same planner (north_star's 40 % clause is about THAT launch)
         alone = None
-        if world == 1 and fused and not args.no_sweep_alone and not args.store_free and sweep_kernel.startswith("fused_step"):
+        if world == 1 and fused and not args.no_sweep_alone and not args.store_free:
             alone = sweep_alone_leg(torch, pl, obs, N_elems, w, P_local * S * 8)
         # the store-free mode of the same workload (the product's default inside one optimize() call), beside the headline
         sfree = None

@@ -35,7 +35,8 @@ extern "C" {
  * 4: sgpmp_comm_library, sgpmp_set_fk_codegen / _info / _compile, sgpmp_dense_particles (round 4);
  * 5: SGPMP_STEP_NO_SAMPLES, sgpmp_row_counts_get / _set, sgpmp_store_free_steps, sgpmp_step honours per-mode sampling
  *    precisions; the options of the retired experiments are gone (round 5);
- * 6: sgpmp_optimize (the K-loop of optimize() behind the ABI), sgpmp_row_counts_clear (round 6).
+ * 6: sgpmp_optimize (the K-loop of optimize() behind the ABI), sgpmp_row_counts_clear, sgpmp_noise; fp64 contexts draw the
+ *    fp32 noise stream, widened (round 6).
  * The Python binding refuses any other value at load time. */
 #define SGPMP_ABI_VERSION 6
 
@@ -230,6 +231,17 @@ int sgpmp_fk_codegen_compile(const char* chain_struct_source, int field_type, in
 int sgpmp_sample(sgpmp_ctx* ctx, int which, uint64_t seed, uint64_t draw, const void* means,
                  int n_modes, int mode_offset, int n_samples, const void* eps, int eps_modes,
                  int eps_mode_offset, void* out, void* stream);
+
+/* The noise itself: out[s][m][:] = the eps of sample s of mode m (global particle mode_offset + m) at draw `draw`, in the layout
+ * of torch's randn(n_samples, n_modes, T*d) (multivariate_normal.py:250-253; element t*d + k: position noise of dof k at
+ * waypoint t, t*d + n + k: its velocity noise) and the context's dtype -- exactly the values sgpmp_sample / sgpmp_step /
+ * sgpmp_optimize draw for eps == NULL.  One counter-based stream serves fp32 and fp64 contexts (Philox4x32 + the fp32
+ * Box-Muller, widened for fp64: csrc/rng.h), keyed on (seed, draw, global particle, sample, waypoint pair, dof).  What it is
+ * for: feeding the SAME eps to the reference's algorithm (oracle/ref_equiv.py: TrajPrior.sample(eps=...)) -- the hardware's
+ * log2 / sin / cos are approximations that a CPU restatement (oracle/native_noise.py) reproduces to an ulp of fp32, not bit
+ * for bit.  The reference draws from torch's sequential generator and has no counterpart. */
+int sgpmp_noise(sgpmp_ctx* ctx, uint64_t seed, uint64_t draw, int n_modes, int mode_offset, int n_samples, void* out,
+                void* stream);
 
 /* K3. CostComposite.eval (cost_functions.py:47-58): trajs [B,T,d] -> costs [B].
  * Row b of the batch is global row batch_offset + b (for CostGoalPrior's goal lookup).

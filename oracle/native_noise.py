@@ -3,8 +3,10 @@
 The reference draws eps = randn(S, P, M) from torch's sequential global generator (planner.py:48-49,
 torch multivariate_normal.py:250-253); the HIP sampler's default mode replaces that by a counter-based
 stream (csrc/rng.h): Philox4x32-R, R = 7 by default, 10 as a build option (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3",
-SC'11 -- the generator behind curand / torch.cuda) + Box-Muller, keyed on
-(seed, draw, global particle, sample, waypoint pair, dof).  This file restates that stream so that the
+SC'11 -- the generator behind curand / torch.cuda) + the fp32 Box-Muller (fp64 contexts draw the same normals, widened), keyed on
+(seed, draw, global particle, sample, waypoint pair, dof).  The device forms log2 / sin / cos on the hardware's approximating units;
+this restatement forms them in fp64 and rounds: equal to an ulp of fp32, not bit for bit -- tests that need the device's exact
+eps read it back through sgpmp_noise (Engine.noise).  This file restates that stream so that the
 native mode has a deterministic checker too: `native_eps(...)` returns the noise in torch's
 `randn(S, P, M)` layout, ready for `oracle.ref_equiv.TrajPrior.sample(eps=...)`.
 
@@ -55,16 +57,6 @@ def box_muller_f32(a, b):
     return (r * np.cos(ang)).astype(np.float32), (r * np.sin(ang)).astype(np.float32)
 
 
-def box_muller_f64(a, b, c, d):
-    """csrc/rng.h box_muller_f64: 53-bit uniforms from two words each."""
-    m1 = ((a.astype(np.uint64) << np.uint64(32)) | b.astype(np.uint64)) >> np.uint64(11)
-    m2 = ((c.astype(np.uint64) << np.uint64(32)) | d.astype(np.uint64)) >> np.uint64(11)
-    u1 = (m1.astype(np.float64) + 0.5) * 1.1102230246251565e-16
-    u2 = m2.astype(np.float64) * 1.1102230246251565e-16
-    r = np.sqrt(-2.0 * np.log(u1))
-    return r * np.cos(2.0 * np.pi * u2), r * np.sin(2.0 * np.pi * u2)
-
-
 def native_eps(seed, draw, particles, S, T, n, dtype="float32", rounds=None):
     """Noise of the HIP sampler for global particle indices `particles` -> [S, len(particles), T*2n]
     (torch.randn(S, P, M) layout: element t*d + k is the position noise of dof k at waypoint t,
@@ -78,14 +70,9 @@ def native_eps(seed, draw, particles, S, T, n, dtype="float32", rounds=None):
     m_idx = particles.reshape(1, P, 1, 1)
     k_idx = np.arange(n, dtype=np.uint64).reshape(1, 1, 1, n)
     c3 = np.uint64(draw & 0xFFFFFFFF)
+    # (one stream for both precisions since round 6: fp64 contexts draw the fp32 normals, widened -- csrc/rng.h NoiseGen<double>)
     out = np.zeros((S, P, T, d), dtype=np.float64 if dtype == "float64" else np.float32)
-    if dtype == "float64":
-        t_idx = np.arange(T, dtype=np.uint64).reshape(1, 1, T, 1)
-        x, y, z, w = philox4x32(t_idx | (k_idx << np.uint64(20)), s_idx, m_idx,
-                                c3 ^ np.uint64(0x80000000), k0, k1, rounds)
-        z0, z1 = box_muller_f64(x, y, z, w)
-        out[..., :n], out[..., n:] = z0, z1
-    else:
+    if True:
         nb = (T + 1) // 2
         b_idx = np.arange(nb, dtype=np.uint64).reshape(1, 1, nb, 1)
         x, y, z, w = philox4x32(b_idx | (k_idx << np.uint64(20)), s_idx, m_idx, c3, k0, k1, rounds)

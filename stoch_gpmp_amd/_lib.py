@@ -84,6 +84,7 @@ SIGNATURES = {
     "sgpmp_fk_codegen_compile": (_I, [C.c_char_p, _I, C.POINTER(_I64)]),
     "sgpmp_fk_codegen_info": (_I, [_P, C.POINTER(_I), C.POINTER(_D), C.POINTER(_I), C.POINTER(_I)]),
     "sgpmp_sample": (_I, [_P, _I, _U64, _U64, _P, _I, _I, _I, _P, _I, _I, _P, _P]),
+    "sgpmp_noise": (_I, [_P, _U64, _U64, _I, _I, _I, _P, _P]),
     "sgpmp_cost_eval": (_I, [_P, _P, _I64, _I64, _P, _I, _P, _I, _P, _P, _P]),
     "sgpmp_is_weights": (_I, [_P, _P, _I, _D, _P, _P]),
     "sgpmp_update": (_I, [_P, _P, _I, _P, _P, _D, _D, _P, _P, _P, _P, _P]),

@@ -923,6 +923,14 @@ static int check_spheres(sgpmp_ctx* c, const void* spheres, int n_spheres) {
     return SGPMP_OK;
 }
 
+extern "C" int sgpmp_noise(sgpmp_ctx* c, uint64_t seed, uint64_t draw, int n_modes, int mode_offset, int n_samples, void* out,
+                           void* stream) {
+    if (!c || !out || n_modes < 0 || mode_offset < 0 || n_samples < 0) return fail(SGPMP_EINVAL, "sgpmp_noise: bad argument");
+    HIPCHK(launch_noise(c->dims.dtype, c->dims.n_dof, c->dims.traj_len, n_modes, mode_offset, n_samples, seed, draw, out,
+                        (hipStream_t)stream));
+    return SGPMP_OK;
+}
+
 extern "C" int sgpmp_cost_eval(sgpmp_ctx* c, const void* trajs, int64_t batch, int64_t batch_offset,
                                const void* spheres, int n_spheres, const void* is_weights,
                                int rows_per_particle, void* costs, double* costs64, void* stream) {

@@ -215,9 +215,11 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         g.coef = prior.iso64; g.scan = prior.scan64; g.means = (const double*)means; g.samples = (double*)samples;
         g.seed = seed; g.draw = draw; g.mode_offset = mode_offset; g.S = S; g.zero_stats = zero_stats;
         const size_t lds = (size_t)T * SGPMP_SCAN64_ROW * sizeof(double);
-        g.scan_in_lds = lds <= 48 * 1024 ? 1 : 0;
-        // (few trajectories -- BASELINE configs[0] has 64 -- : one wave per workgroup, so that every wave gets a CU of its own)
+        // (few trajectories -- BASELINE configs[0] has 64 -- : one wave per workgroup, so that every wave gets a CU of its own, and
+        // the lanes read their rows of the scan table straight from memory: staging 14 KB per workgroup for one or two items is a
+        // string of dependent round trips a latency-bound launch cannot hide)
         const int block = a.batch <= 2048 ? 64 : 256;
+        g.scan_in_lds = (lds <= 48 * 1024 && a.batch > 2048) ? 1 : 0;
         long long blocks = (a.batch + block / 64 - 1) / (block / 64);
         const long long cap = 256LL * 32;
         if (blocks > cap) blocks = cap;

@@ -73,19 +73,6 @@ __device__ __forceinline__ void box_muller_f32(uint32_t a, uint32_t b, float& z0
     z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
-__device__ __forceinline__ void box_muller_f64(uint32_t a, uint32_t b, uint32_t c, uint32_t d,
-                                               double& z0, double& z1) {
-    const uint64_t m1 = (((uint64_t)a << 32) | b) >> 11;             // 53 bits
-    const uint64_t m2 = (((uint64_t)c << 32) | d) >> 11;
-    const double u1 = ((double)m1 + 0.5) * 1.1102230246251565e-16;   // (0,1)
-    const double u2 = (double)m2 * 1.1102230246251565e-16;           // [0,1)
-    const double r = sqrt(-2.0 * log(u1));
-    double s, co;
-    sincospi(2.0 * u2, &s, &co);
-    z0 = r * co;
-    z1 = r * s;
-}
-
 // ---- one step of the scan recurrence  y_t = H_t y_{t-1} + G_t eps_t  of an isotropic prior, per (sample, dof):
 //     pn = g11 e_pos + h11 p + h12 v,     vn = g21 e_pos + g22 e_vel + h21 p + h22 v
 // in ONE evaluation order, every product-sum an explicit fma, so that hipcc has no choice of which multiply to fuse with which
@@ -214,19 +201,24 @@ template <> struct NoiseGen<float> {
     }
 };
 
+// fp64 contexts draw the SAME normals as fp32 contexts (round 6): the fp32 Box-Muller of the block of waypoints (t, t ^ 1), widened.
+// Rounds 1-5 gave them a stream of their own -- 53-bit uniforms, log / sqrt / sincospi in double: ~120 software fp64 operations
+// per pair of normals, a third of an fp64 step's vector instructions -- for digits of the NOISE that no result depends on (the
+// reference draws torch.randn from a generator that cannot be matched natively anyway; parity with it is the external-eps mode).
+// One stream for both precisions also lets an fp32 planner be compared with its fp64 twin on identical noise at any size.
+// The exact values a context's kernels use can be read back with sgpmp_noise (the hardware's log2 / sin / cos are approximations
+// that a CPU restatement reproduces to an ulp of fp32, not bit for bit).
 template <> struct NoiseGen<double> {
-    uint32_t k0, k1, c1, c2, c3, kk;
-    __device__ __forceinline__ void init(uint64_t seed, uint64_t draw, uint32_t mode, uint32_t s,
-                                         uint32_t k) {
-        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
-        c1 = s; c2 = mode; c3 = (uint32_t)draw; kk = k << 20;
-    }
+    NoiseGen<float> g;
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t draw, uint32_t mode, uint32_t s, uint32_t k) { g.init(seed, draw, mode, s, k); }
     __device__ __forceinline__ void get(int t, double& e_pos, double& e_vel) {
-        const Philox4 r = philox4x32_r((uint32_t)t | kk, c1, c2, c3 ^ 0x80000000u, k0, k1);
-        box_muller_f64(r.x, r.y, r.z, r.w, e_pos, e_vel);
+        float p, v;
+        g.get(t, p, v);
+        e_pos = (double)p; e_vel = (double)v;
     }
     __device__ __forceinline__ void get4(int t_even, double (&e)[4]) {
-        get(t_even, e[0], e[1]);
-        get(t_even + 1, e[2], e[3]);
+        float f[4];
+        g.get4(t_even, f);
+        e[0] = (double)f[0]; e[1] = (double)f[1]; e[2] = (double)f[2]; e[3] = (double)f[3];
     }
 };

@@ -190,7 +190,7 @@ sample_iso_small_kernel(int n_arg, int T, int S, int SPB, int TC, const real* __
 #if defined(SGPMP_SMALL_SKIP) && SGPMP_SMALL_SKIP == 1
         if (false) {} else if (false)
 #endif
-        if (sizeof(real) == 4) {
+        {   // (both precisions: a Philox block serves the waypoints (2b, 2b + 1) -- fp64 contexts draw the fp32 stream, widened: rng.h)
             const int pairs = (tc + 1) >> 1;              // t0 is even: blocks cover waypoints (2b, 2b+1)
             for (int w = tid; w < chains * pairs; w += blockDim.x) {
                 const int c = w / pairs, b = w - c * pairs;
@@ -203,18 +203,6 @@ sample_iso_small_kernel(int n_arg, int T, int S, int SPB, int TC, const real* __
                 real* o = tile + (size_t)sl * pitch + (2 * b) * d + k;
                 scan_step_noise<real>(cw, e[0], e[1], o[0], o[n]);
                 if (2 * b + 1 < tc) scan_step_noise<real>(cw + 8, e[2], e[3], o[d], o[d + n]);
-            }
-        } else {
-            for (int w = tid; w < chains * tc; w += blockDim.x) {
-                const int c = w / tc, tt = w - c * tc;
-                const int sl = c / n, k = c - sl * n;
-                const real* cw = coef + (size_t)(t0 + tt) * 8;
-                NoiseGen<real> gen;
-                gen.init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)(s0 + sl), (uint32_t)k);
-                real e1, e2;
-                gen.get(t0 + tt, e1, e2);
-                real* o = tile + (size_t)sl * pitch + tt * d + k;
-                scan_step_noise<real>(cw, e1, e2, o[0], o[n]);
             }
         }
         SST(0);
@@ -438,4 +426,42 @@ hipError_t launch_sample(int dtype, int n, int T, const PriorDev& prior, uint64_
     return sample_dispatch<float>(n, T, prior, seed, draw, (const float*)means, n_modes, mode_offset,
                                   n_samples, (const float*)eps, eps_modes, eps_mode_offset,
                                   (float*)out, stream, tg, zero_stats);
+}
+
+// ---------------------------------------------------------------------------------- the noise itself
+// eps[s][m][t * d + k] (position noise of dof k at waypoint t), eps[s][m][t * d + n + k] (velocity noise): torch.randn(S, P, M)'s
+// layout (multivariate_normal.py:250-253), the values every sampling kernel of this library draws for (seed, draw, global
+// particle mode_offset + m, sample s) -- the same calls, NoiseGen<real>::get4 on the block of waypoints (2b, 2b + 1).
+template <typename real>
+__global__ void __launch_bounds__(256)
+noise_dump_kernel(int n, int T, int n_modes, int mode_offset, int S, uint64_t seed, uint64_t draw, real* __restrict__ out) {
+    const long long pairs = (T + 1) / 2, total = (long long)S * n_modes * pairs * n;
+    const size_t d = 2 * (size_t)n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % n);
+        long long r = i / n;
+        const int b = (int)(r % pairs);
+        r /= pairs;
+        const int m = (int)(r % n_modes), s = (int)(r / n_modes);
+        NoiseGen<real> gen;
+        gen.init(seed, draw, (uint32_t)(mode_offset + m), (uint32_t)s, (uint32_t)k);
+        real e[4];
+        gen.get4(2 * b, e);
+        real* o = out + ((size_t)s * n_modes + m) * (size_t)T * d + (size_t)(2 * b) * d;
+        o[k] = e[0]; o[n + k] = e[1];
+        if (2 * b + 1 < T) { o[d + k] = e[2]; o[d + n + k] = e[3]; }
+    }
+}
+
+hipError_t launch_noise(int dtype, int n, int T, int n_modes, int mode_offset, int S, uint64_t seed, uint64_t draw, void* out,
+                        hipStream_t stream) {
+    const long long total = (long long)S * n_modes * ((T + 1) / 2) * n;
+    if (total <= 0) return hipSuccess;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (dtype == SGPMP_F64)
+        hipLaunchKernelGGL(noise_dump_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, n, T, n_modes, mode_offset, S, seed, draw, (double*)out);
+    else
+        hipLaunchKernelGGL(noise_dump_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, n, T, n_modes, mode_offset, S, seed, draw, (float*)out);
+    return hipGetLastError();
 }

@@ -179,6 +179,9 @@ hipError_t launch_sample(int dtype, int n, int T, const PriorDev& prior, uint64_
                          const void* eps, int eps_modes, int eps_mode_offset, void* out,
                          hipStream_t stream, const SgpmpToggles& tg, double* zero_stats = nullptr);
 
+hipError_t launch_noise(int dtype, int n, int T, int n_modes, int mode_offset, int S, uint64_t seed, uint64_t draw, void* out,
+                        hipStream_t stream);
+
 hipError_t launch_cost(int dtype, int n, int T, const CostProgram& h_prog, const ChainDev* d_chain,
                        const ChainDev& h_chain, const void* trajs, long long batch,
                        long long batch_offset, const void* spheres, int n_spheres,

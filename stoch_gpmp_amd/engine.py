@@ -371,6 +371,15 @@ class Engine:
                                           eps_mode_offset, L.ptr(out), L.stream_ptr()))
         return out
 
+    def noise(self, seed, draw, n_modes, n_samples, mode_offset=0):
+        """The eps the kernels draw for (seed, draw, global particles mode_offset .. + n_modes, samples 0 .. n_samples) in
+        torch's randn(n_samples, n_modes, T*d) layout (include/sgpmp.h: sgpmp_noise)."""
+        out = torch.empty(n_samples, n_modes, self.T * self.d, **self.tensor_args)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sgpmp_noise(self._ctx, int(seed), int(draw), int(n_modes), int(mode_offset), int(n_samples),
+                                         L.ptr(out), L.stream_ptr()))
+        return out
+
     def cost_eval(self, trajs, batch_offset=0, spheres=None, is_weights=None, rows_per_particle=1,
                   out=None, out64=None):
         self._chk(trajs, "trajs")

@@ -118,6 +118,27 @@ static void run_planner(int n, int T, int P, int P_global, int offset, int S, in
         (void)sgpmp_store_free_steps(c);
     }
     CHECK(sgpmp_pipeline_end(c, nullptr));                      // idempotent
+    // round 6: the K-loop of optimize() behind the ABI (draw counters, alternating statistics slots, flags, the bracket), the
+    // stream-ordered clear of the row counts, the noise read-back
+    {
+        Dev stats2(sizeof(double) * 2 * SGPMP_STAT_SHARDS * 4), prev_last(Pn * M * w);
+        CHECK(sgpmp_optimize(c, 1, 7, 300, means.p, samples.p, costs.p, weights.p, grad.p, prev.p, prev_last.p, n_sph ? sph.p : nullptr, n_sph,
+                             1.0, 0.1, (double*)stats2.p, 0, 0, nullptr));
+        CHECK(sgpmp_optimize(c, 5, 7, 301, means.p, samples.p, costs.p, weights.p, grad.p, prev.p, prev_last.p, n_sph ? sph.p : nullptr, n_sph,
+                             1.0, 0.1, (double*)stats2.p, 1, SGPMP_STEP_MEANS_KEPT | SGPMP_OPT_PIPELINE | SGPMP_OPT_STORE_FREE, nullptr));
+        CHECK(sgpmp_optimize(c, 2, 7, 306, means.p, samples.p, costs.p, nullptr, nullptr, nullptr, nullptr, n_sph ? sph.p : nullptr, n_sph,
+                             1.0, 0.1, nullptr, 0, SGPMP_OPT_STORE_FREE, nullptr));
+        EXPECT(sgpmp_optimize(c, 0, 7, 0, means.p, samples.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0, 0.1, nullptr, 0, 0, nullptr), SGPMP_EINVAL);
+        EXPECT(sgpmp_optimize(nullptr, 1, 7, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0, 0.1, nullptr, 0, 0, nullptr), SGPMP_EINVAL);
+        CHECK(sgpmp_stats_wait(c, nullptr, nullptr));
+        CHECK(sgpmp_row_counts_clear(c, nullptr));
+        EXPECT(sgpmp_row_counts_clear(nullptr, nullptr), SGPMP_EINVAL);
+        if (Pn > 0) {
+            Dev eps((size_t)3 * Pn * M * w);
+            CHECK(sgpmp_noise(c, 7, 2, Pn, 0, 3, eps.p, nullptr));
+        }
+        EXPECT(sgpmp_noise(c, 7, 2, 1, 0, 1, nullptr, nullptr), SGPMP_EINVAL);
+    }
     if (mode_stats) CHECK(sgpmp_mode_stats_wait(c, nullptr));
     CHECK(sgpmp_mode_stats(c, means.p, (double*)mode.p, nullptr));
     if (with_comm) {

@@ -48,6 +48,10 @@ hipError_t launch_sample(int dtype, int n, int T, const PriorDev& p, uint64_t, u
     wr(out, (size_t)n_modes * S * M * esz(dtype)); wr(zero_stats, sizeof(double) * SGPMP_STAT_SHARDS * 4);
     return hipSuccess;
 }
+hipError_t launch_noise(int dtype, int n, int T, int n_modes, int, int S, uint64_t, uint64_t, void* out, hipStream_t) {
+    wr(out, (size_t)S * n_modes * T * 2 * n * esz(dtype));
+    return hipSuccess;
+}
 hipError_t launch_cost(int dtype, int n, int T, const CostProgram&, const ChainDev* dch, const ChainDev&, const void* trajs, long long batch, long long,
                        const void* spheres, int ns, const void* isw, int rpp, double, void* costs, double* c64, hipStream_t, const SgpmpToggles&,
                        const char** picked) {

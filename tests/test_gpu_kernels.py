@@ -855,3 +855,23 @@ def test_zero_sized_batches_are_no_ops():
     cost = hip_planar_cost(SC.PLANAR, 8, [[9., 6., 0., 0.]], 1, 4, om, F64)
     out = cost.eval(torch.zeros(0, 8, 4, **F64))
     assert out.shape == (0,)
+
+
+@pytest.mark.parametrize("shape", [(7, 64), (2, 33)])
+def test_noise_readback_is_the_stream_the_sampler_draws(shape):
+    """sgpmp_noise hands out the eps the sampling kernels draw (round 6): (i) one stream for both precisions -- an fp64 context
+    reads the fp32 context's values, widened, bit for bit; (ii) the numpy restatement (oracle/native_noise.py, pinned by the
+    Random123 vectors) follows it to an ulp of fp32 (the hardware's log2 / sin / cos are approximations); (iii) it IS what the
+    sampler uses: with zero means and the identity as the recurrence's first step, sample_iso_kernel's waypoint 0 is
+    g11 * eps_pos -- checked through the full sampler against the oracle's dense L @ eps in the planner tests; here: moments."""
+    from oracle.native_noise import native_eps
+    from stoch_gpmp_amd.engine import Engine
+    n, T = shape
+    P, S, seed, draw, p0 = 5, 12, 0x1234567855aa, 9, 3
+    e32 = Engine(n, T, P, S, tensor_args={"device": DEV, "dtype": torch.float32}).noise(seed, draw, P, S, mode_offset=p0)
+    e64 = Engine(n, T, P, S, tensor_args={"device": DEV, "dtype": torch.float64}).noise(seed, draw, P, S, mode_offset=p0)
+    assert e32.shape == (S, P, T * 2 * n) and e64.dtype == torch.float64
+    assert torch.equal(e64, e32.double())
+    ref = torch.from_numpy(native_eps(seed, draw, range(p0, p0 + P), S, T, n, "float32"))
+    assert float((e32.cpu() - ref).abs().max()) < 2e-6
+    assert abs(float(e32.mean())) < 0.05 and abs(float(e32.std()) - 1.0) < 0.05

@@ -186,12 +186,17 @@ def test_panda_default_native_noise_matches_oracle_on_the_restated_stream():
     c = SC.PANDA
     T, nppg, S, iters, n, seed = 16, 4, 6, 4, 7, 11
     sph = torch.as_tensor(SC.panda_spheres()).to(**F64)
-    eps0 = torch.from_numpy(native_eps(seed, 0, range(1), nppg, T, n, "float64"))      # [nppg, G, M]
-    ora = SC.oracle_panda_planner(c, T, nppg, S, seed=seed, eps_init=eps0)
     pl = hip_panda_planner(c, T, nppg, S, F64, seed=seed)                              # noise='philox'
+    # The oracle is fed the eps the kernels drew, read back through sgpmp_noise (fp64 contexts draw the fp32 stream, widened:
+    # the hardware's log2 / sin / cos are approximations the numpy restatement follows to an ulp of fp32, which the 1e-7 bound on
+    # the costs below would see) -- and that eps is held to the restatement right here.
+    eps0 = pl._engine.noise(seed, 0, 1, nppg).cpu()                                    # [nppg, G, M]
+    assert float((eps0 - torch.from_numpy(native_eps(seed, 0, range(1), nppg, T, n, "float64"))).abs().max()) < 2e-6
+    ora = SC.oracle_panda_planner(c, T, nppg, S, seed=seed, eps_init=eps0)
     assert rel_err(pl.particle_means, ora.particle_means) < 1e-7
     for it in range(iters):
-        eps = torch.from_numpy(native_eps(seed, 2 + it, range(nppg), S, T, n, "float64"))   # draw 1 is discarded
+        eps = pl._engine.noise(seed, 2 + it, nppg, S).cpu()                            # draw 1 is discarded
+        assert float((eps - torch.from_numpy(native_eps(seed, 2 + it, range(nppg), S, T, n, "float64"))).abs().max()) < 2e-6
         costs_o, grad_o = ora.step(eps=eps, obstacle_spheres=sph.cpu())
         _, _, _, _, costs, grad = pl.optimize(obstacle_spheres=sph)
         assert rel_err(costs, costs_o) < 1e-7
@@ -677,8 +682,8 @@ def test_fused_f64_step_equals_the_two_launch_step(golden, kind):
     b._engine.set_option("no_fused_step", 1)
     for k in (1, 1, 3, 1):
         ra, rb = a.optimize(opt_iters=k, **obs), b.optimize(opt_iters=k, **obs)
-        assert a._engine.last_cost_kernel() == "fused_step_f64_kernel" and a._engine.last_step_launches() == 2
-        assert b._engine.last_cost_kernel() == two_launch and b._engine.last_step_launches() == 3
+        assert a._engine.last_cost_kernel() == "fused_step_f64_kernel" and b._engine.last_cost_kernel() == two_launch
+        assert a._engine.last_step_launches() == b._engine.last_step_launches() - 1      # (2 against 3; + K5 in a first step)
         scale = float(b.state_samples.abs().max())
         assert float((a.state_samples - b.state_samples).abs().max()) <= 1e-13 * scale
         assert rel_err(a._costs, b._costs) < 1e-12 and torch.equal(a._costs.argmin(1), b._costs.argmin(1))
@@ -706,7 +711,8 @@ def test_config3_shape_fp64_free_running_against_the_dense_oracle():
     scale = float(ora.particle_means.abs().max())
     worst = worst_cost = 0.0
     for it in range(5):
-        eps = torch.from_numpy(native_eps(seed, pl._draw, sub, S, T, n, "float64")).double()
+        # (the eps this step's launch draws for the four particles, read back from the library: sgpmp_noise)
+        eps = torch.cat([pl._engine.noise(seed, pl._draw, 1, S, mode_offset=p) for p in sub], dim=1).cpu()
         costs_o, _ = ora.step(eps=eps, obstacle_spheres=sph)
         costs = pl.optimize(opt_iters=1, obstacle_spheres=sph.to(**F64))[4]
         assert pl._engine.last_cost_kernel() == "fused_step_f64_kernel"
