@@ -111,6 +111,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
     {"comm_packet_event", &SgpmpToggles::comm_packet_event}, {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"planar_store_free", &SgpmpToggles::planar_store_free}, {"no_planar_tail", &SgpmpToggles::no_planar_tail},
     {"no_small_step", &SgpmpToggles::no_small_step}, {"no_ee_fold", &SgpmpToggles::no_ee_fold}, {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
+    {"f64_fields_f32", &SgpmpToggles::f64_fields_f32},
 };
 
 static void toggles_from_env(SgpmpToggles& tg) {

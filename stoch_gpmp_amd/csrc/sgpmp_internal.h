@@ -124,6 +124,7 @@ struct SgpmpToggles {
     int planar_store_free;    // SGPMP_PLANAR_STORE_FREE    store-free steps (SGPMP_STEP_NO_SAMPLES) also for fused_planar_seg_kernel: measured SLOWER at config 2 (the launch saves 3.8 us, the update's regeneration costs 5.2: 42.4 k -> 40.0 k it/s, profiles/r05), hence opt-in
     int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
     int no_ee_fold;           // SGPMP_NO_EE_FOLD           the step's end-effector goal term by a launch of ee_goal_kernel in front of update_kernel (rounds 1-4) instead of inside it
+    int f64_fields_f32;       // SGPMP_F64_FIELDS_F32       fp64 steps (fused_step_f64_kernel) evaluate the LINK fields -- forward kinematics, self-distance and sphere fields -- on the packed-fp32 code of the fp32 launches, from the fp64 waypoint rounded to fp32; samples, means, GP / goal-prior / importance-sampling terms stay fp64.  Opt-in: the collision part of a cost then carries fp32's ~1e-6 relative error (~1e-9 of a total cost at the reference's hyper-parameters)
     int no_small_step;        // SGPMP_NO_SMALL_STEP        small steps through fused_step_kernel (one wave per item) instead of fused_step_small_kernel (one workgroup per item)
     long long small_step_items;   // SGPMP_SMALL_STEP_ITEMS     items (groups of 8 samples) up to which a step counts as small (0: default 512 -- two workgroups per CU -- for shapes on the launch's 8 x 16 grid, 256 for the others)
     long long store_free_min_bytes;   // SGPMP_STORE_FREE_MIN_BYTES  a store-free step that REGENERATES rows in update_kernel is taken when one waypoint of all the step's samples (P S 2n floats) has at least this many bytes (0: the measured break-even, SGPMP_STORE_FREE_BREAK_EVEN; 1: always)

@@ -694,6 +694,28 @@ def test_fused_f64_step_equals_the_two_launch_step(golden, kind):
         b.particle_means.copy_(a.particle_means)         # (keep the twins on one trajectory: rounding differences must not pile up)
 
 
+def test_fused_f64_step_with_link_fields_in_fp32():
+    """Option f64_fields_f32 (opt-in): an fp64 step whose LINK fields -- forward kinematics, self-distance, sphere fields -- run on
+    the fp32 launches' packed code from the fp64 waypoint rounded to fp32, while noise, recurrence, samples, means, GP / goal /
+    importance-sampling terms stay fp64.  Against the all-fp64 step from the same state: samples bit-identical, costs within the
+    collision part's fp32 error (1e-6 of that part: <= 1e-7 of a total cost here), the same arg-mins, means to 1e-12 -- rbf, sdf
+    and occupancy sphere fields."""
+    for ft in ("rbf", "sdf", "occupancy"):
+        sph = torch.as_tensor(SC.panda_spheres(num=6, seed=5)).to(**F64)
+        a = hip_panda_planner(SC.PANDA, 64, 8, 32, F64, seed=19, field_type=ft)
+        b = hip_panda_planner(SC.PANDA, 64, 8, 32, F64, seed=19, field_type=ft)
+        b._engine.set_option("f64_fields_f32", 1)
+        for it in range(3):
+            a.optimize(obstacle_spheres=sph)
+            b.optimize(obstacle_spheres=sph)
+            assert a._engine.last_cost_kernel() == "fused_step_f64_kernel"
+            assert b._engine.last_cost_kernel() == "fused_step_f64_kernel (link fields in fp32)"
+            assert torch.equal(a.state_samples, b.state_samples)
+            assert rel_err(b._costs, a._costs) < 1e-7, (ft, it, rel_err(b._costs, a._costs))
+            assert torch.equal(a._costs.argmin(1), b._costs.argmin(1))
+            assert float((a.particle_means - b.particle_means).abs().max()) <= 1e-12 * float(a.particle_means.abs().max())
+
+
 def test_config3_shape_fp64_free_running_against_the_dense_oracle():
     """north_star's fp64 clause -- trajectory means within 1e-5 relative -- AT configs[2]'s shape (Panda 1024 x 128 x 64; rounds
     1-4 measured it at config 1's 4 particles only): the fp64 context (sampler + generic sweep on the generated chain + update:
