@@ -380,10 +380,13 @@ OTHER_SPECS = [
 
 def config_row(torch, dev, label, key, spec, steps, passes=1, single_calls=False):
     """One other configuration: `passes` timed passes of K iterations (the fastest kept), an event pass, the store-free
-    mode beside it where the launch has one."""
+    mode beside it where the launch has one.  spec["options"]: development switches of the context (sgpmp_set_option)."""
     spec = dict(spec)
     dtype = {"f32": torch.float32, "f64": torch.float64}[spec.pop("dtype")]
+    options = spec.pop("options", {})
     pl, obs, name = build_planner(torch, dev=dev, dtype=dtype, store_free=False, **spec)
+    for k, v in options.items():
+        pl._engine.set_option(k, v)
     time_loop(torch, pl, obs, 150, 0)                        # (clock and chain-stream warm-up, see main())
     els = [time_loop(torch, pl, obs, steps, 10 if i == 0 else 0) for i in range(passes)]
     el = min(els)

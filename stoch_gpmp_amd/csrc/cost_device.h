@@ -29,8 +29,62 @@ template <> struct RealOps<double> {
     static __device__ __forceinline__ double sqrt_(double a) { return sqrt(a); }
     static __device__ __forceinline__ double floor_(double a) { return floor(a); }
     static __device__ __forceinline__ void sincos_(double a, double* s, double* c) { sincos(a, s, c); }
-    static __device__ __forceinline__ double exp2_(double a) { return exp2(a); }
-    static __device__ __forceinline__ void fsincos_(double a, double* s, double* c) { sincos(a, s, c); }
+    // The two transcendentals of the fp64 link fields, 47 exponentials and 7 sine / cosine pairs per waypoint of the Panda program:
+    // the device library's general forms are ~24 and ~65 fp64 instructions each (overflow / underflow selects; a double-double
+    // argument reduction in front of a Payne-Hanek branch) -- a third of an fp64 step's vector instructions (round 6).  These
+    // are the same algorithms cut to the arguments the field code forms, full double accuracy (checked against the reference's
+    // fixtures at 1e-11: tests/test_gpu_kernels.py g3 / g4):
+    //  * 2^a for a = k d^2, k < 0: split a = n + r, |r| <= 1/2, the Taylor polynomial of 2^r to degree 12 (truncation 1.7e-16),
+    //    v_ldexp_f64; a clamped to [-1100, 1000] instead of selects on the result (2^-1100 is 0 either way)
+    static __device__ __forceinline__ double exp2_(double a) {
+        a = fmin(fmax(a, -1100.0), 1000.0);
+        const double n = __builtin_rint(a);
+        const double r = a - n;
+        double p = 0x1.c3bd650fc2986p-36;
+        p = __builtin_fma(p, r, 0x1.e8cac7351bb25p-32);
+        p = __builtin_fma(p, r, 0x1.e4cf5158b8ecap-28);
+        p = __builtin_fma(p, r, 0x1.b5253d395e7c4p-24);
+        p = __builtin_fma(p, r, 0x1.62c0223a5c824p-20);
+        p = __builtin_fma(p, r, 0x1.ffcbfc588b0c7p-17);
+        p = __builtin_fma(p, r, 0x1.430912f86c787p-13);
+        p = __builtin_fma(p, r, 0x1.5d87fe78a6731p-10);
+        p = __builtin_fma(p, r, 0x1.3b2ab6fba4e77p-7);
+        p = __builtin_fma(p, r, 0x1.c6b08d704a0c0p-5);
+        p = __builtin_fma(p, r, 0x1.ebfbdff82c58fp-3);
+        p = __builtin_fma(p, r, 0x1.62e42fefa39efp-1);
+        p = __builtin_fma(p, r, 1.0);
+        return ldexp(p, (int)n);
+    }
+    //  * sin / cos of a joint angle: Cody-Waite reduction by three 33-bit pieces of pi/2 (n pi/2 exact for |n| < 2^20), the
+    //    classic degree-13 / degree-14 kernels on |r| <= pi/4, quadrant by select and sign bit; |a| >= 1e6 (never a joint angle)
+    //    takes the library's path
+    static __device__ __forceinline__ void fsincos_(double a, double* s, double* c) {
+        if (__builtin_expect(!(fabs(a) < 1.0e6), 0)) { sincos(a, s, c); return; }
+        const double n = __builtin_rint(a * 6.36619772367581382433e-01);
+        double r = __builtin_fma(-n, 1.57079632673412561417e+00, a);
+        r = __builtin_fma(-n, 6.07710050630396597660e-11, r);
+        r = __builtin_fma(-n, 2.02226624871116645580e-21, r);
+        const int q = (int)n;
+        const double z = r * r;
+        double ps = 1.58969099521155010221e-10;
+        ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+        ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+        ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+        ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+        ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+        const double sr = __builtin_fma(r * z, ps, r);
+        double pc = -1.13596475577881948265e-11;
+        pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+        pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+        pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+        pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+        pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+        const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+        const bool swap = (q & 1) != 0;
+        const double ss = swap ? cr : sr, cc = swap ? sr : cr;
+        *s = __hiloint2double(__double2hiint(ss) ^ ((q & 2) << 30), __double2loint(ss));
+        *c = __hiloint2double(__double2hiint(cc) ^ (((q + 1) & 2) << 30), __double2loint(cc));
+    }
     static __device__ __forceinline__ double rcp_(double a) { return 1.0 / a; }
 };
 

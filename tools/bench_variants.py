@@ -30,6 +30,10 @@ def variants(torch, dev):
         ("config 3 with the sdf sphere field", "cfg3_sdf", dict(workload="panda", P_local=1024, S=128, T=64, dtype="f32", field="sdf"), 100),
         ("config 3 with 64 sphere obstacles", "cfg3_64sph", dict(workload="panda", P_local=1024, S=128, T=64, dtype="f32", spheres=64), 40),
         ("config 3's shape in fp64 (Panda 1024 x 128 x 64)", "cfg3_f64", dict(workload="panda", P_local=1024, S=128, T=64, dtype="f64"), 20),
+        ("config 3's shape in fp64, link fields in fp32 (option f64_fields_f32)", "cfg3_f64_mixed",
+         dict(workload="panda", P_local=1024, S=128, T=64, dtype="f64", options={"f64_fields_f32": 1}), 20),
+        ("config 3's shape in fp64 as rounds 1-5 ran it: sampler, sweep, update as three launches (option no_fused_step)", "cfg3_f64_unfused",
+         dict(workload="panda", P_local=1024, S=128, T=64, dtype="f64", options={"no_fused_step": 1}), 20),
         ("config 2's shape in fp64 (planar 256 x 64 x 128)", "cfg2_f64", dict(workload="planar", P_local=256, S=64, T=128, dtype="f64", goals=4), 100),
     ]
     return [B.config_row(torch, dev, label, key, spec, steps, passes=2, single_calls=True) for label, key, spec, steps in specs]
