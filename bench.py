@@ -687,6 +687,10 @@ def main():
                                               "cfg3_f64" if (args.workload, P_local, S, T, args.dtype, goals) == ("panda", 1024, 128, 64, "f64", 1) else "")
         if args.workload == "panda" and cfg_key == "cfg3" and args.field == "sdf":
             cfg_key = "cfg3_sdf"
+        if cfg_key and sweep_kernel == "fused_step_f64_mixed_kernel":
+            cfg_key += "_mixed"
+        if cfg_key and not fused and args.workload == "panda":
+            cfg_key += "_unfused"
         ms_step = 1e3 * elapsed / args.steps
         launches_per_iteration = pl._engine.last_step_launches()
         roof, roof_detail = roofline_of(sweep_kernel, kms["cost_sweep"], N_elems, w, P_local * S * 8, fused,

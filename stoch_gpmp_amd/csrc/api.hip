@@ -1259,7 +1259,9 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         // bring a workgroup for every CU, or two half-empty launches take turns: 40.3 k against 44.4 k it/s at config 2)
         const bool seg = planar_seg_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P, D.particle_offset, S,
                                          n_spheres, c->tg);
-        const bool split = !eps && !c->profiling && !c->tg.no_step_pipeline && !c->ms_buf &&
+        // (fp32 steps only: an fp64 step's launch is 0.5 - 0.8 ms of vector arithmetic at two waves per SIMD with a per-workgroup
+        // prologue -- two half-size launches side by side measured 6 % SLOWER than one, and the update is 2 % of the step)
+        const bool split = !eps && !c->profiling && !c->tg.no_step_pipeline && !c->ms_buf && D.dtype == SGPMP_F32 &&
                            (long long)(P0 < P - P0 ? P0 : P - P0) * S >= (seg ? 256 * 64 : 256 * 4 * 8) &&
                            fused_step_eligible(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P0, D.particle_offset,
                                                S, n_spheres, c->tg) &&

@@ -226,14 +226,14 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         const unsigned dyn = g.scan_in_lds ? (unsigned)lds : 0u;
         const bool mixed = tg.f64_fields_f32 && h_prog.needs_fk && n_spheres <= SGPMP_SPH_LDS;
         if (h_prog.needs_fk && mixed)
-            hipLaunchKernelGGL((fused_step_f64_kernel<CCp::N, 1000, true>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
+            hipLaunchKernelGGL((fused_step_f64_mixed_kernel<CCp::N, 1000>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
         else if (h_prog.needs_fk)
             hipLaunchKernelGGL((fused_step_f64_kernel<CCp::N, 1000>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
         else if (n == 2)
             hipLaunchKernelGGL((fused_step_f64_kernel<2, 0>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
         else
             hipLaunchKernelGGL((fused_step_f64_kernel<3, 0>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
-        if (picked) *picked = mixed ? "fused_step_f64_kernel (link fields in fp32)" : "fused_step_f64_kernel";
+        if (picked) *picked = mixed ? "fused_step_f64_mixed_kernel" : "fused_step_f64_kernel";
         *launched = true;
         return hipGetLastError();
     }

@@ -710,7 +710,7 @@ def test_fused_f64_step_with_link_fields_in_fp32():
             a.optimize(obstacle_spheres=sph)
             b.optimize(obstacle_spheres=sph)
             assert a._engine.last_cost_kernel() == "fused_step_f64_kernel"
-            assert b._engine.last_cost_kernel() == "fused_step_f64_kernel (link fields in fp32)"
+            assert b._engine.last_cost_kernel() == "fused_step_f64_mixed_kernel"
             assert torch.equal(a.state_samples, b.state_samples)
             assert rel_err(b._costs, a._costs) < 1e-7, (ft, it, rel_err(b._costs, a._costs))
             assert torch.equal(a._costs.argmin(1), b._costs.argmin(1))
