@@ -1089,8 +1089,10 @@ def test_fp32_population_follows_its_fp64_twin_on_identical_noise():
     identical eps at any size without a CPU oracle in the loop -- and the fp64 one-launch step is itself held to the dense
     oracle at 1e-9 (test_config3_shape_fp64_free_running_*, bench.py's parity leg).  BASELINE configs[2] at full size, all 1024
     particles, 12 re-synchronised iterations = 12 288 particle-iterations: samples equal to fp32 rounding, costs within 5e-3
-    (measured ~1e-5), and every particle whose fp32 update leaves its fp64 twin (> 1e-3 of the means' scale) does so through an
-    arg-min flip between two samples whose fp64 costs lie within 2e-5 of each other -- the fp32 path's only way to differ.
+    (measured ~1e-5), and every particle whose fp32 update leaves its fp64 twin (> 1e-3 of the means' scale) does so through a
+    near tie of its two best samples (fp64 costs within 2e-5 of each other): an arg-min flip, or -- same arg-min -- a softmax
+    weight the two share in fp64 and fp32 cannot resolve (found by this test's first run: 1 in 12 288) -- the fp32 path's only
+    ways to differ.
     The flip rate is reported (profiles: ~1 in 7 000, as the banded-oracle population test measured)."""
     import json
     import os
@@ -1117,8 +1119,13 @@ def test_fp32_population_follows_its_fp64_twin_on_identical_noise():
         for p in off:
             a, b = int(a_lo[p]), int(a_hi[p])
             gap = float((c_hi[p, a] - c_hi[p, b]).abs() / c_hi[p, b].abs())
-            rec = {"iteration": it + 1, "particle": p, "near_tie_gap": gap, "means_rel": float(d[p])}
-            (flips if (a != b and gap < 2e-5) else unexplained).append(rec)
+            # (the same arg-min on both sides can still move the means apart: two samples whose fp64 costs differ by O(1) of 1e9
+            # SHARE the softmax weight in fp64, while fp32 -- cost resolution 64 at 1e9 -- sees a tie or a one-hot: a near tie
+            # of the two best samples all the same)
+            top2 = torch.topk(c_hi[p], 2, largest=False).values
+            gap2 = float((top2[1] - top2[0]) / top2[0].abs())
+            rec = {"iteration": it + 1, "particle": p, "near_tie_gap": gap if a != b else gap2, "same_arg_min": a == b, "means_rel": float(d[p])}
+            (flips if ((a != b and gap < 2e-5) or gap2 < 2e-5) else unexplained).append(rec)
     rec = {"configuration": "config 3: Panda 1024 x 128 x 64, fp32 fused launch against the fp64 one-launch step on identical noise",
            "particle_iterations": P * iters, "near_tie_flips": flips, "flip_rate_per_particle_iteration": len(flips) / float(P * iters),
            "unexplained_departures": unexplained, "cost_rel_err_max": worst_cost, "samples_rel_err_max": worst_samples}
