@@ -17,8 +17,8 @@ Output (rank 0):
     that): value / ms_per_step (storing mode: every iteration writes its samples -- the mode SURVEY.md 8(d)'s
     algorithmic bytes are defined on), roofline, cpu_baseline, single_iteration_calls, store_free, parity,
     rccl, one short row per other single-GPU configuration;
-  * bench_detail.json beside this script (and on stderr): everything else -- per-kernel event timings, the
-    counters' sources, the measured CPU points, per-pass times.
+  * bench_detail.json beside this script: everything else -- per-kernel event timings, the counters' sources,
+    the measured CPU points, per-pass times (stderr only says where it went: nothing JSON-shaped besides the line).
 
 `roofline.frac` = SURVEY 8(d)'s algorithmic bytes of the dominant launch / the TIMED pass's ms_per_step / 8 TB/s
 (a lower bound: the step also holds the update kernel); `launch_ms` is the launch's own average duration from
@@ -182,7 +182,7 @@ def compact_line(full):
 
 
 def emit(full, json_fd, detail_path):
-    """Write the detailed record beside the script (and to stderr), the compact line to the saved stdout."""
+    """Write the detailed record beside the script, the compact line to the saved stdout."""
     full = dict(full)
     full["detail_file"] = os.path.basename(detail_path) if detail_path else None
     try:
@@ -192,7 +192,8 @@ def emit(full, json_fd, detail_path):
     except OSError as e:                                  # (a read-only tree must not cost the line)
         full["detail_file"] = None
         print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
-    print("bench.py detail: " + json.dumps(_clean(full), allow_nan=False), file=sys.stderr)
+    # (nothing JSON-shaped goes to stderr: a driver that scans the combined output for the line must find exactly one)
+    print(f"bench.py: detailed record -> {detail_path if full['detail_file'] else '(not written)'}", file=sys.stderr)
     line = compact_line(full)
     os.write(json_fd, (line + "\n").encode())
     return line
