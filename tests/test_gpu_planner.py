@@ -657,7 +657,8 @@ def test_config5_share_free_running_ten_iterations_against_the_banded_oracle():
     assert rec["tracking_fraction_per_iteration"][0] == 1.0
 
 
-@pytest.mark.parametrize("kind", ["panda", "panda_two_goals_sdf", "planar", "planar_two_passes", "planar_three_passes_ragged"])
+@pytest.mark.parametrize("kind", ["panda", "panda_two_goals_sdf", "panda_scan_table_in_lds", "planar", "planar_two_passes",
+                                  "planar_three_passes_ragged"])
 def test_fused_f64_step_equals_the_two_launch_step(golden, kind):
     """fp64 contexts run sampler + sweep as ONE launch since round 6 (fused_step_f64_kernel: one wave per trajectory, lane =
     waypoint, the sampling recurrence as a Kogge-Stone scan over the lanes with 2 x 2 propagator products from a host-built
@@ -668,7 +669,10 @@ def test_fused_f64_step_equals_the_two_launch_step(golden, kind):
     if kind.startswith("panda"):
         two = kind == "panda_two_goals_sdf"
         g = [SC.PANDA["goal_q"] + [0.] * 7, [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5] + [0.] * 7] if two else None
-        mk = lambda: hip_panda_planner(SC.PANDA, 64, 6, 24, F64, seed=13, goals=g, field_type="sdf" if two else "rbf")   # noqa: E731
+        # (beyond 2048 trajectories the launch runs 256-thread workgroups that stage the scan table in LDS; below, one-wave
+        # workgroups whose lanes read their rows from memory)
+        nppg, S = (24, 128) if kind == "panda_scan_table_in_lds" else (6, 24)
+        mk = lambda: hip_panda_planner(SC.PANDA, 64, nppg, S, F64, seed=13, goals=g, field_type="sdf" if two else "rbf")   # noqa: E731
         obs = {"obstacle_spheres": torch.as_tensor(SC.panda_spheres(num=5, seed=3)).to(**F64)}
         two_launch = "cost_sweep_kernel<f64, generated chain>"
     else:
