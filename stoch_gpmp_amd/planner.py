@@ -4,9 +4,10 @@ and `sample_trajectories`, running on the HIP kernels of libsgpmp.so.
 
 Per iteration (the loop body at reference planner.py:289-299) the reference rebuilds a
 MultivariateNormal over a replicated [P,M,M] precision, samples through a dense M x M factor,
-evaluates the costs with a dozen torch ops and a dense importance-sampling matmul.  Here one call,
-`sgpmp_step`, enqueues K5 (IS weights) -> K2 (scan sampler) -> K3 (cost sweep) -> K4 (reweight +
-mean update) on the current HIP stream; Python only passes pointers.
+evaluates the costs with a dozen torch ops and a dense importance-sampling matmul.  Here one call per
+iteration, `sgpmp_step`, enqueues K5 (IS weights) -> K2 (scan sampler) -> K3 (cost sweep; K2 + K3 as ONE launch
+where the step qualifies) -> K4 (reweight + mean update) on the current HIP stream, and one call per optimize(),
+`sgpmp_optimize`, runs the loop of those steps on the C side; Python only passes pointers.
 
 Additions over the reference API (all optional keyword arguments):
   noise='philox' | 'torch'   'philox' (default) draws counter-based noise inside K2, keyed on
