@@ -551,8 +551,12 @@ def parity_leg(torch, args, dev, P_local, S, T, goals, K=10, followed=2):
     worst_cost = worst_means = 0.0
     scale = None
     for it in range(1, K + 1):
-        eps = torch.from_numpy(native_eps(seed, pl._draw, [pl.p0 + i for i in sub], S, T, n,
-                                          "float32" if dtype == torch.float32 else "float64")).double()
+        if dtype == torch.float64:
+            # (fp64 contexts draw the fp32 normals, widened: the oracle gets the eps the kernels draw, read back through the C ABI
+            # -- the numpy restatement follows the hardware's log2 / sin / cos to an ulp of fp32 only, which an fp64 comparison sees)
+            eps = torch.cat([pl._engine.noise(seed, pl._draw, 1, S, mode_offset=pl.p0 + i) for i in sub], dim=1).cpu()
+        else:
+            eps = torch.from_numpy(native_eps(seed, pl._draw, [pl.p0 + i for i in sub], S, T, n, "float32")).double()
         costs_o, _ = ora.step(eps=eps, **ora_obs)
         costs = pl.optimize(opt_iters=1, **obs)[4]
         scale = scale or float(ora.particle_means.abs().max())
