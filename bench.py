@@ -158,8 +158,8 @@ def compact_line(full):
     opt("per_rank_iterations_per_s", full.get("per_rank_iterations_per_s"))
     opt("last_iteration", _clean(full.get("last_iteration")))
     opt("sweep_alone_frac", _clean((full.get("sweep_alone") or {}).get("frac"), 4))
-    opt("sweep_alone", _pick(full.get("sweep_alone"), ("kernel", "launch_ms", "frac", "sampler_kernel", "sampler_launch_ms",
-                                                       "sampler_frac"), 4))
+    opt("sweep_alone", _pick(full.get("sweep_alone"), ("kernel", "launch_ms", "frac", "launch_ms_rocprof", "frac_rocprof",
+                                                       "sampler_kernel", "sampler_launch_ms", "sampler_frac"), 4))
     opt("mode", full.get("mode"))
     opt("field", full.get("field"))
     opt("launches_per_iteration", full.get("launches_per_iteration"))
@@ -333,7 +333,7 @@ def store_free_leg(torch, spec_kwargs, dev, config_key, steps, storing_ms, passe
     return out
 
 
-def sweep_alone_leg(torch, pl, obs, N_elems, w, costs_bytes, reps=60):
+def sweep_alone_leg(torch, pl, obs, N_elems, w, costs_bytes, reps=60, config_key=""):
     """north_star's ">= 40 % of the HBM roofline on the cost-gradient sweep" is about the STAND-ALONE sweep: sgpmp_cost_eval on the
     planner's own sample tensor (K3 as a launch of its own: what sample_and_eval() and the two-launch steps run), `reps` launches
     back to back between two HIP events on the launch stream -- likewise the stand-alone sampler (sgpmp_sample).  Sweep bytes =
@@ -364,7 +364,13 @@ def sweep_alone_leg(torch, pl, obs, N_elems, w, costs_bytes, reps=60):
     kernel = eng.last_cost_kernel()
     samp_ms = timed(sampler)
     pl.optimize(opt_iters=1, **obs)                        # (the planner's buffers hold a step's tensors again)
+    # beside the live figure (launches back to back: the clock a chip holds under nothing but this kernel), the committed
+    # rocprofv3 duration of the same kernel inside a loop of two-launch steps (profiles/rNN: <config>_unfused)
+    k, src = profiled(config_key + "_unfused", kernel) if config_key else (None, None)
+    prof_ms = k["avg_ns_under_stats"] * 1e-6 if (k and "avg_ns_under_stats" in k) else None
     return {"kernel": kernel, "launch_ms": sweep_ms, "algorithmic_bytes": N_elems * w + costs_bytes,
+            "launch_ms_rocprof": prof_ms, "rocprof_source": src,
+            "frac_rocprof": ((N_elems * w + costs_bytes) / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if prof_ms else None,
             "frac": (N_elems * w + costs_bytes) / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "sampler_kernel": "sample_iso_kernel", "sampler_launch_ms": samp_ms,
             "sampler_frac": N_elems * w / (samp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_timed": reps,
@@ -708,7 +714,7 @@ def main():
         # the stand-alone sampler and sweep of the same planner (north_star's 40 % clause is about THAT launch)
         alone = None
         if world == 1 and fused and not args.no_sweep_alone and not args.store_free:
-            alone = sweep_alone_leg(torch, pl, obs, N_elems, w, P_local * S * 8)
+            alone = sweep_alone_leg(torch, pl, obs, N_elems, w, P_local * S * 8, config_key=cfg_key)
         # the store-free mode of the same workload (the product's default inside one optimize() call), beside the headline
         sfree = None
         spec = dict(workload=args.workload, P_local=P_local, S=S, T=T, dtype=dtype, field=args.field, spheres=args.spheres,
