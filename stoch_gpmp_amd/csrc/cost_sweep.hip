@@ -219,20 +219,20 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         // the lanes read their rows of the scan table straight from memory: staging 14 KB per workgroup for one or two items is a
         // string of dependent round trips a latency-bound launch cannot hide)
         const int block = a.batch <= 2048 ? 64 : 256;
-        g.scan_in_lds = (lds <= 48 * 1024 && a.batch > 2048) ? 1 : 0;
+        const bool scan_lds = lds <= 48 * 1024 && a.batch > 2048;
         long long blocks = (a.batch + block / 64 - 1) / (block / 64);
         const long long cap = 256LL * 32;
         if (blocks > cap) blocks = cap;
-        const unsigned dyn = g.scan_in_lds ? (unsigned)lds : 0u;
+        const unsigned dyn = scan_lds ? (unsigned)lds : 0u;
         const bool mixed = tg.f64_fields_f32 && h_prog.needs_fk && n_spheres <= SGPMP_SPH_LDS;
-        if (h_prog.needs_fk && mixed)
-            hipLaunchKernelGGL((fused_step_f64_mixed_kernel<CCp::N, 1000>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
-        else if (h_prog.needs_fk)
-            hipLaunchKernelGGL((fused_step_f64_kernel<CCp::N, 1000>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
-        else if (n == 2)
-            hipLaunchKernelGGL((fused_step_f64_kernel<2, 0>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
-        else
-            hipLaunchKernelGGL((fused_step_f64_kernel<3, 0>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g);
+        // (SCAN_: how a big launch reads its staged scan table -- cost_sweep_kernel.inc: in one batch, or round by round)
+#define F64_LAUNCH(K_, N_, FK_, SCAN_) do { if (scan_lds) hipLaunchKernelGGL((K_<N_, FK_, SCAN_>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g); \
+                                            else hipLaunchKernelGGL((K_<N_, FK_, 0>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g); } while (0)
+        if (h_prog.needs_fk && mixed) F64_LAUNCH(fused_step_f64_mixed_kernel, CCp::N, 1000, 2);
+        else if (h_prog.needs_fk) F64_LAUNCH(fused_step_f64_kernel, CCp::N, 1000, 1);
+        else if (n == 2) F64_LAUNCH(fused_step_f64_kernel, 2, 0, 2);
+        else F64_LAUNCH(fused_step_f64_kernel, 3, 0, 2);
+#undef F64_LAUNCH
         if (picked) *picked = mixed ? "fused_step_f64_mixed_kernel" : "fused_step_f64_kernel";
         *launched = true;
         return hipGetLastError();
