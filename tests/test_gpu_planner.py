@@ -911,6 +911,11 @@ def test_dense_weight_update_adds_partials_of_the_fused_launch_instead_of_reread
 # noise of its own global index: 2 re-synchronised iterations (the oracle is handed the HIP means before the step: every
 # particle-iteration an independent trial) + 5 free-running ones (both sides on their own).  The population is cut into
 # chunks of particles that worker threads step side by side (particles are independent: planner.py:263-275).
+# SGPMP_LONG_PARITY=1: the whole-population tests at round 5's iteration counts (2 + 5 at config 3, 1 + 3 at config 5's share) and
+# the fp32-against-fp64 twin over 120 iterations -- for the round's record (profiles/rNN), not for the driver's timed suite
+_LONG_PARITY = bool(__import__("os").environ.get("SGPMP_LONG_PARITY"))
+
+
 def _population_parity(tag, pl, make_band, n, obs_hip, obs_ora, expect_kernel, sync_iters=2, free_iters=5, pchunk=32, workers=32,
                        cost_quantum=None):
     """cost_quantum (planar problems): the weight 1 / sigma_coll^2 of one occupancy-grid count.  The grid lookup is a step
@@ -1035,7 +1040,7 @@ def test_whole_population_parity_config3():
     # driver's GPU suite has a 1200 s limit.)
     rec = _population_parity("config 3: Panda 1024 x 128 x 64 fp32 (fused launch)", pl, make_band, n,
                              {"obstacle_spheres": sph.to(**F32)}, {"obstacle_spheres": sph}, "fused_step_kernel",
-                             sync_iters=1, free_iters=3)
+                             sync_iters=2 if _LONG_PARITY else 1, free_iters=5 if _LONG_PARITY else 3)
     assert rec["still_tracking_after_free_run"] >= 0.99 * P
 
 
@@ -1084,7 +1089,7 @@ def test_whole_population_parity_config5_share():
                                c["sigma_start_sample"], c["sigma_goal_sample"], c["sigma_gp_sample"], mu, chunk=2)
     rec = _population_parity("config 5 share: shard 3 of 8 of Panda 4 goals x 1024 x 256 x 128 fp32 (fused launch)", pl,
                              make_band, n, {"obstacle_spheres": sph.to(**F32)}, {"obstacle_spheres": sph}, "fused_step_kernel",
-                             sync_iters=1, free_iters=2, pchunk=16, workers=32)
+                             sync_iters=1, free_iters=3 if _LONG_PARITY else 2, pchunk=16, workers=32)
     assert rec["still_tracking_after_free_run"] >= 0.99 * 512
 
 
@@ -1100,7 +1105,7 @@ def test_fp32_population_follows_its_fp64_twin_on_identical_noise():
     The flip rate is reported (profiles: ~1 in 7 000, as the banded-oracle population test measured)."""
     import json
     import os
-    T, S, P, seed, iters = 64, 128, 1024, 101, 12
+    T, S, P, seed, iters = 64, 128, 1024, 101, 120 if _LONG_PARITY else 12
     sph = torch.as_tensor(SC.panda_spheres(num=5))
     lo = hip_panda_planner(SC.PANDA, T, P, S, F32, seed=seed)
     hi = hip_panda_planner(SC.PANDA, T, P, S, F64, seed=seed)
