@@ -1093,7 +1093,8 @@ def test_whole_population_parity_config5_share():
     assert rec["still_tracking_after_free_run"] >= 0.99 * 512
 
 
-def test_fp32_population_follows_its_fp64_twin_on_identical_noise():
+@pytest.mark.parametrize("config", ["config3", "config5_share"])
+def test_fp32_population_follows_its_fp64_twin_on_identical_noise(config):
     """One noise stream serves both precisions (round 6), so an fp32 planner can be held to an fp64 planner of THIS library on
     identical eps at any size without a CPU oracle in the loop -- and the fp64 one-launch step is itself held to the dense
     oracle at 1e-9 (test_config3_shape_fp64_free_running_*, bench.py's parity leg).  BASELINE configs[2] at full size, all 1024
@@ -1105,10 +1106,20 @@ def test_fp32_population_follows_its_fp64_twin_on_identical_noise():
     The flip rate is reported (profiles: ~1 in 7 000, as the banded-oracle population test measured)."""
     import json
     import os
-    T, S, P, seed, iters = 64, 128, 1024, 101, 120 if _LONG_PARITY else 12
     sph = torch.as_tensor(SC.panda_spheres(num=5))
-    lo = hip_panda_planner(SC.PANDA, T, P, S, F32, seed=seed)
-    hi = hip_panda_planner(SC.PANDA, T, P, S, F64, seed=seed)
+    if config == "config3":
+        T, S, P, seed, iters = 64, 128, 1024, 101, 120 if _LONG_PARITY else 12
+        lo = hip_panda_planner(SC.PANDA, T, P, S, F32, seed=seed)
+        hi = hip_panda_planner(SC.PANDA, T, P, S, F64, seed=seed)
+    else:
+        # BASELINE configs[4]'s per-GPU share (4 goals x 1024 x 256 x 128, shard 3 of 8): T = 128 is two passes of the fp64
+        # launch's 64 lanes -- the carried state of its scan at full size
+        T, S, P, seed, iters = 128, 256, 512, 103, 24 if _LONG_PARITY else 4
+        goals = [g + [0.] * 7 for g in [SC.PANDA["goal_q"], [-0.4, 0.5, -0.3, -2.0, 0.2, 1.5, -0.5],
+                                        [0.9, -0.2, 0.4, -1.1, -0.3, 1.9, 0.8], [-0.8, 0.1, 0.6, -2.4, 0.4, 2.6, -0.2]]]
+        lo = hip_panda_planner(SC.PANDA, T, 1024, S, F32, seed=seed, goals=goals, rank=3, world_size=8)
+        hi = hip_panda_planner(SC.PANDA, T, 1024, S, F64, seed=seed, goals=goals, rank=3, world_size=8)
+        assert (lo.p0, lo.p1) == (1536, 2048)
     assert lo._draw == hi._draw
     flips, unexplained, worst_cost, worst_samples = [], [], 0.0, 0.0
     for it in range(iters):
@@ -1135,13 +1146,18 @@ def test_fp32_population_follows_its_fp64_twin_on_identical_noise():
             gap2 = float((top2[1] - top2[0]) / top2[0].abs())
             rec = {"iteration": it + 1, "particle": p, "near_tie_gap": gap if a != b else gap2, "same_arg_min": a == b, "means_rel": float(d[p])}
             (flips if ((a != b and gap < 2e-5) or gap2 < 2e-5) else unexplained).append(rec)
-    rec = {"configuration": "config 3: Panda 1024 x 128 x 64, fp32 fused launch against the fp64 one-launch step on identical noise",
+    rec = {"configuration": f"{config}: Panda {P} x {S} x {T}, fp32 fused launch against the fp64 one-launch step on identical noise",
            "particle_iterations": P * iters, "near_tie_flips": flips, "flip_rate_per_particle_iteration": len(flips) / float(P * iters),
            "unexplained_departures": unexplained, "cost_rel_err_max": worst_cost, "samples_rel_err_max": worst_samples}
     print("\n[fp32 vs fp64 twin, whole population] " + json.dumps(rec))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
-        json.dump(rec, open(os.path.join(out, "parity_fp32_vs_fp64_twin.json"), "w"), indent=1)
+        path = os.path.join(out, "parity_fp32_vs_fp64_twin.json")
+        old = json.load(open(path)) if os.path.exists(path) else {}
+        if "configuration" in old:
+            old = {}
+        old[config] = rec
+        json.dump(old, open(path, "w"), indent=1)
     assert not unexplained, unexplained[:5]
     assert worst_cost < 5e-3 and worst_samples < 2e-6, (worst_cost, worst_samples)
     assert len(flips) <= 0.002 * P * iters
