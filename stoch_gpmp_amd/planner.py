@@ -37,6 +37,10 @@ Additions over the reference API (all optional keyword arguments):
                              other half's sampler + sweep launch); same results, bit for bit.
   c_loop=True                optimize() is ONE call into the library (include/sgpmp.h: sgpmp_optimize runs the K-loop);
                              False: one sgpmp_step call per iteration from Python, as in rounds 1-5 (same results, bit for bit).
+  f64_fields_f32=False       fp64 planners only, opt-in: the one-launch step evaluates the LINK fields (forward kinematics, self
+                             distance, sphere fields) on the fp32 launches' packed code from the fp64 waypoint rounded to fp32;
+                             noise, recurrence, samples, means, GP / goal-prior / importance-sampling terms stay fp64.  Costs
+                             within ~1e-9 of the all-fp64 step's, 1.6 x faster.
   store_free=True            optimize(opt_iters = K) returns the LAST iteration's tensors only (planner.py:289-317), so
                              iterations 1 .. K - 1 do not write their samples (470 MB per iteration at 1024 x 128 x 64):
                              the update regenerates the rows that carry weight from their noise keys, bit for bit
@@ -166,6 +170,7 @@ class StochGPMP:
         self.clone_outputs = bool(kwargs.get('clone_outputs', True))
         self.store_free = bool(kwargs.get('store_free', True))
         self.c_loop = bool(kwargs.get('c_loop', True))
+        self.f64_fields_f32 = bool(kwargs.get('f64_fields_f32', False))
         self._mode_buf = None
 
         self.reset(start_state, multi_goal_states, initial_particle_means=initial_particle_means)
@@ -240,6 +245,8 @@ class StochGPMP:
         fresh = self._engine is None
         if fresh:
             self._engine = Engine(n, T, Pl, S, G, nppg, self.p0, P, tensor_args=ta)
+            if self.f64_fields_f32:
+                self._engine.set_option("f64_fields_f32", 1)
             self._attach_comm()
             if self.mode_stats_every_step:
                 self._mode_buf = torch.zeros(G, M + 1, 2, device=ta['device'], dtype=torch.float64)

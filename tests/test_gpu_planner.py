@@ -708,8 +708,7 @@ def test_fused_f64_step_with_link_fields_in_fp32():
     for ft in ("rbf", "sdf", "occupancy"):
         sph = torch.as_tensor(SC.panda_spheres(num=6, seed=5)).to(**F64)
         a = hip_panda_planner(SC.PANDA, 64, 8, 32, F64, seed=19, field_type=ft)
-        b = hip_panda_planner(SC.PANDA, 64, 8, 32, F64, seed=19, field_type=ft)
-        b._engine.set_option("f64_fields_f32", 1)
+        b = hip_panda_planner(SC.PANDA, 64, 8, 32, F64, seed=19, field_type=ft, f64_fields_f32=True)     # (= option / SGPMP_F64_FIELDS_F32)
         for it in range(3):
             a.optimize(obstacle_spheres=sph)
             b.optimize(obstacle_spheres=sph)
