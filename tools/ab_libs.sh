@@ -8,7 +8,7 @@
 LIBS=${@:-stoch_gpmp_amd/libsgpmp.so}
 for rep in 1 2; do
 for lib in $LIBS; do
-  SGPMP_LIB_PATH=$PWD/$lib python3 bench.py --steps 300 --warmup 20 --no-other-configs --no-cpu-baseline --no-parity 2>/dev/null | python3 -c "
+  SGPMP_LIB_PATH=$PWD/$lib python3 bench.py --steps 300 --warmup 20 --no-other-configs --no-cpu-baseline --no-parity --no-sweep-alone 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', round(d['value'],1), round(d['ms_per_step'],5), {k:round(v,5) for k,v in d['kernel_ms_per_step'].items()})"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', 'storing', round(d['value'],1), round(d['ms_per_step'],5), 'launch', d['roofline']['launch_ms'], 'store-free', (d.get('store_free') or {}).get('iterations_per_s'), 'single calls', (d.get('single_iteration_calls') or {}).get('iterations_per_s'))"
 done; done
