@@ -30,6 +30,15 @@
 #define SGPMP_SAMPLE_TC 16
 #define SGPMP_SAMPLE_PAD(n) ((n) > 4 ? 8 : 4)
 
+#ifndef SGPMP_SAMPLE_STORE_NT      // sample_iso_kernel's stores of x = mu + y (whole rows, written once, read by another kernel): non-temporal --
+#define SGPMP_SAMPLE_STORE_NT 1    // 121.4 -> 111.7 us at config 3 (same box, three passes each: profiles/r06/store_policy_ab.txt)
+#endif
+#if SGPMP_SAMPLE_STORE_NT
+#define SGPMP_SAMPLE_STORE(p_, v_) __builtin_nontemporal_store((v_), (p_))
+#else
+#define SGPMP_SAMPLE_STORE(p_, v_) (*(p_) = (v_))
+#endif
+
 template <typename real, int VW>
 __global__ void __launch_bounds__(256)
 sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*[T][8]*/,
@@ -123,7 +132,7 @@ sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*
                 for (int r = ln >> lpr_shift; r < rows; r += groups) {
                     vec val = *reinterpret_cast<const vec*>(tile + (size_t)r * pitch + j0 * VW);
                     val += mu0;                                                          // x = mu + y
-                    *reinterpret_cast<vec*>(out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d + j0 * VW) = val;
+                    SGPMP_SAMPLE_STORE(reinterpret_cast<vec*>(out + ((size_t)m * S + s0 + r) * M + (size_t)t0 * d + j0 * VW), val);
                 }
         } else {
             for (int r = ln >> lpr_shift; r < rows; r += groups) {
@@ -132,7 +141,7 @@ sample_iso_kernel(int n, int T, int S, int spw, const real* __restrict__ coef /*
                 for (int j = j0; j < seg; j += lpr) {
                     vec val = *reinterpret_cast<const vec*>(trow_r + j * VW);
                     val += *reinterpret_cast<const vec*>(mu + (size_t)t0 * d + j * VW);
-                    *reinterpret_cast<vec*>(orow + j * VW) = val;
+                    SGPMP_SAMPLE_STORE(reinterpret_cast<vec*>(orow + j * VW), val);
                 }
             }
         }
