@@ -29,8 +29,16 @@ def _free_port():
 def one_rank_group():
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
-                            device_id=DEV)
+    # (a port that was free a moment ago can be taken by the time the store listens on it -- EADDRINUSE once in this build's
+    # ~2000 fixture set-ups: try another one)
+    for attempt in range(5):
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                    device_id=DEV)
+            break
+        except Exception as e:                            # torch.distributed.DistNetworkError
+            if "EADDRINUSE" not in str(e) and "address already in use" not in str(e) or attempt == 4:
+                raise
     yield dist
     dist.destroy_process_group()
 
