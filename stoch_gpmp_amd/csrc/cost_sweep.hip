@@ -224,8 +224,8 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         const long long cap = 256LL * 32;
         if (blocks > cap) blocks = cap;
         const bool mixed = tg.f64_fields_f32 && h_prog.needs_fk && n_spheres <= SGPMP_SPH_LDS;
-        // (+ the all-fp64 chain launch's store tile: a pass of 64 waypoints x d doubles per wave -- cost_sweep_kernel.inc: SCAN == 1)
-        const bool store_tile = scan_lds && h_prog.needs_fk && !mixed;
+        // (+ the chain launches' store tile: a pass of 64 waypoints x d doubles per wave -- cost_sweep_kernel.inc)
+        const bool store_tile = scan_lds && h_prog.needs_fk;
         const unsigned dyn = scan_lds ? (unsigned)(lds + (store_tile ? (size_t)(block / 64) * 64 * 2 * n * sizeof(double) : 0)) : 0u;
         // (SCAN_: how a big launch reads its staged scan table -- cost_sweep_kernel.inc: in one batch, or round by round)
 #define F64_LAUNCH(K_, N_, FK_, SCAN_) do { if (scan_lds) hipLaunchKernelGGL((K_<N_, FK_, SCAN_>), dim3((unsigned)blocks), dim3(block), dyn, stream, a, PK, F, g); \
