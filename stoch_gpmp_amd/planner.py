@@ -40,7 +40,7 @@ Additions over the reference API (all optional keyword arguments):
   f64_fields_f32=False       fp64 planners only, opt-in: the one-launch step evaluates the LINK fields (forward kinematics, self
                              distance, sphere fields) on the fp32 launches' packed code from the fp64 waypoint rounded to fp32;
                              noise, recurrence, samples, means, GP / goal-prior / importance-sampling terms stay fp64.  Costs
-                             within ~1e-9 of the all-fp64 step's, 1.6 x faster.
+                             within ~1e-9 of the all-fp64 step's, 1.7 x faster.
   store_free=True            optimize(opt_iters = K) returns the LAST iteration's tensors only (planner.py:289-317), so
                              iterations 1 .. K - 1 do not write their samples (470 MB per iteration at 1024 x 128 x 64):
                              the update regenerates the rows that carry weight from their noise keys, bit for bit
