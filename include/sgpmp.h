@@ -150,7 +150,8 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * f64_fields_f32 (opt-in, fp64 contexts: the one-launch step evaluates the LINK fields -- forward kinematics, self-distance and
  * sphere fields -- on the fp32 launches' packed code from the fp64 waypoint rounded to fp32; noise, recurrence, samples, means and
  * the GP / goal-prior / importance-sampling terms stay fp64.  The collision part of a cost then carries fp32's ~1e-6 relative
- * error -- ~1e-9 of a total cost at the reference's hyper-parameters -- and the step runs 1.7 x as fast: 0.46 against 0.79 ms at BASELINE configs[2]'s shape),
+ * error -- ~1e-9 of a total cost at the reference's hyper-parameters -- and the step runs 1.7 x as fast: 0.46 against 0.79 ms at BASELINE configs[2]'s shape; the occupancy COUNT is then taken on
+ * fp32 link positions too: a point within fp32 rounding of a sphere's surface may count differently, one quantum 1 / sigma_coll^2),
  * pipe_split (1..15) and k3_blocks (count).  (The launches that measured slower -- tail_update, small_step, planar_slabs,
  * wave_groups, fused_pipe -- were removed in round 5; DESIGN.md 8 keeps their numbers and the commit that last held them.)
  * No reference counterpart. */
