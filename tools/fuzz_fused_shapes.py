@@ -32,7 +32,7 @@ for i in range(count):
         crel = float(((a._costs - b._costs).abs() / b._costs.abs().clamp_min(1e-30)).max())
         mrel = float((a.particle_means - b.particle_means).abs().max()) / max(float(b.particle_means.abs().max()), 1e-30)
         flip = not bool(torch.equal(a._costs.argmin(1), b._costs.argmin(1)))
-        if ka != "fused_step_kernel" or not same or crel > 3e-5 or (mrel > 2e-6 and not flip) or not torch.isfinite(a._costs).all():
+        if not ka.startswith("fused_step") or not same or crel > 3e-5 or (mrel > 2e-6 and not flip) or not torch.isfinite(a._costs).all():
             ok = False
             print("MISMATCH", dict(T=T, S=S, nppg=nppg, G=G, ft=ft, nsph=nsph, it=it, kernel=ka, samples_equal=same, cost_rel=crel, means_rel=mrel, argmin_flip=flip))
         if flip:
