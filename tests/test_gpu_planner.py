@@ -284,7 +284,9 @@ def _fp32_panda_run(T, nppg, S, iters, goals=None, field_type='rbf', n_sph=5, se
     eps0 = torch.from_numpy(native_eps(seed, 0, range(G), nppg, T, n, "float32")).double()
     ora = SC.oracle_panda_planner(c, T, nppg, S, seed=seed, eps_init=eps0, goals=goals, field_type=field_type)
     pl = hip_panda_planner(c, T, nppg, S, F32, seed=seed, goals=goals, field_type=field_type)
-    if fused != True:
+    if fused == "small":
+        pl._engine.set_option("no_small_step", 0)        # the product's default for <= 512 items: one workgroup per item (conftest.py switches it off)
+    elif fused != True:
         pl._engine.set_option("no_fused_step", 1)        # sampler and sweep as two launches
     if fused == "dual":
         pl._engine.set_option("no_chunked_sweep", 1)     # ... and the 64-lane-pass two-trajectory sweep
@@ -328,8 +330,8 @@ def _report(tag, recs):
     return frac
 
 
-@pytest.mark.parametrize("fused,kernel", [(True, "fused_step_kernel"), ("chunked", "cost_sweep_chunked_kernel"),
-                                          ("dual", "cost_sweep_dual_pf_kernel")])
+@pytest.mark.parametrize("fused,kernel", [(True, "fused_step_kernel"), ("small", "fused_step_small_kernel"),
+                                          ("chunked", "cost_sweep_chunked_kernel"), ("dual", "cost_sweep_dual_pf_kernel")])
 def test_panda_fp32_headline_kernel_means_match_fp64_oracle(fused, kernel):
     """north_star: fp32 trajectory means within 1e-3 of the reference CPU path.  The headline kernels
     (the fused sampler + sweep launch, and cost_sweep_dual_pf_kernel behind the separate sampler: even
