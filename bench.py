@@ -320,6 +320,9 @@ def store_free_leg(torch, spec_kwargs, dev, config_key, steps, storing_ms, passe
     kms = kernel_profile(torch, pl, obs, min(steps, 60), unread=True)
     kernel = pl._engine.last_cost_kernel()
     ran = pl._engine.store_free_steps()
+    # (planar problems with 64 samples per particle: ONE launch runs all K - 1 store-free iterations of a call -- launch_ms below
+    # is then the single-iteration launch the step profiler times, iterations_per_launch what the timed call ran)
+    multi = pl._engine.multi_iteration_launches()
     k, src = profiled(config_key + "_store_free", kernel)
     launch_ms = kms["cost_sweep"]
     out = {"kernel": kernel, "iterations_per_s": steps / el, "ms_per_step": 1e3 * el / steps,
@@ -327,7 +330,8 @@ def store_free_leg(torch, spec_kwargs, dev, config_key, steps, storing_ms, passe
            "vs_storing": (storing_ms / (1e3 * el / steps)) if storing_ms else None,
            "launch_ms": launch_ms, "update_ms": kms.get("update"), "launches_per_step": pl._engine.last_step_launches(),
            "valu_frac": (k["valu_floor_ms"] / launch_ms) if (k and "valu_floor_ms" in k) else None,
-           "moved_bytes_per_launch": k.get("bytes") if k else None, "counters": src, "store_free_steps_run": ran}
+           "moved_bytes_per_launch": k.get("bytes") if k else None, "counters": src, "store_free_steps_run": ran,
+           "multi_iteration_launches": multi, "iterations_per_launch": (steps - 1) if multi else 1}
     del pl
     torch.cuda.empty_cache()
     return out

@@ -35,8 +35,8 @@ extern "C" {
  * 4: sgpmp_comm_library, sgpmp_set_fk_codegen / _info / _compile, sgpmp_dense_particles (round 4);
  * 5: SGPMP_STEP_NO_SAMPLES, sgpmp_row_counts_get / _set, sgpmp_store_free_steps, sgpmp_step honours per-mode sampling
  *    precisions; the options of the retired experiments are gone (round 5);
- * 6: sgpmp_optimize (the K-loop of optimize() behind the ABI), sgpmp_row_counts_clear, sgpmp_noise; fp64 contexts draw the
- *    fp32 noise stream, widened (round 6).
+ * 6: sgpmp_optimize (the K-loop of optimize() behind the ABI), sgpmp_row_counts_clear, sgpmp_noise, sgpmp_multi_iteration_launches;
+ *    fp64 contexts draw the fp32 noise stream, widened (round 6).
  * The Python binding refuses any other value at load time. */
 #define SGPMP_ABI_VERSION 6
 
@@ -137,6 +137,8 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * planar_store_free (store-free planar steps of ANY sample count by regenerating rows in update_kernel: bit-identical, measured slower
  * than storing at BASELINE configs[1]; problems with 64 samples per particle run store-free by default, with the update inside the launch),
  * no_planar_tail (those steps with update_kernel behind the launch instead),
+ * no_persist_planar (sgpmp_optimize runs the store-free iterations of such a problem one launch each, as round 5 did, instead of
+ * all of them in ONE launch: bit-identical, 1.4 x slower per iteration at BASELINE configs[1]),
  * no_ee_fold (the step's end-effector goal term by a launch of ee_goal_kernel in front of update_kernel, as in rounds 1-4, instead of
  * inside update_kernel: same numbers, one launch more),
  * no_small_step (steps of up to small_step_items items -- groups of 8 samples; default 512, two per CU, 256 for shapes off the
@@ -289,6 +291,8 @@ int sgpmp_row_counts_set(sgpmp_ctx* ctx, const uint32_t* in);
 int sgpmp_row_counts_clear(sgpmp_ctx* ctx, void* stream);
 /* steps of this context that ran store-free so far (SGPMP_STEP_NO_SAMPLES honoured; tests and bench.py report it) */
 long long sgpmp_store_free_steps(sgpmp_ctx* ctx);
+/* launches of this context that ran SEVERAL iterations each (sgpmp_optimize, planar problems with 64 samples per particle) */
+long long sgpmp_multi_iteration_launches(sgpmp_ctx* ctx);
 
 /* One body of the loop at planner.py:289-299 for the context's particle shard:
  * K5 -> K2 -> K3 -> K4 on `stream` (K2 + K3 as ONE launch when the configuration qualifies, see

@@ -93,6 +93,7 @@ SIGNATURES = {
     "sgpmp_row_counts_set": (_I, [_P, C.POINTER(C.c_uint32)]),
     "sgpmp_row_counts_clear": (_I, [_P, _P]),
     "sgpmp_store_free_steps": (C.c_longlong, [_P]),
+    "sgpmp_multi_iteration_launches": (C.c_longlong, [_P]),
     "sgpmp_optimize": (_I, [_P, _I, _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _I, _D, _D, _P, _I, _I, _P]),
     "sgpmp_step": (_I, [_P, _U64, _U64, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _D, _D, _P, _I, _P]),
     "sgpmp_fk": (_I, [_P, _P, _I64, _P, _P]),

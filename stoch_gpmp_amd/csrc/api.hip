@@ -97,6 +97,8 @@ struct sgpmp_ctx {
     float* d_part = nullptr;         // [P][ceil(S / 8)][4 + M], allocated by the first step that can use it
     unsigned* d_nnz = nullptr;       // [P], allocated (zero) by the first fp32 step
     long long dense_armed_steps = 0, store_free_steps = 0;
+    long long multi_iteration_launches = 0;
+    int tail_iters_next = 0;         // sgpmp_optimize -> its next sgpmp_step: iterations the step's launch runs itself (fused_planar_seg.inc: PERSIST)
     int last_step_launches = 0;      // kernels the last sgpmp_step enqueued for its particle range (1: everything in one launch)
     hipStream_t k1_side = nullptr;   // sgpmp_set_priors: the second factorisation's stream
     hipEvent_t k1_fork = nullptr;
@@ -109,7 +111,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"k3_no_one", &SgpmpToggles::k3_no_one}, {"k3_no_lds_prefetch", &SgpmpToggles::k3_no_lds_prefetch},
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
-    {"comm_packet_event", &SgpmpToggles::comm_packet_event}, {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"planar_store_free", &SgpmpToggles::planar_store_free}, {"no_planar_tail", &SgpmpToggles::no_planar_tail},
+    {"comm_packet_event", &SgpmpToggles::comm_packet_event}, {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"planar_store_free", &SgpmpToggles::planar_store_free}, {"no_planar_tail", &SgpmpToggles::no_planar_tail}, {"no_persist_planar", &SgpmpToggles::no_persist_planar},
     {"no_small_step", &SgpmpToggles::no_small_step}, {"no_ee_fold", &SgpmpToggles::no_ee_fold}, {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
     {"f64_fields_f32", &SgpmpToggles::f64_fields_f32},
 };
@@ -1060,6 +1062,7 @@ extern "C" int sgpmp_row_counts_clear(sgpmp_ctx* c, void* stream) {
     return SGPMP_OK;
 }
 extern "C" long long sgpmp_store_free_steps(sgpmp_ctx* c) { return c ? c->store_free_steps : 0; }
+extern "C" long long sgpmp_multi_iteration_launches(sgpmp_ctx* c) { return c ? c->multi_iteration_launches : 0; }
 
 // ---- two-chain steps (StepPipe) ----------------------------------------------------------------------------
 static int pipe_first_half(const sgpmp_ctx* c) {
@@ -1316,11 +1319,17 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         if (!c->ms_buf) {                                        // (the per-step mean statistics want update_kernel's snapshot of the new means)
             dense.tail_done = c->d_done; dense.tail_acc = c->d_tail_acc; dense.stats_out = acc_stats;
             dense.weights = weights; dense.grad = grad; dense.means_prev = means_prev; dense.step_size = step_size;
+            dense.tail_iters = c->tail_iters_next;
         }
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, means, P,
                                  D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, acc_stats, costs,
                                  c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, &dense, &partials, &regen, &tail_ran));
         if (fused) { c->last_step_launches += 1; if (partials) c->dense_armed_steps += 1; if (regen.recipe != 0 || tail_ran) c->store_free_steps += 1; }
+        if (dense.tail_iters > 1) {                              // (sgpmp_optimize checked that this step's launch carries its update)
+            if (!tail_ran) return fail(SGPMP_ESTATE, "sgpmp_step: the launch of several iterations did not run (internal)");
+            c->store_free_steps += dense.tail_iters - 1;
+            c->multi_iteration_launches += 1;
+        }
         eet = fused ? ee_term_to_fold(c) : nullptr;
         for (int i = 0; fused && !eet && i < c->h_prog.n_terms; ++i)
             if (c->h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) {
@@ -1392,9 +1401,38 @@ extern "C" int sgpmp_optimize(sgpmp_ctx* c, int opt_iters, uint64_t seed, uint64
     if (opt_iters < 1) return fail(SGPMP_EINVAL, "sgpmp_optimize: opt_iters must be at least 1");
     const bool piped = (flags & SGPMP_OPT_PIPELINE) && opt_iters >= 2;
     int rc = SGPMP_OK;
+    // A planar problem whose store-free steps carry their update inside the launch (S = 64: BASELINE configs[1]) runs ALL of
+    // the call's store-free iterations in ONE launch (fused_planar_seg.inc: PERSIST) -- a particle's workgroup needs nothing from
+    // outside itself between two iterations, so what the K - 2 launch boundaries cost (4 of an iteration's 20 us there) goes.
+    // Same arithmetic on the same numbers: bit-identical.  (Not with a communicator, per-step statistics of the means or the
+    // step profiler: each wants something per iteration from the host side.)
+    int inner = 0;
+    if ((flags & SGPMP_OPT_STORE_FREE) && opt_iters >= 3 && !c->comm && !c->ms_buf && !c->profiling &&
+        means && samples && c->prior[SGPMP_PRIOR_SAMPLE].valid && finalize_program(c) == SGPMP_OK) {
+        const sgpmp_dims& D = c->dims;
+        const PriorDev& pr = c->prior[SGPMP_PRIOR_SAMPLE];
+        // (such a step is never split over the two chains: a half would have to bring 256 workgroups, i.e. S = 64 x 512 particles
+        // -- checked all the same, on the pipeline's own criterion)
+        const int P = D.num_particles, P0 = pipe_first_half(c);
+        const bool may_split = piped && !c->tg.no_step_pipeline && (long long)(P0 < P - P0 ? P0 : P - P0) * D.num_samples >= 256 * 64;
+        if (!may_split && !(pr.n_factor_modes > 0) &&
+            planar_persist_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, P, D.particle_offset, D.num_samples, n_spheres, c->tg))
+            inner = opt_iters - 1;
+    }
     if (piped && (rc = sgpmp_pipeline_begin(c, stream)) != SGPMP_OK) return rc;
     for (int k = 0; k < opt_iters; ++k) {
         const bool last = k == opt_iters - 1;
+        if (k == 0 && inner >= 2) {
+            // iterations 0 .. inner - 1 (draws draw0 .. draw0 + inner - 1) in one launch; no statistics of theirs are formed
+            c->tail_iters_next = inner;
+            rc = sgpmp_step(c, seed, draw0, nullptr, 0, 0, means, samples, costs, weights, grad, means_prev_scratch, spheres,
+                            n_spheres, temperature, step_size, nullptr,
+                            ((flags & SGPMP_STEP_MEANS_KEPT) ? SGPMP_STEP_MEANS_KEPT : 0) | SGPMP_STEP_NO_SAMPLES, stream);
+            c->tail_iters_next = 0;
+            if (rc != SGPMP_OK) break;
+            k = inner - 1;
+            continue;
+        }
         const int f = ((k > 0 || (flags & SGPMP_STEP_MEANS_KEPT)) ? SGPMP_STEP_MEANS_KEPT : 0) |
                       ((!last && (flags & SGPMP_OPT_STORE_FREE)) ? SGPMP_STEP_NO_SAMPLES : 0);
         double* st = stats_pair ? stats_pair + (size_t)((first_slot + k) & 1) * SGPMP_STAT_SHARDS * 4 : nullptr;

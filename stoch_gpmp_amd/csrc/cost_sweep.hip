@@ -167,6 +167,28 @@ bool planar_seg_step(int dtype, int n, int T, const PriorDev& prior, const CostP
            planar_seg_len(n, T, S, tg) != 0;
 }
 
+static size_t planar_seg_lds(int n, int T, int L) {
+    const int G = T / L;
+    return (size_t)G * 64 * (16 * n + 8) + (size_t)G * 64 * 20 * sizeof(float) + (size_t)G * 16;
+}
+bool planar_tail_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
+                      int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg) {
+    if (!planar_seg_step(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg)) return false;
+    const int L = planar_seg_len(n, T, S, tg);
+    return S == 64 && prior.isotropic && !tg.no_planar_tail && (long long)P * S / 64 <= (1LL << 20) &&
+           (size_t)T * 2 * n * sizeof(float) + planar_seg_lds(n, T, L) <= 160 * 1024;
+}
+// ... and can ONE launch run several of them (PERSIST)?  Instantiated for n = 2 with segments of 8 waypoints -- BASELINE
+// configs[1]'s shape: 110 vector registers.  Segments of 16 and n = 3 hold 32 / 48 waypoint values per lane: their single-step
+// launches use 118 / 114 of the 128 registers a 1024-thread workgroup's waves can have, and the loop's few carried values
+// pushed 21 / 19 registers into scratch (tools/audit_asm_loads.py refuses scratch in these kernels) -- those shapes keep one
+// launch per iteration.
+bool planar_persist_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
+                         int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg) {
+    return !tg.no_persist_planar && n == 2 && planar_seg_len(n, T, S, tg) == 8 &&
+           planar_tail_step(dtype, n, T, prior, h_prog, h_chain, P, mode_offset, S, n_spheres, tg);
+}
+
 // Which rows would update_kernel have to regenerate if this step ran store-free?  1: fused_step_kernel's, 2:
 // fused_planar_seg_kernel's (*seg_len waypoints per segment), 0: the step's launch has no store-free form (the tile launch
 // fused_planar_kernel, the two-launch paths) or its costs are not complete inside the launch (ee_goal_kernel reads the rows).
@@ -299,7 +321,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
             const int L = planar_seg_len(n, T, S, tg), G = L ? T / L : 0;
             const long long wgs = batch / 64;
             if (L && wgs <= (1LL << 20)) {
-                size_t lds = (size_t)G * 64 * (16 * n + 8) + (size_t)G * 64 * 20 * sizeof(float) + (size_t)G * 16;
+                size_t lds = planar_seg_lds(n, T, L);
                 fs.gpp = S / 64; fs.gpp_shift = log2_exact(fs.gpp);
                 // Store-free step of a problem whose particles have exactly one workgroup's 64 samples: the UPDATE runs inside the
                 // launch (seg_update) -- no sample store, no update_kernel, no regeneration: one launch per iteration
@@ -312,6 +334,9 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                     t.means_prev = (float*)dense->means_prev; t.isw_next = (float*)const_cast<void*>(isw); t.nnz_out = dense->nnz;
                     t.Qinv = prior.Qinv; t.ks = prior.ks; t.kg = prior.kg; t.dt = prior.dt;
                     t.temperature = dense->temperature; t.step_size = dense->step_size; t.P = P;
+                    t.iters = dense->tail_iters > 1 ? dense->tail_iters : 1;
+                    if (t.iters > 1 && !(n == 2 && L == 8)) return hipErrorInvalidValue;    // (planar_persist_step: the caller asks first)
+                    if (t.iters > 1) { t.done = nullptr; t.stats_out = nullptr; }    // (several iterations in this launch: no statistics)
                     fs.nostore = 1; fs.store_threshold = 0xffffffffu;
                     fs.zero_stats = nullptr;                      // (the launch's last particle writes the statistics)
                     lds += (size_t)T * 2 * n * sizeof(float);
@@ -319,9 +344,11 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                     *tail_ran = true;
                 }
                 const float* tab = prior.slabpre + (size_t)(L == 8 ? 3 : 4) * T * 4;
+                const bool persist = upd && fs.tail.iters > 1;
 #define SEG_LAUNCH(NN, LL) do { if (upd) hipLaunchKernelGGL((fused_planar_seg_kernel<NN, LL, true>), dim3((unsigned)wgs), dim3(64 * G), (unsigned)lds, stream, a, F, fs, tab); \
                                  else hipLaunchKernelGGL((fused_planar_seg_kernel<NN, LL, false>), dim3((unsigned)wgs), dim3(64 * G), (unsigned)lds, stream, a, F, fs, tab); } while (0)
-                if (n == 2) { if (L == 8) SEG_LAUNCH(2, 8); else SEG_LAUNCH(2, 16); }
+                if (persist) hipLaunchKernelGGL((fused_planar_seg_kernel<2, 8, true, true>), dim3((unsigned)wgs), dim3(64 * G), (unsigned)lds, stream, a, F, fs, tab);
+                else if (n == 2) { if (L == 8) SEG_LAUNCH(2, 8); else SEG_LAUNCH(2, 16); }
                 else SEG_LAUNCH(3, 8);
 #undef SEG_LAUNCH
                 if (picked) *picked = "fused_planar_seg_kernel";

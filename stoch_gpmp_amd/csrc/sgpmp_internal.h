@@ -125,6 +125,7 @@ struct SgpmpToggles {
     int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
     int no_ee_fold;           // SGPMP_NO_EE_FOLD           the step's end-effector goal term by a launch of ee_goal_kernel in front of update_kernel (rounds 1-4) instead of inside it
     int f64_fields_f32;       // SGPMP_F64_FIELDS_F32       fp64 steps (fused_step_f64_kernel) evaluate the LINK fields -- forward kinematics, self-distance and sphere fields -- on the packed-fp32 code of the fp32 launches, from the fp64 waypoint rounded to fp32; samples, means, GP / goal-prior / importance-sampling terms stay fp64.  Opt-in: the collision part of a cost then carries fp32's ~1e-6 relative error (~1e-9 of a total cost at the reference's hyper-parameters)
+    int no_persist_planar;    // SGPMP_NO_PERSIST_PLANAR    sgpmp_optimize runs the store-free iterations of a planar S = 64 problem as one launch each (round 5) instead of ONE launch for all of them (fused_planar_seg.inc: PERSIST)
     int no_small_step;        // SGPMP_NO_SMALL_STEP        small steps through fused_step_kernel (one wave per item) instead of fused_step_small_kernel (one workgroup per item)
     long long small_step_items;   // SGPMP_SMALL_STEP_ITEMS     items (groups of 8 samples) up to which a step counts as small (0: default 512 -- two workgroups per CU -- for shapes on the launch's 8 x 16 grid, 256 for the others)
     long long store_free_min_bytes;   // SGPMP_STORE_FREE_MIN_BYTES  a store-free step that REGENERATES rows in update_kernel is taken when one waypoint of all the step's samples (P S 2n floats) has at least this many bytes (0: the measured break-even, SGPMP_STORE_FREE_BREAK_EVEN; 1: always)
@@ -209,6 +210,7 @@ struct FusedDenseHost {
     double* stats_out;            // the step's statistics buffer or null
     void* weights; void* grad; void* means_prev;   // K4's optional outputs (context dtype)
     double step_size;
+    int tail_iters;               // > 1: the launch runs that many store-free iterations itself (fused_planar_seg.inc: PERSIST; sgpmp_optimize)
 };
 // bytes of one waypoint of all samples of a step above which a regenerating store-free step is faster than a storing one
 // (cost_sweep.hip: launch_fused_step has the measurement)
@@ -243,6 +245,12 @@ int fused_step_regen_recipe(int dtype, int n, int T, const PriorDev& prior, cons
                             int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg, int* seg_len);
 bool planar_seg_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
                      int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg);
+// ... and would a store-free step of it run its update inside the launch (one launch per iteration; what PERSIST extends)?
+bool planar_tail_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
+                      int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg);
+// ... and can one launch run SEVERAL such steps (FusedDenseHost::tail_iters > 1)?
+bool planar_persist_step(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
+                         int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg);
 // does the step qualify for the fused launch? (same conditions, no launch)
 bool fused_step_eligible(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog,
                          const ChainDev& h_chain, int P, int mode_offset, int S, int n_spheres,

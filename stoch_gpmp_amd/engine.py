@@ -123,6 +123,10 @@ class Engine:
         """Steps of this context that did not write their samples (SGPMP_STEP_NO_SAMPLES honoured)."""
         return int(self.lib.sgpmp_store_free_steps(self._ctx))
 
+    def multi_iteration_launches(self):
+        """Launches that ran several iterations of an optimize(opt_iters = K) call each (planar problems, 64 samples per particle)."""
+        return int(self.lib.sgpmp_multi_iteration_launches(self._ctx))
+
     def last_cost_kernel(self):
         """Name of the cost-sweep kernel the dispatcher picked at the last launch."""
         return self.lib.sgpmp_last_cost_kernel(self._ctx).decode()

@@ -116,6 +116,7 @@ static void run_planner(int n, int T, int P, int P_global, int offset, int S, in
         CHECK(sgpmp_row_counts_set(c, rc.data()));
         CHECK(sgpmp_row_counts_set(c, nullptr));
         (void)sgpmp_store_free_steps(c);
+        (void)sgpmp_multi_iteration_launches(c);
     }
     CHECK(sgpmp_pipeline_end(c, nullptr));                      // idempotent
     // round 6: the K-loop of optimize() behind the ABI (draw counters, alternating statistics slots, flags, the bracket), the

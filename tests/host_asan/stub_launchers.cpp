@@ -70,6 +70,8 @@ int fused_step_regen_recipe(int dtype, int n, int T, const PriorDev& pr, const C
     return fused_step_eligible(dtype, n, T, pr, prog, ch, P, off, S, ns, tg) && prog.n_ee == 0 ? 1 : 0;
 }
 bool planar_seg_step(int, int, int, const PriorDev&, const CostProgram&, const ChainDev&, int, int, int, int, const SgpmpToggles&) { return false; }
+bool planar_persist_step(int, int, int, const PriorDev&, const CostProgram&, const ChainDev&, int, int, int, int, const SgpmpToggles&) { return false; }
+bool planar_tail_step(int, int, int, const PriorDev&, const CostProgram&, const ChainDev&, int, int, int, int, const SgpmpToggles&) { return false; }
 bool fused_step_eligible(int dtype, int, int T, const PriorDev&, const CostProgram&, const ChainDev&, int P, int, int S, int, const SgpmpToggles& tg) {
     return env1("STUB_FUSED") && dtype == SGPMP_F32 && !tg.no_fused_step && T % 16 == 0 && S % 8 == 0 && P > 0;
 }

@@ -1246,6 +1246,40 @@ def test_store_free_iterations_equal_storing_iterations_bitwise_planar(golden, n
         assert a._engine.last_step_launches() == 2           # (the call's last iteration: launch + update_kernel)
         a.step(_samples_unread=True)
         assert a._engine.last_step_launches() == 1           # a store-free step: ONE launch
+        # round 6: calls of three iterations and more run ALL their store-free iterations in one launch where the launch has that
+        # form (n = 2, segments of 8 waypoints: BASELINE configs[1]'s shape) -- the calls of 5 and 3 above did
+        assert a._engine.multi_iteration_launches() == (3 if (n == 2 and T <= 128) else 0)
+
+
+@pytest.mark.parametrize("nppg,G,T", [(64, 4, 128), (3, 2, 64), (1, 1, 16)])
+def test_all_store_free_iterations_in_one_launch_equal_one_launch_each(golden, nppg, G, T):
+    """sgpmp_optimize hands iterations 0 .. K - 2 of a planar problem with 64 samples per particle to ONE launch
+    (fused_planar_seg.inc: PERSIST -- a particle's workgroup loops over them, re-reading its own means and importance-sampling
+    weights) against round 5's launch per iteration (option no_persist_planar): the returned tuple, means, samples, weights,
+    gradient, costs, previous means, row counts and the statistics of the call's last step, bit for bit, over calls of several
+    lengths (K = 2 has one store-free iteration: no such launch)."""
+    goals = [[9., 6., 0., 0.], [9., -3., 0., 0.], [-3., 9., 0., 0.], [6., 9., 0., 0.]][:G]
+    om = planar_map(golden, F32)
+    a = hip_planar_planner(SC.PLANAR, T, goals, nppg, 64, om, F32, seed=71)
+    b = hip_planar_planner(SC.PLANAR, T, goals, nppg, 64, om, F32, seed=71)
+    b._engine.set_option("no_persist_planar", 1)
+    launches = 0
+    for k in (3, 2, 40, 1, 7):
+        ra, rb = a.optimize(opt_iters=k), b.optimize(opt_iters=k)
+        for i, (x, y) in enumerate(zip(ra, rb)):
+            assert torch.equal(x, y), (k, i)
+        assert torch.equal(a.particle_means, b.particle_means) and torch.equal(a.state_samples, b.state_samples), k
+        assert torch.equal(a._weights_buf, b._weights_buf) and torch.equal(a._grad, b._grad), k
+        assert torch.equal(a._costs, b._costs) and torch.equal(a._means_prev, b._means_prev), k
+        assert (a._engine.row_counts() == b._engine.row_counts()).all()
+        sa, sb = a.global_stats(), b.global_stats()
+        assert abs(sa[0] / sb[0] - 1) < 1e-12 and abs(sa[1] / sb[1] - 1) < 1e-12
+        launches += 1 if k >= 3 else 0
+        assert a._engine.multi_iteration_launches() == launches and b._engine.multi_iteration_launches() == 0
+    assert a._engine.store_free_steps() == b._engine.store_free_steps() == 2 + 1 + 39 + 0 + 6
+    # a step of its own afterwards starts from the state the loop left (the weights of the next step were written inside it)
+    ra, rb = a.step(), b.step()
+    assert torch.equal(a.particle_means, b.particle_means) and torch.equal(a.state_samples, b.state_samples)
 
 
 def test_store_free_planar_update_inside_the_launch_with_soft_weights(golden):
