@@ -323,7 +323,9 @@ def store_free_leg(torch, spec_kwargs, dev, config_key, steps, storing_ms, passe
     # (planar problems with 64 samples per particle: ONE launch runs all K - 1 store-free iterations of a call -- launch_ms below
     # is then the single-iteration launch the step profiler times, iterations_per_launch what the timed call ran)
     multi = pl._engine.multi_iteration_launches()
-    k, src = profiled(config_key + "_store_free", kernel)
+    k, src = profiled(config_key + "_store_free", kernel + "_tail")   # (tools/summarise_prof.py: the planar launch with its update inside)
+    if not k:
+        k, src = profiled(config_key + "_store_free", kernel)
     launch_ms = kms["cost_sweep"]
     out = {"kernel": kernel, "iterations_per_s": steps / el, "ms_per_step": 1e3 * el / steps,
            "ms_per_step_of_each_pass": [1e3 * e / steps for e in els], "steps": steps,

@@ -349,7 +349,12 @@ int sgpmp_pipeline_end(sgpmp_ctx* ctx, void* stream);
  * SGPMP_OPT_STORE_FREE gives steps 0 .. K - 2 SGPMP_STEP_NO_SAMPLES (the reference returns the last iteration's tensors
  * only); SGPMP_OPT_PIPELINE brackets the call with sgpmp_pipeline_begin / _end when opt_iters >= 2.  Results are those of
  * the same sgpmp_step calls made one by one, bit for bit; the first failing step's status is returned (the bracket is
- * closed first).  No host synchronisation. */
+ * closed first).  No host synchronisation.
+ * Under SGPMP_OPT_STORE_FREE, opt_iters >= 3, a planar problem with 64 samples per particle (n = 2, time segments of 8: the
+ * store-free step carries its update inside the launch) runs steps 0 .. K - 2 as ONE launch (csrc/fused_planar_seg.inc:
+ * PERSIST; not with a communicator, the step profiler or per-step mean statistics).  Every output is the same, bit for bit,
+ * with one exception: the statistics of steps 0 .. K - 2 are not formed -- only the LAST step's slot of stats_pair,
+ * (first_slot + K - 1) & 1, is written by such a call.  Option no_persist_planar. */
 #define SGPMP_OPT_PIPELINE 4
 #define SGPMP_OPT_STORE_FREE 8
 int sgpmp_optimize(sgpmp_ctx* ctx, int opt_iters, uint64_t seed, uint64_t draw0, void* means, void* samples,

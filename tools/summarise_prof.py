@@ -16,7 +16,17 @@ def short(name):
 
 
 def base(name):
-    return name.replace("void ", "").split("<")[0].split("(")[0].strip()
+    b = name.replace("void ", "").split("<")[0].split("(")[0].strip()
+    # fused_planar_seg_kernel<N, L, TAIL, PERSIST>: three different launches under one name -- the storing step, the store-free
+    # step with its update inside (one iteration), and the launch that runs ALL store-free iterations of a call (its per-launch
+    # figures are those of K - 1 iterations, K whatever the profiled command's calls were)
+    if b == "fused_planar_seg_kernel" and "<" in name:
+        targs = [t.strip() for t in name.split("<", 1)[1].split(">")[0].split(",")]
+        if len(targs) >= 4 and targs[3] == "true":
+            return b + "_multi"
+        if len(targs) >= 3 and targs[2] == "true":
+            return b + "_tail"
+    return b
 
 
 def main(d):
