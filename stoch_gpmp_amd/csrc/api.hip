@@ -82,7 +82,6 @@ struct sgpmp_ctx {
     // launches by construction (the launch's last particle resets them)
     unsigned* d_done = nullptr;      // [2]
     double* d_tail_acc = nullptr;    // [2][SGPMP_STAT_SHARDS][4]
-    unsigned* d_arrive = nullptr;    // [P] finished-item counters of the update inside fused_step_small_kernel (zero between launches)
     // per-goal mean statistics once per iteration (sgpmp_set_step_mode_stats): the update kernel leaves a snapshot of
     // the new means, a side stream reduces it per goal and all-reduces the sums -- nothing on the steps' own stream
     double* ms_buf = nullptr;        // caller's [G][M+1][2] buffer, or null: off
@@ -112,7 +111,7 @@ static const struct { const char* name; int SgpmpToggles::*flag; } kToggleNames[
     {"k3_no_one", &SgpmpToggles::k3_no_one}, {"k3_no_lds_prefetch", &SgpmpToggles::k3_no_lds_prefetch},
     {"no_small_sampler", &SgpmpToggles::no_small_sampler}, {"no_fused_step", &SgpmpToggles::no_fused_step},
     {"no_chunked_sweep", &SgpmpToggles::no_chunked_sweep}, {"no_step_pipeline", &SgpmpToggles::no_step_pipeline},
-    {"comm_packet_event", &SgpmpToggles::comm_packet_event}, {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"planar_store_free", &SgpmpToggles::planar_store_free}, {"no_planar_tail", &SgpmpToggles::no_planar_tail}, {"no_persist_planar", &SgpmpToggles::no_persist_planar}, {"no_small_tail", &SgpmpToggles::no_small_tail},
+    {"comm_packet_event", &SgpmpToggles::comm_packet_event}, {"no_planar_seg", &SgpmpToggles::no_planar_seg}, {"planar_store_free", &SgpmpToggles::planar_store_free}, {"no_planar_tail", &SgpmpToggles::no_planar_tail}, {"no_persist_planar", &SgpmpToggles::no_persist_planar},
     {"no_small_step", &SgpmpToggles::no_small_step}, {"no_ee_fold", &SgpmpToggles::no_ee_fold}, {"no_dense_partials", &SgpmpToggles::no_dense_partials}, {"gpmp_cholesky", &SgpmpToggles::gpmp_cholesky},
     {"f64_fields_f32", &SgpmpToggles::f64_fields_f32},
 };
@@ -371,7 +370,7 @@ extern "C" void sgpmp_destroy(sgpmp_ctx* c) {
     free_prior(c->prior[0]);
     free_prior(c->prior[1]);
     hipFree(c->d_qc); hipFree(c->d_prog); hipFree(c->d_chain); hipFree(c->d_isw);
-    hipFree(c->d_costs64); hipFree(c->d_done); hipFree(c->d_tail_acc); hipFree(c->d_arrive);
+    hipFree(c->d_costs64); hipFree(c->d_done); hipFree(c->d_tail_acc);
     hipFree(c->d_part); hipFree(c->d_nnz);
     if (c->ms_side) { hipStreamSynchronize(c->ms_side); hipStreamDestroy(c->ms_side); }
     for (int i = 0; i < 2; ++i) { hipFree(c->ms_snap[i]); if (c->ms_read[i]) hipEventDestroy(c->ms_read[i]); }
@@ -1006,10 +1005,6 @@ static int dense_buffers(sgpmp_ctx* c, FusedDenseHost* d, double temperature, bo
         HIPCHK(hipMemset(c->d_nnz, 0, P * sizeof(unsigned)));
     }
     d->nnz = c->d_nnz;
-    if (chain_code_step && !c->d_arrive) {
-        HIPCHK(hipMalloc(&c->d_arrive, (size_t)D.num_particles * sizeof(unsigned)));
-        HIPCHK(hipMemset(c->d_arrive, 0, (size_t)D.num_particles * sizeof(unsigned)));
-    }
     if (chain_code_step && !c->tg.no_dense_partials && c->M % 4 == 0) {
         if (!c->d_part)
             HIPCHK(hipMalloc(&c->d_part, (size_t)D.num_particles * (size_t)((D.num_samples + 7) / 8) * (size_t)(c->M + 4) * sizeof(float)));
@@ -1312,7 +1307,7 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
     c->last_step_launches = prepared ? 0 : 1;
     FusedDenseHost dense;                                        // what the launch and the update share per particle (row counts, partials)
     std::memset(&dense, 0, sizeof(dense));
-    bool partials = false, tail_ran = false, tail_storing = false;   // tail_ran: the launch also updated its particles (seg_update; lat_update_tail: a storing step)
+    bool partials = false, tail_ran = false;                     // tail_ran: the launch also updated its particles (fused_planar_seg.inc: seg_update)
     RegenHost regen;                                             // store-free step: how the update regenerates rows
     std::memset(&regen, 0, sizeof(regen));
     const CostTerm* eet = nullptr;                               // the end-effector goal term update_kernel evaluates itself (fused steps)
@@ -1323,14 +1318,13 @@ extern "C" int sgpmp_step(sgpmp_ctx* c, uint64_t seed, uint64_t draw, const void
         dense.nostore = (flags & SGPMP_STEP_NO_SAMPLES) ? 1 : 0;
         if (!c->ms_buf) {                                        // (the per-step mean statistics want update_kernel's snapshot of the new means)
             dense.tail_done = c->d_done; dense.tail_acc = c->d_tail_acc; dense.stats_out = acc_stats;
-            dense.arrive = c->d_arrive; dense.d_chain = c->have_chain ? c->d_chain : nullptr;
             dense.weights = weights; dense.grad = grad; dense.means_prev = means_prev; dense.step_size = step_size;
             dense.tail_iters = c->tail_iters_next;
         }
         HIPCHK(launch_fused_step(D.dtype, D.n_dof, D.traj_len, pr, c->h_prog, c->h_chain, seed, draw, means, P,
                                  D.particle_offset, S, samples, spheres, n_spheres, c->d_isw, acc_stats, costs,
-                                 c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, &dense, &partials, &regen, &tail_ran, &tail_storing));
-        if (fused) { c->last_step_launches += 1; if (partials) c->dense_armed_steps += 1; if (regen.recipe != 0 || (tail_ran && !tail_storing)) c->store_free_steps += 1; }
+                                 c->d_costs64, st, c->tg, &c->last_cost_kernel, &fused, &dense, &partials, &regen, &tail_ran));
+        if (fused) { c->last_step_launches += 1; if (partials) c->dense_armed_steps += 1; if (regen.recipe != 0 || tail_ran) c->store_free_steps += 1; }
         if (dense.tail_iters > 1) {                              // (sgpmp_optimize checked that this step's launch carries its update)
             if (!tail_ran) return fail(SGPMP_ESTATE, "sgpmp_step: the launch of several iterations did not run (internal)");
             c->store_free_steps += dense.tail_iters - 1;

@@ -213,8 +213,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                              int mode_offset, int S, void* samples, const void* spheres, int n_spheres,
                              const void* isw, double* zero_stats, void* costs, double* costs64,
                              hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched,
-                             const FusedDenseHost* dense, bool* partials_armed, RegenHost* regen, bool* tail_ran, bool* tail_storing) {
-    if (tail_storing) *tail_storing = false;
+                             const FusedDenseHost* dense, bool* partials_armed, RegenHost* regen, bool* tail_ran) {
     *launched = false;
     if (tail_ran) *tail_ran = false;
     if (partials_armed) *partials_armed = false;
@@ -375,30 +374,6 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
     // unsharded run takes)
     const long long items_global = (long long)(dense && dense->particles_global > 0 ? dense->particles_global : P) * fs.gpp;
     const bool small = !tg.no_small_step && items_global <= small_items && (T + SGPMP_FUSED_TC - 1) / SGPMP_FUSED_TC <= 16;
-    // ... with its update inside (fused_step.inc: lat_update_tail): a STORING small step whose update update_kernel would run
-    // from the rows in memory -- at most one end-effector goal term, folded in as update_kernel folds it; no per-step mean
-    // statistics (the caller leaves tail_done null for those); M a multiple of 4 (update_particle's 16-byte instantiation);
-    // update_particle's scratch -- S weights and indices, the new means, S doubles of the end-effector term -- inside the
-    // launch's 30.7 KB of sample tiles.  One item per workgroup (the small launch's grid).
-    const CostTerm* eet = nullptr;
-    for (int i = 0; i < h_prog.n_terms; ++i)
-        if (h_prog.terms[i].kind == SGPMP_COST_EE_GOAL) eet = &h_prog.terms[i];
-    const size_t tail_lds = (((((size_t)S * 12 + 15) & ~(size_t)15) + (size_t)T * 2 * n * sizeof(float) + 15) & ~(size_t)15) + (size_t)S * 8;
-    const bool small_tail = small && dense && dense->tail_done && dense->arrive && tail_ran && !tg.no_small_tail && !fs.nostore &&
-                            (h_prog.n_ee == 0 || (h_prog.n_ee == 1 && eet && !tg.no_ee_fold && dense->d_chain && update_ee_fold_fits(dtype, n, T, S))) &&
-                            prior.isotropic && (T * 2 * n) % 4 == 0 &&
-                            tail_lds <= (size_t)4 * SGPMP_FUSED_SPW * (((2 * n + 3) / 4) * 4 + SGPMP_FUSED_TC * 2 * n) * sizeof(float);
-    if (small_tail) {
-        SegTail& t = fs.tail;
-        t.done = dense->tail_done; t.acc = dense->tail_acc; t.stats_out = dense->stats_out; t.arrive = dense->arrive;
-        t.means = (float*)const_cast<void*>(means); t.weights = (float*)dense->weights; t.grad = (float*)dense->grad;
-        t.means_prev = (float*)dense->means_prev; t.isw_next = (float*)const_cast<void*>(isw); t.nnz_out = dense->nnz;
-        t.Qinv = prior.Qinv; t.ks = prior.ks; t.kg = prior.kg; t.dt = prior.dt;
-        t.temperature = dense->temperature; t.step_size = dense->step_size; t.P = P; t.iters = 1;
-        if (h_prog.n_ee == 1) t.ee = EeFold<float>{dense->d_chain, make_ee_target<float>(*eet), n, T, (float*)costs};
-        fs.zero_stats = nullptr;                          // (the launch's last particle writes the statistics)
-    }
-    auto tail_launched = [&]() { if (small_tail) { *tail_ran = true; if (tail_storing) *tail_storing = true; } };
     if (h_chain.plan.codegen_id == 2) {           // this chain's kernels were compiled at run time (chain_rtc.hip)
         hipFunction_t f = rtc_kernel((RtcChain*)h_chain.rtc, ft, false, srag, small);
         if (!f) return hipSuccess;                // (not launched: the caller takes the two-launch path)
@@ -406,7 +381,6 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
         const hipError_t e = rtc_launch(f, small ? (unsigned)fs.nitems : (unsigned)blocks, (unsigned)fused_wave_dyn_lds(n_spheres, F.has_goal ? F.goal.dim0 : 0), stream, args, nullptr);
         if (picked) *picked = small ? "fused_step_small_kernel (run-time chain code)" : "fused_step_kernel (run-time chain code)";
         *launched = e == hipSuccess;
-        if (e == hipSuccess) tail_launched();
         return e;
     }
 #ifndef SGPMP_FUSED_EXTRA_LDS   // occupancy diagnostic: unused bytes per workgroup, e.g. 8000 -> four workgroups per CU instead of five
@@ -424,7 +398,6 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
 #undef SMALL_LAUNCH
         if (picked) *picked = "fused_step_small_kernel";
         *launched = true;
-        tail_launched();
         return hipGetLastError();
     }
 #define FUSED_LAUNCH(FT_, RAG_) hipExtLaunchKernelGGL((fused_step_kernel<CCp::N, CCp, FT_, RAG_>), dim3((unsigned)blocks), dim3(256), (unsigned)dyn + SGPMP_FUSED_EXTRA_LDS, stream, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0u, a, F, fs)

@@ -125,7 +125,6 @@ struct SgpmpToggles {
     int no_planar_seg;        // SGPMP_NO_PLANAR_SEG        planar one-launch step as fused_planar_kernel (8 samples per wave through an LDS tile) even where fused_planar_seg_kernel (lane = sample, wave = time segment) applies
     int no_ee_fold;           // SGPMP_NO_EE_FOLD           the step's end-effector goal term by a launch of ee_goal_kernel in front of update_kernel (rounds 1-4) instead of inside it
     int f64_fields_f32;       // SGPMP_F64_FIELDS_F32       fp64 steps (fused_step_f64_kernel) evaluate the LINK fields -- forward kinematics, self-distance and sphere fields -- on the packed-fp32 code of the fp32 launches, from the fp64 waypoint rounded to fp32; samples, means, GP / goal-prior / importance-sampling terms stay fp64.  Opt-in: the collision part of a cost then carries fp32's ~1e-6 relative error (~1e-9 of a total cost at the reference's hyper-parameters)
-    int no_small_tail;        // SGPMP_NO_SMALL_TAIL        small steps (fused_step_small_kernel): update_kernel behind the launch (round 5) instead of the update inside it, by the particle's last workgroup (fused_step.inc: lat_update_tail)
     int no_persist_planar;    // SGPMP_NO_PERSIST_PLANAR    sgpmp_optimize runs the store-free iterations of a planar S = 64 problem as one launch each (round 5) instead of ONE launch for all of them (fused_planar_seg.inc: PERSIST)
     int no_small_step;        // SGPMP_NO_SMALL_STEP        small steps through fused_step_kernel (one wave per item) instead of fused_step_small_kernel (one workgroup per item)
     long long small_step_items;   // SGPMP_SMALL_STEP_ITEMS     items (groups of 8 samples) up to which a step counts as small (0: default 512 -- two workgroups per CU -- for shapes on the launch's 8 x 16 grid, 256 for the others)
@@ -211,8 +210,6 @@ struct FusedDenseHost {
     double* stats_out;            // the step's statistics buffer or null
     void* weights; void* grad; void* means_prev;   // K4's optional outputs (context dtype)
     double step_size;
-    const ChainDev* d_chain;      // DEVICE chain (the end-effector goal term inside that update), or null
-    unsigned* arrive;             // [P] finished-item counters for the update inside fused_step_small_kernel (zero between launches), or null: not offered
     int tail_iters;               // > 1: the launch runs that many store-free iterations itself (fused_planar_seg.inc: PERSIST; sgpmp_optimize)
 };
 // bytes of one waypoint of all samples of a step above which a regenerating store-free step is faster than a storing one
@@ -242,7 +239,7 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& prior, con
                              const void* isw, double* zero_stats, void* costs, double* costs64,
                              hipStream_t stream, const SgpmpToggles& tg, const char** picked, bool* launched,
                              const FusedDenseHost* dense = nullptr, bool* partials_armed = nullptr, RegenHost* regen = nullptr,
-                             bool* tail_ran = nullptr, bool* tail_storing = nullptr);   // *tail_ran: the launch also updated its particles (no update_kernel behind it)
+                             bool* tail_ran = nullptr);   // *tail_ran: the launch also updated its particles (no update_kernel behind it)
 // the recipe update_kernel would need to regenerate this step's rows (0: the step's launch cannot run store-free)
 int fused_step_regen_recipe(int dtype, int n, int T, const PriorDev& prior, const CostProgram& h_prog, const ChainDev& h_chain,
                             int P, int mode_offset, int S, int n_spheres, const SgpmpToggles& tg, int* seg_len);

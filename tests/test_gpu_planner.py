@@ -1393,44 +1393,6 @@ def test_small_step_launch_equals_the_one_wave_per_item_launch_bitwise(shape):
     assert a._engine.last_cost_kernel() == ("fused_step_small_kernel" if shape == "one_particle" else "fused_step_kernel")
 
 
-@pytest.mark.parametrize("shape", ["example", "ragged", "soft_weights", "one_particle"])
-def test_small_step_update_inside_the_launch_equals_update_kernel_bitwise(shape):
-    """Round 6: a small storing step is ONE launch -- the particle's last workgroup to finish runs update_kernel's body itself
-    (fused_step.inc: lat_update_tail; release / count / acquire, nobody waits).  Against the same launch with update_kernel behind
-    it (option no_small_tail) and against the one-wave launch + update_kernel: everything a caller sees bit for bit, the
-    statistics to rounding, the row counts, and the NEXT step's importance-sampling weights (the following step is `prepared`)."""
-    sph = torch.as_tensor(SC.panda_spheres(num=5, seed=29)).to(**F32)
-    cfg, args, calls = SC.PANDA, (64, 5, 32), (1, 1, 3, 1)
-    if shape == "ragged":
-        args = (50, 7, 27)
-    elif shape == "soft_weights":
-        cfg = dict(SC.PANDA, temperature=1e14, sigma_start_sample=1.0, sigma_goal_sample=1.0, sigma_gp_sample=30.0)
-        args, calls = (32, 6, 64), (1, 1, 4, 2)
-    elif shape == "one_particle":
-        args = (16, 1, 8)
-    T, nppg, S = args
-    a, b, c = (hip_panda_planner(cfg, T, nppg, S, F32, seed=83, store_free=False) for _ in range(3))
-    a._engine.set_option("no_small_step", 0)
-    b._engine.set_option("no_small_step", 0)
-    b._engine.set_option("no_small_tail", 1)
-    for call, k in enumerate(calls):
-        ra, rb, rc = (p.optimize(opt_iters=k, obstacle_spheres=sph) for p in (a, b, c))
-        assert a._engine.last_cost_kernel() == b._engine.last_cost_kernel() == "fused_step_small_kernel"
-        if call > 0 or k > 1:        # (a planner's very first step also computes its importance-sampling weights: K5, one launch more)
-            assert a._engine.last_step_launches() == 1 and b._engine.last_step_launches() == 2 and c._engine.last_step_launches() == 2
-        for other, ro in ((b, rb), (c, rc)):
-            for i, (x, y) in enumerate(zip(ra, ro)):
-                assert torch.equal(x, y), (k, i)
-            for nm in ("particle_means", "state_samples", "_weights_buf", "_grad", "_costs", "_means_prev"):
-                assert torch.equal(getattr(a, nm), getattr(other, nm)), (k, nm)
-            assert (a._engine.row_counts() == other._engine.row_counts()).all()
-            sa, so = a.global_stats(), other.global_stats()
-            assert abs(sa[0] / so[0] - 1) < 1e-12 and abs(sa[1] / so[1] - 1) < 1e-12
-    assert a._engine.store_free_steps() == 0
-    if shape == "soft_weights":
-        assert a._engine.dense_armed_steps() > 0 and int(a._engine.row_counts().max()) > 16
-
-
 def test_small_step_launch_costs_bitwise_over_many_seeds():
     """The rare event the shapes above could miss: the small-step launch once ran the MASKED instantiation for every shape, and
     against the unmasked one-wave-per-item launch of an on-grid shape ~0.1 % of the costs came out one ulp apart (hipcc pairs the
