@@ -139,6 +139,7 @@ void sgpmp_destroy(sgpmp_ctx* ctx);
  * no_planar_tail (those steps with update_kernel behind the launch instead),
  * no_persist_planar (sgpmp_optimize runs the store-free iterations of such a problem one launch each, as round 5 did, instead of
  * all of them in ONE launch: bit-identical, 1.4 x slower per iteration at BASELINE configs[1]),
+ * persist_max_iters (count: iterations one such launch runs at most; 0: 2048 -- a longer call takes several launches),
  * no_ee_fold (the step's end-effector goal term by a launch of ee_goal_kernel in front of update_kernel, as in rounds 1-4, instead of
  * inside update_kernel: same numbers, one launch more),
  * no_small_step (steps of up to small_step_items items -- groups of 8 samples; default 512, two per CU, 256 for shapes off the

@@ -128,6 +128,7 @@ static void toggles_from_env(SgpmpToggles& tg) {
     if (const char* e = getenv("SGPMP_PIPE_SPLIT")) tg.pipe_split = atoll(e);
     if (const char* e = getenv("SGPMP_STORE_FREE_MIN_BYTES")) tg.store_free_min_bytes = atoll(e);
     if (const char* e = getenv("SGPMP_SMALL_STEP_ITEMS")) tg.small_step_items = atoll(e);
+    if (const char* e = getenv("SGPMP_PERSIST_MAX_ITERS")) tg.persist_max_iters = atoll(e);
 }
 
 #ifdef SGPMP_HOST_TIMING      // diagnostic build (tools/host_step_cost.py): host nanoseconds of sgpmp_step's segments, printed by sgpmp_destroy
@@ -225,6 +226,7 @@ extern "C" int sgpmp_set_option(sgpmp_ctx* c, const char* name, long long value)
     if (std::strcmp(name, "pipe_split") == 0) { c->tg.pipe_split = value; return SGPMP_OK; }
     if (std::strcmp(name, "store_free_min_bytes") == 0) { c->tg.store_free_min_bytes = value; return SGPMP_OK; }
     if (std::strcmp(name, "small_step_items") == 0) { c->tg.small_step_items = value; return SGPMP_OK; }
+    if (std::strcmp(name, "persist_max_iters") == 0) { c->tg.persist_max_iters = value; return SGPMP_OK; }
     for (const auto& t : kToggleNames)
         if (std::strcmp(name, t.name) == 0) { c->tg.*(t.flag) = value != 0; return SGPMP_OK; }
     return fail(SGPMP_EINVAL, std::string("sgpmp_set_option: unknown option ") + name);
@@ -1420,17 +1422,21 @@ extern "C" int sgpmp_optimize(sgpmp_ctx* c, int opt_iters, uint64_t seed, uint64
             inner = opt_iters - 1;
     }
     if (piped && (rc = sgpmp_pipeline_begin(c, stream)) != SGPMP_OK) return rc;
+    // (a launch runs persist_max_iters iterations at most -- 2048: ~25 ms at BASELINE configs[1], far below anything a driver
+    // would call a hang; a longer call takes several such launches, a single left-over iteration an ordinary store-free step)
+    const long long cap = c->tg.persist_max_iters >= 2 ? c->tg.persist_max_iters : 2048;
     for (int k = 0; k < opt_iters; ++k) {
         const bool last = k == opt_iters - 1;
-        if (k == 0 && inner >= 2) {
-            // iterations 0 .. inner - 1 (draws draw0 .. draw0 + inner - 1) in one launch; no statistics of theirs are formed
-            c->tail_iters_next = inner;
-            rc = sgpmp_step(c, seed, draw0, nullptr, 0, 0, means, samples, costs, weights, grad, means_prev_scratch, spheres,
-                            n_spheres, temperature, step_size, nullptr,
-                            ((flags & SGPMP_STEP_MEANS_KEPT) ? SGPMP_STEP_MEANS_KEPT : 0) | SGPMP_STEP_NO_SAMPLES, stream);
+        if (inner - k >= 2) {
+            // iterations k .. k + n - 1 (draws draw0 + k ...) in one launch; no statistics of theirs are formed
+            const int n = (int)((long long)(inner - k) < cap ? (long long)(inner - k) : cap);
+            c->tail_iters_next = n;
+            rc = sgpmp_step(c, seed, draw0 + (uint64_t)k, nullptr, 0, 0, means, samples, costs, weights, grad, means_prev_scratch,
+                            spheres, n_spheres, temperature, step_size, nullptr,
+                            ((k > 0 || (flags & SGPMP_STEP_MEANS_KEPT)) ? SGPMP_STEP_MEANS_KEPT : 0) | SGPMP_STEP_NO_SAMPLES, stream);
             c->tail_iters_next = 0;
             if (rc != SGPMP_OK) break;
-            k = inner - 1;
+            k += n - 1;
             continue;
         }
         const int f = ((k > 0 || (flags & SGPMP_STEP_MEANS_KEPT)) ? SGPMP_STEP_MEANS_KEPT : 0) |

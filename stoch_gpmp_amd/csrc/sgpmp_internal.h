@@ -127,6 +127,7 @@ struct SgpmpToggles {
     int f64_fields_f32;       // SGPMP_F64_FIELDS_F32       fp64 steps (fused_step_f64_kernel) evaluate the LINK fields -- forward kinematics, self-distance and sphere fields -- on the packed-fp32 code of the fp32 launches, from the fp64 waypoint rounded to fp32; samples, means, GP / goal-prior / importance-sampling terms stay fp64.  Opt-in: the collision part of a cost then carries fp32's ~1e-6 relative error (~1e-9 of a total cost at the reference's hyper-parameters)
     int no_persist_planar;    // SGPMP_NO_PERSIST_PLANAR    sgpmp_optimize runs the store-free iterations of a planar S = 64 problem as one launch each (round 5) instead of ONE launch for all of them (fused_planar_seg.inc: PERSIST)
     int no_small_step;        // SGPMP_NO_SMALL_STEP        small steps through fused_step_kernel (one wave per item) instead of fused_step_small_kernel (one workgroup per item)
+    long long persist_max_iters;  // SGPMP_PERSIST_MAX_ITERS    iterations ONE launch of fused_planar_seg_kernel<.., PERSIST> runs at most (0: 2048 -- ~25 ms at BASELINE configs[1]: a launch must stay far below the driver's hang detection); longer calls take several such launches
     long long small_step_items;   // SGPMP_SMALL_STEP_ITEMS     items (groups of 8 samples) up to which a step counts as small (0: default 512 -- two workgroups per CU -- for shapes on the launch's 8 x 16 grid, 256 for the others)
     long long store_free_min_bytes;   // SGPMP_STORE_FREE_MIN_BYTES  a store-free step that REGENERATES rows in update_kernel is taken when one waypoint of all the step's samples (P S 2n floats) has at least this many bytes (0: the measured break-even, SGPMP_STORE_FREE_BREAK_EVEN; 1: always)
     long long pipe_split;     // SGPMP_PIPE_SPLIT           first chain's share of the particles in 16ths (0 = default 8)
