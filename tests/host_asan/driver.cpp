@@ -13,6 +13,9 @@
 #include "sgpmp.h"
 
 extern "C" int stub_hip_live_objects(void);
+extern "C" int stub_launch_log(int i, unsigned long long* draw, int* iters);   // stub_launchers.cpp: every fused launch's (draw, iterations)
+extern "C" void stub_launch_log_clear();
+static int g_multi = 0;                                // launches of several iterations seen by the checks below
 extern "C" int hipMalloc(void**, size_t);
 extern "C" int hipFree(void*);
 
@@ -129,6 +132,28 @@ static void run_planner(int n, int T, int P, int P_global, int offset, int S, in
                              1.0, 0.1, (double*)stats2.p, 1, SGPMP_STEP_MEANS_KEPT | SGPMP_OPT_PIPELINE | SGPMP_OPT_STORE_FREE, nullptr));
         CHECK(sgpmp_optimize(c, 2, 7, 306, means.p, samples.p, costs.p, nullptr, nullptr, nullptr, nullptr, n_sph ? sph.p : nullptr, n_sph,
                              1.0, 0.1, nullptr, 0, SGPMP_OPT_STORE_FREE, nullptr));
+        // the call's iterations, however sgpmp_optimize cuts them into launches (several iterations per launch where the launch
+        // has that form -- STUB_PERSIST -- and at most `persist_max_iters` of them): every draw counter exactly once, in order
+        if (P > 0 && !mode_stats && !with_comm) {
+            for (long long cap : {0LL, 7LL, 2LL}) {
+                CHECK(sgpmp_set_option(c, "persist_max_iters", cap));
+                for (int K : {1, 2, 3, 8, 9, 16, 40}) {
+                    stub_launch_log_clear();
+                    CHECK(sgpmp_optimize(c, K, 7, 1000, means.p, samples.p, costs.p, weights.p, grad.p, prev.p, prev_last.p, n_sph ? sph.p : nullptr, n_sph,
+                                         1.0, 0.1, (double*)stats2.p, 0, SGPMP_STEP_MEANS_KEPT | SGPMP_OPT_STORE_FREE, nullptr));
+                    unsigned long long d = 0, next = 1000; int it = 0, total = 0;
+                    const int nl = stub_launch_log(-1, &d, &it);
+                    for (int i = 0; i < nl; ++i) {
+                        stub_launch_log(i, &d, &it);
+                        if (d != next || it < 1 || (cap >= 2 && it > cap)) { std::fprintf(stderr, "optimize(K=%d, cap %lld): launch %d has draw %llu x %d, expected draw %llu\n", K, cap, i, d, it, next); std::exit(6); }
+                        next += (unsigned long long)it; total += it;
+                        g_multi += it > 1 ? 1 : 0;
+                    }
+                    if (nl > 0 && total != K) { std::fprintf(stderr, "optimize(K=%d, cap %lld): %d iterations launched\n", K, cap, total); std::exit(6); }
+                }
+            }
+            CHECK(sgpmp_set_option(c, "persist_max_iters", 0));
+        }
         EXPECT(sgpmp_optimize(c, 0, 7, 0, means.p, samples.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0, 0.1, nullptr, 0, 0, nullptr), SGPMP_EINVAL);
         EXPECT(sgpmp_optimize(nullptr, 1, 7, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0, 0.1, nullptr, 0, 0, nullptr), SGPMP_EINVAL);
         CHECK(sgpmp_stats_wait(c, nullptr, nullptr));
@@ -209,11 +234,13 @@ int main() {
     //           n   T   P   Pglobal off  S   G  dtype      comm   mode   steps
     run_planner(2, 16, 6, 6, 0, 8, 2, SGPMP_F64, false, false, 3);
     run_planner(2, 32, 64, 64, 0, 64, 4, SGPMP_F32, comm, true, 20);
+    run_planner(2, 32, 16, 16, 0, 64, 2, SGPMP_F32, false, false, 5);         // planar-like, no communicator: optimize() may put several iterations into one launch
     run_planner(3, 16, 5, 40, 35, 8, 1, SGPMP_F32, comm, false, 11);        // the last shard of a ragged split
     run_planner(7, 16, 1024, 1024, 0, 8, 1, SGPMP_F32, comm, false, 10);      // big enough for two particle-half chains
     run_planner(7, 16, 0, 3, 3, 8, 1, SGPMP_F32, comm, true, 10);             // an empty shard still joins the collectives
     const int live = stub_hip_live_objects();
     if (live != 0) { std::fprintf(stderr, "%d streams / events / device buffers outlived their contexts\n", live); return 7; }
+    std::printf("MULTI_ITERATION_LAUNCHES %d\n", g_multi);
     std::printf("HOST_ASAN_OK\n");
     return 0;
 }

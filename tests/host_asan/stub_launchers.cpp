@@ -70,12 +70,24 @@ int fused_step_regen_recipe(int dtype, int n, int T, const PriorDev& pr, const C
     return fused_step_eligible(dtype, n, T, pr, prog, ch, P, off, S, ns, tg) && prog.n_ee == 0 ? 1 : 0;
 }
 bool planar_seg_step(int, int, int, const PriorDev&, const CostProgram&, const ChainDev&, int, int, int, int, const SgpmpToggles&) { return false; }
-bool planar_persist_step(int, int, int, const PriorDev&, const CostProgram&, const ChainDev&, int, int, int, int, const SgpmpToggles&) { return false; }
+// STUB_PERSIST=1 (with STUB_FUSED, STUB_TAIL): as if the launch could run several iterations (fused_planar_seg.inc: PERSIST) --
+// sgpmp_optimize's chunking of a call is then exercised on the host; every fused launch is logged (draw, iterations) for the driver
+bool planar_persist_step(int dtype, int n, int T, const PriorDev& pr, const CostProgram& prog, const ChainDev& ch, int P, int off, int S, int ns, const SgpmpToggles& tg) {
+    return env1("STUB_PERSIST") && env1("STUB_TAIL") && !tg.no_persist_planar && fused_step_eligible(dtype, n, T, pr, prog, ch, P, off, S, ns, tg) && prog.n_ee == 0 &&
+           update_regen_rows(dtype, n, T, S, 1) > 0;
+}
+static unsigned long long g_log_draw[4096];
+static int g_log_iters[4096], g_log_n = 0;
+extern "C" int stub_launch_log(int i, unsigned long long* draw, int* iters) {     // entry i of the log; returns the number of entries
+    if (i >= 0 && i < g_log_n) { *draw = g_log_draw[i]; *iters = g_log_iters[i]; }
+    return g_log_n;
+}
+extern "C" void stub_launch_log_clear() { g_log_n = 0; }
 bool planar_tail_step(int, int, int, const PriorDev&, const CostProgram&, const ChainDev&, int, int, int, int, const SgpmpToggles&) { return false; }
 bool fused_step_eligible(int dtype, int, int T, const PriorDev&, const CostProgram&, const ChainDev&, int P, int, int S, int, const SgpmpToggles& tg) {
     return env1("STUB_FUSED") && dtype == SGPMP_F32 && !tg.no_fused_step && T % 16 == 0 && S % 8 == 0 && P > 0;
 }
-hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& pr, const CostProgram& prog, const ChainDev& ch, uint64_t, uint64_t, const void* means,
+hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& pr, const CostProgram& prog, const ChainDev& ch, uint64_t, uint64_t draw, const void* means,
                              int P, int off, int S, void* samples, const void* spheres, int ns, const void* isw, double* zero_stats, void* costs,
                              double* c64, hipStream_t, const SgpmpToggles& tg, const char** picked, bool* launched, const FusedDenseHost* dense,
                              bool* armed, RegenHost* regen, bool* tail_ran) {
@@ -104,6 +116,8 @@ hipError_t launch_fused_step(int dtype, int n, int T, const PriorDev& pr, const 
         wr(dense->means_prev, (size_t)P * M * 4); wr(const_cast<void*>(isw), (size_t)P * (T + 1) * 2 * n * 4); wr(dense->nnz, (size_t)P * 4, 1);
         *tail_ran = true;
     }
+    if (dense && dense->tail_iters > 1 && !(tail_ran && *tail_ran)) return hipErrorInvalidValue;   // (as the real launcher: the caller asks planar_persist_step first)
+    if (g_log_n < 4096) { g_log_draw[g_log_n] = draw; g_log_iters[g_log_n] = (dense && dense->tail_iters > 1) ? dense->tail_iters : 1; ++g_log_n; }
     if (picked) *picked = "stub_fused";
     return hipSuccess;
 }

@@ -477,10 +477,13 @@ def test_host_bookkeeping_under_address_and_ub_sanitizers(tmp_path):
     for extra in ({}, {"SGPMP_RCCL_LIB": fake}, {"SGPMP_RCCL_LIB": fake, "STUB_FUSED": "1", "STUB_EVENT_LAG": "1"},
                   {"STUB_FUSED": "1", "SGPMP_NO_STEP_PIPELINE": "1"}, {"STUB_FUSED": "1", "SGPMP_NO_DENSE_PARTIALS": "1"},
                   {"STUB_FUSED": "1", "STUB_TAIL": "1"}, {"SGPMP_RCCL_LIB": fake, "STUB_FUSED": "1", "STUB_TAIL": "1"},
+                  {"STUB_FUSED": "1", "STUB_TAIL": "1", "STUB_PERSIST": "1"},      # several iterations per launch: sgpmp_optimize's chunking
                   {"STUB_FUSED": "1", "SGPMP_NO_EE_FOLD": "1"}):
         p = subprocess.run([exe], env=dict(base, **extra), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "HOST_ASAN_OK" in p.stdout, (extra, p.stdout[-1000:], p.stderr[-4000:])
         assert "Sanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
+        multi = int(p.stdout.split("MULTI_ITERATION_LAUNCHES")[1].split()[0])
+        assert (multi > 0) == ("STUB_PERSIST" in extra), (extra, multi)
     p = subprocess.run([exe], env=dict(base, HOST_ASAN_INJECT="1"), capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and "AddressSanitizer" in p.stderr, "the harness did not notice a short buffer"
     shutil.rmtree(b, ignore_errors=True)
