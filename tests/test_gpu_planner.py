@@ -393,6 +393,39 @@ def test_planar_fp32_means_match_fp64_oracle_native_noise(golden):
     assert np.mean(fr) >= 0.99                         # measured: 1.0000 (arg-min identical for 99.7 %)
 
 
+def test_planar_one_call_of_several_iterations_against_the_oracle(golden):
+    """Round 6: optimize(opt_iters = K) of a planar problem with 64 samples per particle runs iterations 0 .. K - 2 in ONE launch
+    (fused_planar_seg.inc: PERSIST) -- nothing of them is visible from outside, so the oracle meets the call's END state: K free
+    iterations of the fp64 oracle from the same means on the restated noise stream (draws 2 .. 2 + K - 1), particle for particle.
+    (fp32 against fp64 over K free iterations: a particle whose two best samples tie to fp32 rounding takes the other one and
+    leaves -- the tests above count such flips; here: >= 97 % of the particles within 1e-3 after 6 iterations.)"""
+    from oracle.native_noise import native_eps
+    z = golden("g2_planar_e2e.npz")
+    T, nppg, S, n, seed, K = 64, 16, 64, 2, 9, 6
+    goals = z["goals"]
+    G = len(goals)
+    P = G * nppg
+    eps0 = torch.from_numpy(native_eps(seed, 0, range(G), nppg, T, n, "float32")).double()
+    ora = SC.oracle_planar_planner(SC.PLANAR, T, goals, nppg, S, z["grid"], float(z["cell_size"]),
+                                   z["c_offset"], seed=seed, eps_init=eps0)
+    pl = hip_planar_planner(SC.PLANAR, T, goals, nppg, S, planar_map(golden, F32), F32, seed=seed)
+    ora.particle_means.copy_(pl.particle_means.cpu().double())
+    ora.prior.set_mean(ora.particle_means.view(P, -1))
+    scale = float(ora.particle_means.abs().max())
+    _, _, _, _, costs, _ = pl.optimize(opt_iters=K)
+    assert pl._engine.last_cost_kernel() == "fused_planar_seg_kernel" and pl._engine.multi_iteration_launches() == 1
+    assert pl._engine.store_free_steps() == K - 1
+    for it in range(K):
+        eps = torch.from_numpy(native_eps(seed, 2 + it, range(P), S, T, n, "float32")).double()
+        costs_o, _ = ora.step(eps=eps)
+    d = (pl.particle_means.cpu().double() - ora.particle_means).abs().amax(dim=(1, 2)) / scale
+    frac = float((d < 1e-3).double().mean())
+    same = float((costs.cpu().argmin(1) == costs_o.argmin(1)).double().mean())
+    print(f"\n[fp32 parity] planar {P} x {S} x {T}, one call of {K} iterations: particles within 1e-3 of the oracle's free run: {frac:.4f}; "
+          f"same arg-min in the last iteration {same:.4f}; median departure {float(d.median()):.2e}")
+    assert frac >= 0.97 and float(d.median()) < 1e-5
+
+
 # --------------------------------------------------------------------------- BASELINE's stated sizes, directly
 # The tests above meet the oracle in miniature and carry the result to the full sizes through kernel-vs-kernel
 # identities.  These run the HIP planner AT the sizes BASELINE.json states and check its particles directly against the
