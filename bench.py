@@ -158,7 +158,8 @@ def compact_line(full):
     opt("per_rank_iterations_per_s", full.get("per_rank_iterations_per_s"))
     opt("last_iteration", _clean(full.get("last_iteration")))
     opt("sweep_alone_frac", _clean((full.get("sweep_alone") or {}).get("frac"), 4))
-    opt("sweep_alone", _pick(full.get("sweep_alone"), ("kernel", "launch_ms", "frac", "launch_ms_rocprof", "frac_rocprof",
+    opt("sweep_in_step_frac", _clean((full.get("sweep_alone") or {}).get("in_step_frac"), 4))
+    opt("sweep_alone", _pick(full.get("sweep_alone"), ("kernel", "launch_ms", "frac", "in_step_launch_ms", "in_step_frac", "launch_ms_rocprof", "frac_rocprof",
                                                        "sampler_kernel", "sampler_launch_ms", "sampler_frac"), 4))
     opt("mode", full.get("mode"))
     opt("field", full.get("field"))
@@ -370,6 +371,21 @@ def sweep_alone_leg(torch, pl, obs, N_elems, w, costs_bytes, reps=60, config_key
     kernel = eng.last_cost_kernel()
     samp_ms = timed(sampler)
     pl.optimize(opt_iters=1, **obs)                        # (the planner's buffers hold a step's tensors again)
+    # ... and the same kernel where a planner runs it as a launch of its own: inside two-launch STEPS (sampler, sweep, update, one
+    # after the other -- option no_fused_step), timed by the context's HIP events around each kernel.  There the sweep reads rows
+    # the sampler has just written (part of them still in the 256 MB of last-level cache); `reps` launches back to back on ONE
+    # tensor stream it from HBM every time -- the harder case, reported beside it.
+    in_step = None
+    try:
+        eng.set_option("no_fused_step", 1)
+        for _ in range(5):
+            pl.optimize(opt_iters=1, **obs)
+        kms = kernel_profile(torch, pl, obs, 40)
+        if eng.last_cost_kernel() == kernel:
+            in_step = {"sweep_ms": kms["cost_sweep"], "sampler_ms": kms.get("sample"), "update_ms": kms.get("update"), "steps": 40}
+    finally:
+        eng.set_option("no_fused_step", 0)
+        pl.optimize(opt_iters=1, **obs)
     # beside the live figure (launches back to back: the clock a chip holds under nothing but this kernel), the committed
     # rocprofv3 duration of the same kernel inside a loop of two-launch steps (profiles/rNN: <config>_unfused)
     k, src = profiled(config_key + "_unfused", kernel) if config_key else (None, None)
@@ -378,6 +394,10 @@ def sweep_alone_leg(torch, pl, obs, N_elems, w, costs_bytes, reps=60, config_key
             "launch_ms_rocprof": prof_ms, "rocprof_source": src,
             "frac_rocprof": ((N_elems * w + costs_bytes) / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if prof_ms else None,
             "frac": (N_elems * w + costs_bytes) / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "in_step_launch_ms": in_step["sweep_ms"] if in_step else None,
+            "in_step_frac": ((N_elems * w + costs_bytes) / (in_step["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if in_step else None,
+            "in_step": in_step,
+            "in_step_how": "HIP events of the context around each kernel of 40 two-launch steps (sampler, sweep, update; option no_fused_step)",
             "sampler_kernel": "sample_iso_kernel", "sampler_launch_ms": samp_ms,
             "sampler_frac": N_elems * w / (samp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_timed": reps,
             "how": "launches back to back between two HIP events on the launch stream"}
