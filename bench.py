@@ -372,9 +372,9 @@ def sweep_alone_leg(torch, pl, obs, N_elems, w, costs_bytes, reps=60, config_key
     samp_ms = timed(sampler)
     pl.optimize(opt_iters=1, **obs)                        # (the planner's buffers hold a step's tensors again)
     # ... and the same kernel where a planner runs it as a launch of its own: inside two-launch STEPS (sampler, sweep, update, one
-    # after the other -- option no_fused_step), timed by the context's HIP events around each kernel.  There the sweep reads rows
-    # the sampler has just written (part of them still in the 256 MB of last-level cache); `reps` launches back to back on ONE
-    # tensor stream it from HBM every time -- the harder case, reported beside it.
+    # after the other -- option no_fused_step), timed by the context's HIP events around each kernel.  (`reps` launches of nothing
+    # but this kernel run into the chip's power limit: rocprofv3's per-dispatch trace shows the first dozen at 120 us and the rest
+    # at 151 us -- profiles/r06/sweep_series_trace.txt -- while between a sampler and an update the sweep keeps 120 us.)
     in_step = None
     try:
         eng.set_option("no_fused_step", 1)
